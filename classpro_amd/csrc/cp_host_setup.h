@@ -1,0 +1,183 @@
+// cp_host_setup.h -- one-time global setup on the host (the reference does this once in main(),
+// src/ClassPro.c:536-554): log-factorial table, global coverages, default error model and the
+// count-threshold table.  Pure host code (glibc log/exp/sqrt, like the reference); the result is
+// uploaded to HBM once and read by every kernel.
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <cstdlib>
+#include <vector>
+#include "cp_types.h"
+
+// hist.c:28-105 over the histogram as Load_Histogram + Modify_Histogram(H,low,high,0) leave it
+// (libfastk.c:22-147: interior cells become instance counts, boundary cells swap with the two
+// hidden cells).
+static inline int cp_host_hist_covs(const int64_t *disk, int low, int high, int64_t ilowcnt, int64_t ihighcnt,
+                                    int coverage_opt, int *hcov, int *dcov)
+{ if (coverage_opt > 0)                                   // hist.c:44-50
+    { *dcov = coverage_opt;
+      *hcov = coverage_opt >> 1;
+      return CP_OK;
+    }
+  if (low > 1 || high < 4 || high > (1 << 20))
+    return CP_EINVAL;
+  std::vector<int64_t> buf((size_t)(high-low)+3+4,0);
+  int64_t *hist = buf.data()-low;
+  memcpy(buf.data(),disk,sizeof(int64_t)*((size_t)(high-low)+1));
+  for (int i = low+1; i < high; i++)                      // toggle to instance counts
+    hist[i] *= i;
+  hist[high+1] = hist[low];   hist[low]  = ilowcnt;
+  hist[high+2] = hist[high];  hist[high] = ihighcnt;
+
+  int maxcnt = 0;
+  int64_t maxpk = 0;
+  const int lo = low > 2 ? low : 2, hi = high < 1000 ? high : 1000;
+  for (int i = lo; i < hi; i++)                           // tallest strict local maximum, hist.c:58-64
+    if (hist[i-1] < hist[i] && hist[i] > hist[i+1] && maxpk < hist[i])
+      { maxcnt = i;
+        maxpk = hist[i];
+      }
+  if (maxcnt < 10)
+    return CP_ENOPEAK;
+
+  int lmaxcnt = 0, rmaxcnt = 0, is_lpeak = 0, is_rpeak = 0;
+  int64_t lmaxpk = 0, rmaxpk = 0;
+  double m = (double)maxcnt/2, s = sqrt(m);               // hist.c:75-85
+  for (int i = (int)round(m-s); i <= (int)round(m+s); i++)
+    if (lmaxpk < hist[i])
+      { lmaxcnt = i; lmaxpk = hist[i];
+        is_lpeak = (hist[i-1] < hist[i] && hist[i] > hist[i+1]);
+      }
+  m = (double)maxcnt*2; s = sqrt(m);                      // hist.c:87-97
+  for (int i = (int)round(m-s); i <= (int)round(m+s); i++)
+    if (rmaxpk < hist[i])
+      { rmaxcnt = i; rmaxpk = hist[i];
+        is_rpeak = (hist[i-1] < hist[i] && hist[i] > hist[i+1]);
+      }
+  if (lmaxpk > rmaxpk)                                    // hist.c:99-107
+    { *dcov = maxcnt;
+      *hcov = is_lpeak ? lmaxcnt : (maxcnt >> 1);
+    }
+  else
+    { *hcov = maxcnt;
+      *dcov = is_rpeak ? rmaxcnt : (maxcnt << 1);
+    }
+  return CP_OK;
+}
+
+static inline int cp_host_fill_params(cp_dev_params *P, int K, int read_len, int hcov, int dcov)
+{ memset(P,0,sizeof(*P));
+  if (K < 2 || read_len < 1 || hcov < 1 || dcov < 1 || dcov > 65535)
+    return CP_EINVAL;
+  P->K = K;
+  P->read_len = read_len;
+
+  P->logfact[0] = 0.;                                     // prob.c:14-19: running sum, not lgamma
+  P->logint[0] = log(0.0);
+  for (int n = 1; n <= CP_MAX_KMER_CNT; n++)
+    { P->logint[n]  = log((double)n);
+      P->logfact[n] = P->logfact[n-1]+log(n);
+    }
+
+  P->cov[CP_HAPLO]  = hcov & 0xffff;                      // ClassPro.c:544-548, util.c:9-11
+  P->cov[CP_DIPLO]  = dcov & 0xffff;
+  P->cov[CP_ERROR]  = 1;
+  P->cov[CP_REPEAT] = (P->cov[CP_DIPLO] + (int)(uint16_t)(sqrt((double)P->cov[CP_DIPLO]) * CP_N_SIGMA_RCOV)) & 0xffff;
+  P->dr_ratio = 1.+(double)CP_N_SIGMA_R*(1./sqrt((double)P->cov[CP_DIPLO]));
+  if (P->cov[CP_REPEAT] > 255)                            // wall.c:174-177
+    return CP_ERCOV;
+  P->cmax = P->cov[CP_REPEAT];
+
+  for (int t = 0; t < 3; t++)                             // default error model, wall.c:119-143
+    { P->lmax[t] = CP_MAX_N_LC/(t+1);
+      P->pe[t][0] = 0.;
+      P->lpe[t][0] = log(0.0);
+      P->l1mpe[t][0] = log(1.0);
+      for (int l = 1; l <= P->lmax[t]; l++)
+        { double pe = 0.002 * l * l + 0.002;
+          P->pe[t][l]    = pe;
+          P->lpe[t][l]   = log(pe);
+          P->l1mpe[t][l] = log(1-pe);
+        }
+    }
+  P->hc_erate = P->pe[CP_HP][1];                          // wall.c:180
+  P->hc_lpe   = log(P->hc_erate);
+  P->hc_l1mpe = log(1-P->hc_erate);
+  { double u = 0.1;                                       // class_unrel.c:137,155
+    P->u_lpe = log(u);
+    P->u_l1mpe = log(1-u);
+    double pr = 1-CP_PE_MEAN;                             // class_rel.c:185, class_unrel.c:104-105
+    P->r_lp = log(pr);
+    P->r_l1mp = log(1-pr);
+    P->log_pe_final = log(CP_PE_THRES_FINAL);             // wall.c:1018
+  }
+
+  const double thres[2][2] = { {CP_PE_THRES_INIT_S, CP_PE_THRES_INIT_O}, {CP_PE_THRES_FINAL, CP_PE_THRES_FINAL} };
+  for (int t = 0; t < 3; t++)                             // wall.c:190-224
+    for (int l = 1; l <= P->lmax[t]; l++)
+      { const double lpe = P->lpe[t][l], l1mpe = P->l1mpe[t][l];
+        for (int cout = 1; cout < P->cmax; cout++)
+          { bool found[2][2] = { {false,false}, {false,false} };
+            for (int s = 0; s < 2; s++)
+              { P->cthres[t][l][cout][s][CP_SELF]   = (uint8_t)cout;
+                P->cthres[t][l][cout][s][CP_OTHERS] = 0;
+              }
+            double psum = 1.;
+            for (int cin = 0; cin <= cout; cin++)
+              { if (found[0][0] && found[1][0] && found[0][1] && found[1][1])
+                  break;
+                const double *lf = P->logfact;
+                psum -= exp(lf[cout] - lf[cin] - lf[cout-cin] + cin * lpe + (cout-cin) * l1mpe);
+                for (int s = 0; s < 2; s++)
+                  for (int e = 0; e < 2; e++)
+                    if (!found[s][e] && psum < thres[s][e])
+                      { P->cthres[t][l][cout][s][e] = (uint8_t)(e == CP_SELF ? cin : cout-cin);
+                        found[s][e] = true;
+                      }
+              }
+          }
+      }
+  return CP_OK;
+}
+
+// libfastk.c:1467-1534 without the file-buffer refills.
+static inline int cp_host_decode_profile(const uint8_t *code, int64_t len, uint16_t *profile, int cap)
+{ if (len <= 0)
+    return 0;
+  const uint8_t *c = code, *q = code+len;
+  uint16_t x = *c++, d;
+  if (x & 0x80) d = (uint16_t)(((x & 0x7f) << 8) | *c++);
+  else          d = x;
+  int n = 1;
+  bool writing = cap > 0;                                 // the reference stops storing at the first item that
+  if (writing)                                            // does not fit and only counts from there on
+    profile[0] = d;
+  while (c < q)
+    { x = *c++;
+      if ((x & 0xc0) == 0)                                // 00rrrrrr: run of the current count
+        { if (writing && n+x > cap)
+            writing = false;
+          if (writing)
+            for (int i = 0; i < x; i++)
+              profile[n+i] = d;
+          n += x;
+        }
+      else
+        { if (x & 0x80)                                   // 1sxxxxxx yyyyyyyy: 15-bit delta
+            { x = (x & 0x40) ? (uint16_t)(x << 8) : (uint16_t)((x << 8) & 0x7fff);
+              x |= *c++;
+              d = (uint16_t)((d+x) & 0x7fff);
+            }
+          else if (x & 0x20)                              // 011xxxxx: negative 6-bit delta
+            d = (uint16_t)(d + ((x & 0x1fu) | 0xffe0u));
+          else                                            // 010xxxxx
+            d = (uint16_t)(d + (x & 0x1fu));
+          if (writing && n >= cap)
+            writing = false;
+          if (writing)
+            profile[n] = d;
+          n++;
+        }
+    }
+  return n;
+}

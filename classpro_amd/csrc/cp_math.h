@@ -1,0 +1,138 @@
+// cp_math.h -- scalar numeric primitives of the hot path as device functions.
+//   bessel.c:390-521 (bessi0/bessi1/bessi), prob.c:33-112, util.c:9-55 of the reference.
+// All arithmetic is IEEE double in the reference's evaluation order; the translation unit is built
+// with -ffp-contract=off so no FMA is formed.  log() of constants comes from host-built tables
+// (cp_dev_params); the device evaluates exp/log/sqrt only on data-dependent values.
+//
+// The functions are `__host__ __device__` only so that tests/ can unit-test them against the oracle
+// in a GPU-less container (tests/host_harness.cpp); the product never runs them on the CPU.
+#pragma once
+#include <math.h>
+#include "cp_types.h"
+
+#ifndef __HIPCC__
+#undef  CP_HD
+#define CP_HD static inline
+#endif
+
+// ---- bessel.c:390-411 ----------------------------------------------------------------------
+CP_HD double cp_bessi0(double x)
+{ double ax = fabs(x), y, ans;
+  if (ax < 3.75)
+    { y = x/3.75; y = y*y;
+      ans = 1.0+y*(3.5156229+y*(3.0899424+y*(1.2067492
+            +y*(0.2659732+y*(0.360768e-1+y*0.45813e-2)))));
+    }
+  else
+    { y = 3.75/ax;
+      ans = (exp(ax)/sqrt(ax))*(0.39894228+y*(0.1328592e-1
+            +y*(0.225319e-2+y*(-0.157565e-2+y*(0.916281e-2
+            +y*(-0.2057706e-1+y*(0.2635537e-1+y*(-0.1647633e-1
+            +y*0.392377e-2))))))));
+    }
+  return ans;
+}
+
+// ---- bessel.c:416-438 ----------------------------------------------------------------------
+CP_HD double cp_bessi1(double x)
+{ double ax = fabs(x), y, ans;
+  if (ax < 3.75)
+    { y = x/3.75; y = y*y;
+      ans = ax*(0.5+y*(0.87890594+y*(0.51498869+y*(0.15084934
+            +y*(0.2658733e-1+y*(0.301532e-2+y*0.32411e-3))))));
+    }
+  else
+    { y = 3.75/ax;
+      ans = 0.2282967e-1+y*(-0.2895312e-1+y*(0.1787654e-1
+            -y*0.420059e-2));
+      ans = 0.39894228+y*(-0.3988024e-1+y*(-0.362018e-2
+            +y*(0.163801e-2+y*(-0.1031555e-1+y*ans))));
+      ans *= (exp(ax)/sqrt(ax));
+    }
+  return x < 0.0 ? -ans : ans;
+}
+
+// ---- bessel.c:478-521: downward recurrence, 2*(n+(int)sqrt(40 n)) steps, 1e10 rescale ------
+CP_HD double cp_bessi(int n, double x)
+{ if (n == 0) return cp_bessi0(x);
+  if (n == 1) return cp_bessi1(x);
+  if (x == 0.0) return 0.0;
+  double tox = 2.0/fabs(x), bip = 0.0, ans = 0.0, bi = 1.0, bim;
+  for (int j = 2*(n+(int)sqrt(40.0*n)); j > 0; j--)
+    { bim = bip+j*tox*bi;
+      bip = bi;
+      bi  = bim;
+      if (fabs(bi) > 1.0e10)
+        { ans *= 1.0e-10; bi *= 1.0e-10; bip *= 1.0e-10; }
+      if (j == n) ans = bip;
+    }
+  ans *= cp_bessi0(x)/bi;
+  return (x < 0.0 && (n & 1)) ? -ans : ans;
+}
+
+// ---- prob.c:22-30: counts are cnt_t (uint16) clamped to MAX_KMER_CNT (DEBUG build) ---------
+CP_HD int cp_check_cnt(int n)
+{ n &= 0xffff;
+  return n > CP_MAX_KMER_CNT ? CP_MAX_KMER_CNT : n;
+}
+
+// ---- prob.c:33-39 ---------------------------------------------------------------------------
+CP_HD double cp_logp_poisson(const cp_dev_params *P, int k, int lambda)
+{ k = cp_check_cnt(k);
+  double ll = (lambda >= 0 && lambda <= CP_MAX_KMER_CNT) ? P->logint[lambda] : log((double)lambda);
+  return k * ll - lambda - P->logfact[k];
+}
+
+// ---- prob.c:41-44 ---------------------------------------------------------------------------
+CP_HD double cp_logp_skellam(int k, double lambda)
+{ return -2. * lambda + log(cp_bessi(k < 0 ? -k : k,2.*lambda)); }
+
+// ---- prob.c:59-73 with log(p), log(1-p) supplied ----------------------------------------------
+CP_HD double cp_logp_binom_pre(const cp_dev_params *P, int k, int n, double lpe, double l1mpe)
+{ k = cp_check_cnt(k);
+  n = cp_check_cnt(n);
+  const double *lf = P->logfact;
+  return lf[n] - lf[k] - lf[n-k] + k * lpe + (n-k) * l1mpe;
+}
+
+// ---- prob.c:76-112, exact == false ------------------------------------------------------------
+CP_HD double cp_binom_test_g(const cp_dev_params *P, int k, int n, double pe, double lpe, double l1mpe)
+{ k = cp_check_cnt(k);
+  n = cp_check_cnt(n);
+  const double mean = n * pe;
+  double s, p_first, p_curr;
+  if ((double)k >= mean)
+    { s = p_first = exp(cp_logp_binom_pre(P,k,n,lpe,l1mpe));
+      for (int x = k+1; x <= n; x++)
+        { s += p_curr = exp(cp_logp_binom_pre(P,x,n,lpe,l1mpe));
+          if (10 * p_curr < p_first)
+            break;
+        }
+    }
+  else
+    { s = p_first = (k == 0) ? 0. : exp(cp_logp_binom_pre(P,k-1,n,lpe,l1mpe));
+      for (int x = k-2; x >= 0; x--)
+        { s += p_curr = exp(cp_logp_binom_pre(P,x,n,lpe,l1mpe));
+          if (10 * p_curr < p_first)
+            break;
+        }
+      s = 1-s;
+    }
+  return s;
+}
+
+// ---- util.c:46-55 -----------------------------------------------------------------------------
+CP_HD double cp_p_errorin(const cp_dev_params *P, int e, double erate, double lpe, double l1mpe, int cout, int cin)
+{ return cp_binom_test_g(P,(e == CP_SELF) ? cin : cout-cin,cout,erate,lpe,l1mpe); }
+
+// ---- util.c:35-44 -----------------------------------------------------------------------------
+CP_HD double cp_logp_trans(const cp_dev_params *P, int b, int e, int cb, int ce, int cov)
+{ cov &= 0xffff;
+  int d = e-b;
+  if (d < 0) d = -d;
+  return cp_logp_skellam(ce-cb,(double)cov*d/P->read_len);
+}
+
+// ---- util.c:24-33 (positions are strictly ordered on every call path) -------------------------
+CP_HD double cp_linear_interpolation(int x, int pos1, int cnt1, int pos2, int cnt2)
+{ return (double)cnt1+((double)cnt2-cnt1)*(x-pos1)/(pos2-pos1); }

@@ -1,0 +1,422 @@
+// cp_wall.h -- scalar building blocks of wall detection (reference src/wall.c:264-958) as device
+// functions.  The HIP kernels in kernels.hip orchestrate them: dense per-position passes are
+// lane-parallel, the order-dependent candidate walk (wall.c:590-707) runs on one lane because each
+// candidate's outcome depends on the pair/memo state left by the previous ones.
+//
+// Per-read state lives in HBM scratch owned by the wave that processes the read:
+//   wall[plen+1]        flag byte per profile position (bit layout of wall.c:264-269)
+//   perror[plen+1][4]   memoised P(error) per position, [etype*2+wtype], -inf = unset (wall.c:310-315)
+//   eintvl/ointvl       E-/O-interval lists (ClassPro.h:153-157)
+// Index plen is reset like every other index (the reference leaves it stale, SURVEY.md hazard 1).
+#pragma once
+#include "cp_math.h"
+#include "cp_ctx.h"
+
+struct cp_read
+  { const cp_dev_params *P;
+    const uint16_t      *prof;
+    const char          *seq;
+    int                  plen, rlen;
+    uint8_t             *wall;
+    double              *perror;
+    cp_eintvl           *eintvl, *ointvl;
+    int                  ecap;
+    int                  eidx, oidx;
+    int                  overflow;
+  };
+
+#define CP_PERR(R,i,e,w) ((R)->perror[(size_t)(i)*4+(e)*2+(w)])
+#define CP_NEG_INF (-INFINITY)
+
+// wall.c:310-315
+CP_HD void cp_update_perror(cp_read *R, int i, int e, int w, int cout, int cin, double erate, double lpe, double l1mpe)
+{ if (CP_PERR(R,i,e,w) == CP_NEG_INF)
+    CP_PERR(R,i,e,w) = cp_p_errorin(R->P,e,erate,lpe,l1mpe,cout,cin);
+}
+
+// wall.c:317-322
+CP_HD double cp_logp_diff_pair(const cp_read *R, int i, int j)
+{ const uint16_t *pr = R->prof;
+  int n_drop = (int)pr[i-1]-pr[i];
+  int n_gain = (int)pr[j]-pr[j-1];
+  int cov    = pr[i-1] > pr[j] ? pr[i-1] : pr[j];
+  return cp_logp_trans(R->P,i,j,n_drop,n_gain,cov);
+}
+
+// wall.c:324-329
+CP_HD bool cp_cthres_ng(int e, int cin, int ct)
+{ return (e == CP_SELF) ? (cin >= ct) : (cin < ct); }
+
+// wall.c:331-507: find_gain (w == DROP: partner GAIN to the right of i) and find_drop (w == GAIN:
+// partner DROP to the left), folded into one routine by mirroring the index arithmetic.
+CP_HD bool cp_find_pair(cp_read *R, int i, int cout, int cin, int e, int w, int t, int l,
+                        double erate, double lpe, double l1mpe, cp_eintvl *out)
+{ const cp_dev_params *P = R->P;
+  const uint16_t *pr = R->prof;
+  const int plen = R->plen, K = P->K, CMAX = P->cmax;
+  const int ulen = t+1;
+  const bool right = (w == CP_DROP);
+  int n, j, max_j = -1, cout_j, cin_j;
+  double pe, max_pe = CP_NEG_INF;
+
+  // low-complexity partner (wall.c:345-378 / 432-467)
+  const int m = ulen*l;
+  n = 0;
+  while (true)
+    { int idx = right ? i+ulen*(n+1) : i-ulen*(n+1);
+      if (right ? (idx >= plen) : (idx <= 0))
+        break;
+      if (cp_ctx(R->seq,R->rlen,K,w,idx,t) != m+n+1)     // ctx[DROP] for find_gain, ctx[GAIN] for find_drop
+        break;
+      n++;
+    }
+  j = right ? (i+K-1)+n-m : (i-K+1)-n+m;
+  if (right ? (j <= i) : (j >= i))
+    return false;
+  if (right ? (j >= plen) : (j <= 0))
+    { j = right ? plen : 0;
+      pe = CP_PERR(R,i,e,w) * CP_PERR(R,i,e,w);
+    }
+  else
+    { if (right) { cin_j = pr[j-1]; cout_j = pr[j]; }
+      else       { cout_j = pr[j-1]; cin_j = pr[j]; }
+      pe = CP_NEG_INF;
+      if (cin_j <= cout_j
+          && !(cout_j < CMAX && cp_cthres_ng(e,cin_j,P->cthres[t][l][cout_j][CP_FINAL][e]))
+          && (e == CP_SELF || (right ? cp_logp_diff_pair(R,i,j) : cp_logp_diff_pair(R,j,i)) >= CP_THRES_DIFF_EO))
+        { cp_update_perror(R,j,e,1-w,cout_j,cin_j,erate,lpe,l1mpe);
+          pe = right ? CP_PERR(R,i,e,CP_DROP)*CP_PERR(R,j,e,CP_GAIN)
+                     : CP_PERR(R,j,e,CP_DROP)*CP_PERR(R,i,e,CP_GAIN);
+        }
+    }
+  if (max_pe < pe)
+    { max_j  = j;
+      max_pe = pe;
+    }
+
+  // high-complexity partners (wall.c:380-404 / 469-493)
+  bool   have_pe_i = false;
+  double pe_i = 0.;
+  for (n = 0; n <= CP_MAX_N_HC; n++)
+    { j = right ? (i+K-1)+n : (i-K+1)-n;
+      if (right ? (j >= plen) : (j <= 0))
+        break;
+      if (right) { cin_j = pr[j-1]; cout_j = pr[j]; }
+      else       { cout_j = pr[j-1]; cin_j = pr[j]; }
+      if (!(cin_j <= cout_j))
+        continue;
+      if ((cout < CMAX && cp_cthres_ng(e,cin,P->cthres[CP_HP][1][cout][CP_FINAL][e]))
+          || (cout_j < CMAX && cp_cthres_ng(e,cin_j,P->cthres[CP_HP][1][cout_j][CP_FINAL][e])))
+        continue;
+      if (e == CP_OTHERS && (right ? cp_logp_diff_pair(R,i,j) : cp_logp_diff_pair(R,j,i)) < CP_THRES_DIFF_EO)
+        continue;
+      if (!have_pe_i)                                   // same arguments every time (wall.c:398)
+        { pe_i = cp_p_errorin(P,e,P->hc_erate,P->hc_lpe,P->hc_l1mpe,cout,cin);
+          have_pe_i = true;
+        }
+      double pe_j = cp_p_errorin(P,e,P->hc_erate,P->hc_lpe,P->hc_l1mpe,cout_j,cin_j);
+      pe = pe_i * pe_j;
+      if (max_pe < pe)
+        { max_j  = j;
+          max_pe = pe;
+        }
+    }
+
+  if (max_j == -1)
+    return false;
+  if (right) { out->b = i;     out->e = max_j; }
+  else       { out->b = max_j; out->e = i;     }
+  out->pe = max_pe;
+  return true;
+}
+
+// One iteration of the candidate walk, wall.c:590-707, for a position i that passed the scan
+// (min(c[i-1],c[i]) < R and |c[i-1]-c[i]| >= 3).
+CP_HD void cp_wall_candidate(cp_read *R, int i)
+{ const cp_dev_params *P = R->P;
+  const int CMAX = P->cmax;
+  const int cim1 = R->prof[i-1], ci = R->prof[i];
+  int cng = cim1-ci;
+  if (cng < 0) cng = -cng;
+  int wtype, cin, cout;
+  if (cim1 > ci) { wtype = CP_DROP; cin = ci;   cout = cim1; }
+  else           { wtype = CP_GAIN; cin = cim1; cout = ci;   }
+
+  int maxt = -1, maxl = -1;                              // wall.c:624-634
+  double maxpe = CP_NEG_INF;
+  for (int t = 0; t < 3; t++)
+    { int l = cp_ctx(R->seq,R->rlen,P->K,wtype,i,t);
+      if (l > P->lmax[t]) l = P->lmax[t];
+      double pe = P->pe[t][l];
+      if (maxpe < pe)
+        { maxpe = pe; maxt = t; maxl = l; }
+    }
+  const double lpe = P->lpe[maxt][maxl], l1mpe = P->l1mpe[maxt][maxl];
+
+  int ct_init = 0, ct_final = 0;
+  for (int e = CP_SELF; e <= CP_OTHERS; e++)            // wall.c:638-691
+    { if (R->wall[i] & (e == CP_SELF ? CP_W_PAIRED_S : CP_W_PAIRED_O))
+        continue;
+      if (cout < CMAX)
+        { ct_init  = P->cthres[maxt][maxl][cout][CP_INIT][e];
+          ct_final = P->cthres[maxt][maxl][cout][CP_FINAL][e];
+          if (!(cng > CP_MAX_CNT_CHANGE || cin < (ct_init > 3 ? ct_init : 3)))
+            continue;
+        }
+      if (e == CP_SELF)
+        { if (cout < CMAX && cin >= ct_final)
+            continue;
+          cp_update_perror(R,i,e,wtype,cout,cin,maxpe,lpe,l1mpe);
+          if (CP_PERR(R,i,e,wtype) < CP_PE_THRES_FINAL)
+            continue;
+          cp_eintvl I;
+          if (cp_find_pair(R,i,cout,cin,e,wtype,maxt,maxl,maxpe,lpe,l1mpe,&I) && I.pe >= CP_PE_THRES_FINAL)
+            { R->wall[I.b] |= (CP_W_WALL_S|CP_W_PAIRED_S);
+              R->wall[I.e] |= (CP_W_WALL_S|CP_W_PAIRED_S);
+              if (R->eidx < R->ecap) R->eintvl[R->eidx++] = I;
+              else R->overflow = 1;
+            }
+        }
+      else
+        { if (cng >= P->cov[CP_HAPLO] || (cout < CMAX && cin < ct_final))
+            { R->wall[i] |= CP_W_WALL_O;
+              continue;
+            }
+          cp_update_perror(R,i,e,wtype,cout,cin,maxpe,lpe,l1mpe);
+          if (CP_PERR(R,i,e,wtype) < CP_PE_THRES_FINAL)
+            { R->wall[i] |= CP_W_WALL_O;
+              continue;
+            }
+          cp_eintvl I;
+          if (cp_find_pair(R,i,cout,cin,e,wtype,maxt,maxl,maxpe,lpe,l1mpe,&I) && I.pe >= CP_PE_THRES_FINAL)
+            { R->wall[I.b] |= CP_W_PAIRED_O;
+              R->wall[I.e] |= CP_W_PAIRED_O;
+              if (R->oidx < R->ecap) R->ointvl[R->oidx++] = I;
+              else R->overflow = 1;
+              continue;
+            }
+          R->wall[i] |= CP_W_WALL_O;
+        }
+    }
+}
+
+// wall.c:519-528: order by (b,e); the pe term truncates to 0, and glibc's qsort is a stable merge
+// sort, so ties keep their insertion order.
+CP_HD bool cp_eintvl_before(const cp_eintvl &a, int ia, const cp_eintvl &b, int ib)
+{ if (a.b != b.b) return a.b < b.b;
+  if (a.e != b.e) return a.e < b.e;
+  return ia < ib;
+}
+
+// wall.c:530-546
+CP_HD int cp_bs_eintvl(const cp_eintvl *v, int l, int r, int b, int e)
+{ while (l <= r)
+    { int m = (l+r)/2;
+      if (v[m].b == b)
+        { if (v[m].e == e) return m;
+          else if (e > v[m].e) l = m+1;
+          else r = m-1;
+        }
+      else if (b > v[m].b) l = m+1;
+      else r = m-1;
+    }
+  return -1;
+}
+
+// wall.c:548-568 after the sort: keep the first of each run of equal (b,e)
+CP_HD int cp_dedupe_sorted(cp_eintvl *v, int N)
+{ if (N < 2) return N;
+  int i = 1;
+  while (i < N)
+    { if (v[i-1].b == v[i].b && v[i-1].e == v[i].e)
+        break;
+      i++;
+    }
+  for (int j = i+1; j < N; j++)
+    if (!(v[i-1].b == v[j].b && v[i-1].e == v[j].e))
+      { v[i] = v[j];
+        i++;
+      }
+  return i;
+}
+
+// wall.c:763-860 for one O-only wall i: look up to 200 positions right (DROP) / left (GAIN) for
+// partner walls that would make [i,j) an error interval by multiple errors; boundary intervals at
+// plen / 0.  `NS` = number of sorted unique E-intervals, `*midx` = append cursor.
+CP_HD void cp_wall_mult(cp_read *R, int i, int NS, int *midx)
+{ uint8_t *wall = R->wall;
+  const int plen = R->plen;
+  cp_eintvl *ev = R->eintvl;
+  double pe, pe_i, pe_j;
+  for (int w = CP_DROP; w <= CP_GAIN; w++)
+    { if ((pe_i = CP_PERR(R,i,CP_SELF,w)) < CP_PE_THRES_FINAL)
+        continue;
+      if (w == CP_DROP)
+        { int jend = (i+CP_MULT_WINDOW < plen+1) ? i+CP_MULT_WINDOW : plen+1;
+          for (int j = i+1; j < jend; j++)
+            { if (j == plen)
+                { if ((pe = pe_i * pe_i) < CP_PE_THRES_FINAL)
+                    continue;
+                  if (*midx >= R->ecap) { R->overflow = 1; return; }
+                  ev[*midx].b = i; ev[*midx].e = plen; ev[*midx].pe = pe;
+                  wall[i] |= CP_W_PAIRED_M;
+                  (*midx)++;
+                }
+              if (!(wall[j] & (CP_W_WALL_S|CP_W_WALL_O)))
+                continue;
+              if (cp_bs_eintvl(ev,0,NS-1,i,j) == -1)
+                { pe_j = CP_PERR(R,j,CP_SELF,CP_GAIN);
+                  if ((pe = pe_i * pe_j) >= CP_PE_THRES_FINAL)
+                    { if (*midx >= R->ecap) { R->overflow = 1; return; }
+                      ev[*midx].b = i; ev[*midx].e = j; ev[*midx].pe = pe;
+                      wall[i] |= CP_W_PAIRED_M;
+                      wall[j] |= CP_W_PAIRED_M;
+                      (*midx)++;
+                    }
+                }
+              if (wall[j] & CP_W_WALL_O)
+                break;
+            }
+        }
+      else
+        { int jend = (i-CP_MULT_WINDOW > 0) ? i-CP_MULT_WINDOW : 0;
+          for (int j = i-1; j >= jend; j--)
+            { if (j == 0)
+                { if ((pe = pe_i * pe_i) < CP_PE_THRES_FINAL)
+                    continue;
+                  if (*midx >= R->ecap) { R->overflow = 1; return; }
+                  ev[*midx].b = 0; ev[*midx].e = i; ev[*midx].pe = pe;
+                  wall[i] |= CP_W_PAIRED_M;
+                  (*midx)++;
+                }
+              if (!(wall[j] & (CP_W_WALL_S|CP_W_WALL_O)))
+                continue;
+              if (cp_bs_eintvl(ev,0,NS-1,j,i) == -1)
+                { pe_j = CP_PERR(R,j,CP_SELF,CP_DROP);
+                  if ((pe = pe_i * pe_j) >= CP_PE_THRES_FINAL)
+                    { if (*midx >= R->ecap) { R->overflow = 1; return; }
+                      ev[*midx].b = j; ev[*midx].e = i; ev[*midx].pe = pe;
+                      wall[i] |= CP_W_PAIRED_M;
+                      wall[j] |= CP_W_PAIRED_M;
+                      (*midx)++;
+                    }
+                }
+              if (wall[j] & CP_W_WALL_O)
+                break;
+            }
+        }
+    }
+}
+
+// wall.c:878-909: append the union of every chain of overlapping E-intervals (list sorted by (b,e)).
+CP_HD int cp_merge_eintvl(cp_read *R, int NS)
+{ cp_eintvl *ev = R->eintvl;
+  const int n0 = NS;
+  int i = 0, j;
+  while (i < n0-1)
+    { int    max_e  = ev[i].e;
+      double max_pe = ev[i].pe;
+      j = i;
+      while (j < n0-1)
+        { if (ev[j+1].b <= ev[j].e)
+            { if (max_e < ev[j+1].e) max_e = ev[j+1].e;
+              if (!(max_pe > ev[j+1].pe)) max_pe = ev[j+1].pe;
+              j++;
+            }
+          else
+            break;
+        }
+      if (i < j)
+        { if (NS >= R->ecap) { R->overflow = 1; return NS; }
+          ev[NS].b = ev[i].b; ev[NS].e = max_e; ev[NS].pe = max_pe;
+          NS++;
+        }
+      i = j+1;
+    }
+  return NS;
+}
+
+// wall.c:928-946: the record of interval [b,e) given the final sorted E-interval list.
+CP_HD void cp_make_interval(const cp_read *R, int NS, int b, int e, cp_intvl *out)
+{ int idx = cp_bs_eintvl(R->eintvl,0,NS-1,b,e);
+  out->b = b;
+  out->e = e;
+  out->cb = R->prof[b];
+  out->ce = R->prof[e-1];
+  out->ccb = 0;
+  out->cce = 0;
+  out->is_rel = 0;
+  out->asgn = CP_N_STATE;
+  for (int k = 0; k < 6; k++) out->_pad[k] = 0;
+  out->pe = (idx != -1) ? log(R->eintvl[idx].pe) : CP_NEG_INF;
+  double d = CP_PERR(R,b,CP_OTHERS,CP_DROP), g = CP_PERR(R,b,CP_OTHERS,CP_GAIN);
+  double peob = d > g ? d : g;
+  d = CP_PERR(R,e,CP_OTHERS,CP_DROP); g = CP_PERR(R,e,CP_OTHERS,CP_GAIN);
+  double peoe = d > g ? d : g;
+  out->peo_b = (peob != CP_NEG_INF) ? log(peob) : CP_NEG_INF;
+  out->peo_e = (peoe != CP_NEG_INF) ? log(peoe) : CP_NEG_INF;
+}
+
+// correct_wall_cnt + the filters of find_rel_intvl, wall.c:960-1051, for interval `idx`.
+// The reference's position-indexed loops at wall.c:999-1006 only ever touch the interval itself when
+// its index equals its start position (SURVEY.md hazard 2); that case is applied explicitly.
+CP_HD bool cp_rel_interval(const cp_dev_params *P, const uint16_t *prof, const char *seq, int rlen,
+                           cp_intvl *I, int idx)
+{ const int K = P->K;
+  if (I->e-I->b < K)
+    return false;
+  if ((I->cb > I->ce ? I->cb : I->ce) >= P->cov[CP_REPEAT])
+    return false;
+  if (I->pe >= P->log_pe_final)                          // log(PE_THRES[FINAL][SELF]), wall.c:1018
+    return false;
+
+  int first, last, n_gain = 0, n_drop = 0, lmax;
+  last = (I->b+K-1 < I->e-1) ? I->b+K-1 : I->e-1;
+  for (int i = I->b; i < last; i++)
+    { int d = (int)prof[i+1]-prof[i];
+      if (d > 0) n_gain += d;
+    }
+  if (I->b+K-1 < I->e)
+    { lmax = 0;
+      for (int t = 0; t < 3; t++)
+        { int l = cp_rctx(seq,rlen,I->b+K-1,t)*(t+1);
+          if (lmax < l) lmax = l;
+        }
+      last = I->b+lmax;
+      for (int i = I->b; i < last; i++)
+        { int d = (int)prof[i]-prof[i+1];
+          if (d > 0) n_gain -= d;
+        }
+    }
+  first = (I->e-K+1 > I->b) ? I->e-K+1 : I->b;
+  for (int i = first; i < I->e-1; i++)
+    { int d = (int)prof[i]-prof[i+1];
+      if (d > 0) n_drop += d;
+    }
+  if (I->b < I->e-K+1)
+    { lmax = 0;
+      for (int t = 0; t < 3; t++)
+        { int l = cp_lctx(seq,rlen,(I->e-K+1)+K-2,t)*(t+1);   // ctx[DROP][e-K+1]
+          if (lmax < l) lmax = l;
+        }
+      first = I->e-lmax;
+      for (int i = first; i < I->e-1; i++)
+        { int d = (int)prof[i+1]-prof[i];
+          if (d > 0) n_drop -= d;
+        }
+    }
+  int ccb = I->cb+(n_gain > 0 ? n_gain : 0);
+  int cce = I->ce+(n_drop > 0 ? n_drop : 0);
+  if (ccb > CP_MAX_KMER_CNT) ccb = CP_MAX_KMER_CNT;
+  if (cce > CP_MAX_KMER_CNT) cce = CP_MAX_KMER_CNT;
+  if (idx == I->b && I->e-2*K <= I->b && cce < prof[I->b])  // wall.c:1003-1006 with intvl index == position
+    cce = prof[I->b];
+  I->ccb = (uint16_t)ccb;
+  I->cce = (uint16_t)cce;
+
+  if (cp_logp_trans(P,I->b,I->e,ccb,cce,(ccb+cce)/2) < CP_THRES_DIFF_REL)
+    return false;
+  if ((ccb > cce ? ccb : cce) == CP_MAX_KMER_CNT)
+    return false;
+  return true;
+}

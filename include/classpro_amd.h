@@ -1,0 +1,141 @@
+/*
+ * classpro_amd.h -- C ABI of the MI355X-native per-read k-mer classifier (libclasspro_amd.so).
+ *
+ * Drop-in boundary for ClassPro's per-read hot path.  The reference has no FFI; what a maintainer
+ * would bind is (i) the one-time global setup and (ii) the six per-read calls of the thread loop
+ * (src/ClassPro.c:229-271).  Each entry point below names the reference interface it replaces.
+ * The per-read calls are replaced by *batched* calls over many reads laid out flat in HBM:
+ *
+ *     seq      char   [seq_off[nreads]]   read bases, ASCII, concatenated, no terminators
+ *     seq_off  int64  [nreads+1]          read r = seq[seq_off[r] .. seq_off[r+1])
+ *     prof     uint16 [prof_off[nreads]]  k-mer counts (what Fetch_Profile yields), concatenated;
+ *                                         base address 16-byte aligned
+ *     prof_off int64  [nreads+1]          plen_r = prof_off[r+1]-prof_off[r] = rlen_r-(K-1)
+ *     labels   char   [seq_off[nreads]]   out: 'N'*(K-1) then E/H/D/R per k-mer (ClassPro.c:116-119,265-271)
+ *
+ * All reads of a batch must have rlen >= K (the caller prints shorter reads itself, as
+ * ClassPro.c:209-226 does) and rlen <= CP_MAX_READ_LEN.
+ *
+ * Pointers named d_* are DEVICE pointers (HBM); everything else is host memory.  `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  No torch types appear in this ABI.
+ * Every function returns CP_OK (0) or a negative CP_E* code; cp_last_error() gives the message.
+ * The reference's behaviour on these errors is fprintf(stderr)+exit(1); the CLI mirrors that.
+ */
+#ifndef CLASSPRO_AMD_H
+#define CLASSPRO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CP_MAX_KMER_CNT 32767          /* src/const.c:38  MAX_KMER_CNT */
+#define CP_MAX_READ_LEN 60000          /* src/const.c:55  MAX_READ_LEN (FASTX inputs) */
+
+enum { CP_OK = 0, CP_EINVAL = -1, CP_ENOPEAK = -2, CP_ERCOV = -3, CP_EHIP = -4, CP_EOVERFLOW = -5, CP_ENOMEM = -6 };
+
+/* State codes (src/ClassPro.h:57) and their characters (src/const.c:19). */
+enum { CP_ERROR = 0, CP_REPEAT = 1, CP_HAPLO = 2, CP_DIPLO = 3, CP_N_STATE = 4 };
+
+/* Interval record exchanged by the stage entry points: the fields of the reference's `Intvl`
+ * (src/ClassPro.h:159-170) in a fixed 48-byte layout. */
+typedef struct
+  { int32_t  b, e;                 /* [b,e) in profile coordinates */
+    uint16_t cb, ce;               /* counts at b and e-1 */
+    uint16_t ccb, cce;             /* error-corrected boundary counts (find_rel_intvl) */
+    uint8_t  is_rel;
+    int8_t   asgn;                 /* CP_ERROR..CP_DIPLO, CP_N_STATE = unclassified */
+    uint8_t  _pad[6];
+    double   pe;                   /* log P(interval is a sequencing error in this read) or -inf */
+    double   peo_b, peo_e;         /* log P(boundary explained by errors in other reads) or -inf */
+  } cp_intvl;
+
+const char *cp_last_error(void);
+const char *cp_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * One-time global setup (host).
+ * ------------------------------------------------------------------------------------------ */
+
+/* Replaces process_global_hist (src/hist.c:28-105) on a loaded FASTK histogram
+ * (Load_Histogram/Modify_Histogram, src/libfastk.c:51-147).  `hist` is the on-disk array
+ * hist[0..high-low] of <root>.hist (unique counts); coverage_opt is `-c` (0 = estimate).
+ * CP_ENOPEAK when no peak count >= 10 exists (the reference exits, hist.c:66-69). */
+int cp_hist_covs(const int64_t *hist, int low, int high, int64_t ilowcnt, int64_t ihighcnt,
+                 int coverage_opt, int *hcov, int *dcov);
+
+/* Replaces precompute_logfact (src/prob.c:14-19), the GLOBAL_COV / DR_RATIO block
+ * (src/ClassPro.c:544-548) and calc_init_thres(NULL) (src/wall.c:167-244): builds the read-only
+ * tables on the host and uploads them to the current HIP device.
+ * CP_ERCOV when the repeat threshold exceeds 255 (wall.c:174-177). */
+typedef struct cp_params cp_params;
+int  cp_params_create(int K, int read_len, int hcov, int dcov, cp_params **out);
+void cp_params_destroy(cp_params *p);
+/* Host copies of the tables, for inspection/tests: cov[4]=GLOBAL_COV[E,R,H,D]; cthres is
+ * [3][21][256][2][2] = [ctype][l][cout][INIT|FINAL][SELF|OTHERS]; pe is [3][21]; logfact[32768]. */
+int  cp_params_export(const cp_params *p, int *cov4, double *dr_ratio, int *cmax, double *hc_erate,
+                      uint8_t *cthres, double *pe, double *logfact);
+
+/* Replaces the decoder of Fetch_Profile (src/libfastk.c:1467-1534) for one read's code string
+ * (host; the north star keeps FASTK decoding on the host).  Returns the profile length (may
+ * exceed `cap`, in which case only `cap` counts were written), or a negative CP_E* code. */
+int cp_decode_profile(const uint8_t *code, int64_t len, uint16_t *profile, int cap);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched device path.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cp_workspace cp_workspace;          /* device scratch, grown on demand, reusable */
+int  cp_workspace_create(cp_workspace **out);
+void cp_workspace_destroy(cp_workspace *ws);
+size_t cp_workspace_bytes(const cp_workspace *ws); /* device bytes currently held */
+
+/* Whole hot path for a batch: replaces the body of the read loop, ClassPro.c:229-271
+ * (calc_seq_context, find_wall, find_rel_intvl, classify_rel, classify_unrel, label paint).
+ * Asynchronous on `stream` except for one small D2H size read-back after the scan stage. */
+int cp_classify_batch(const cp_params *p, cp_workspace *ws,
+                      const char *d_seq, const int64_t *d_seq_off,
+                      const uint16_t *d_prof, const int64_t *d_prof_off,
+                      int nreads, int64_t total_bases, int64_t total_kmers,
+                      char *d_labels, void *stream);
+
+/* Stage entry points (the reference's per-read internal contract, batched).  They run the
+ * pipeline up to and including the named stage and keep the results in `ws`:
+ *   CP_STAGE_SCAN      candidate scan of find_wall (wall.c:590-607): bitmap of wall candidates
+ *   CP_STAGE_WALL      find_wall       (src/wall.c:570-958)
+ *   CP_STAGE_REL       find_rel_intvl  (src/wall.c:1016-1051)
+ *   CP_STAGE_CLASS_REL classify_rel    (src/class_rel.c:871-963)
+ *   CP_STAGE_CLASS_ALL classify_unrel  (src/class_unrel.c:248-300)
+ *   CP_STAGE_LABELS    label paint     (src/ClassPro.c:265-271)   == cp_classify_batch */
+enum { CP_STAGE_SCAN = 1, CP_STAGE_WALL = 2, CP_STAGE_REL = 3, CP_STAGE_CLASS_REL = 4,
+       CP_STAGE_CLASS_ALL = 5, CP_STAGE_LABELS = 6 };
+int cp_run_stages(const cp_params *p, cp_workspace *ws,
+                  const char *d_seq, const int64_t *d_seq_off,
+                  const uint16_t *d_prof, const int64_t *d_prof_off,
+                  int nreads, int64_t total_bases, int64_t total_kmers,
+                  char *d_labels, int last_stage, void *stream);
+
+/* Read-back of stage results of the last cp_run_stages/cp_classify_batch on `ws` (host buffers;
+ * synchronises the stream).  counts: n_intvl[nreads], n_rel[nreads]; offsets into the flat arrays
+ * are the exclusive prefix sums of the per-read capacities returned in cap_off[nreads+1]. */
+int cp_get_counts(cp_workspace *ws, int32_t *n_cand, int32_t *n_intvl, int32_t *n_rel, int64_t *cap_off);
+int cp_get_intervals(cp_workspace *ws, cp_intvl *intvl, cp_intvl *rintvl, int64_t capacity);
+int cp_get_rel_asgn(cp_workspace *ws, int8_t *fw, int8_t *bw, int64_t capacity);
+int cp_get_bitmap(cp_workspace *ws, uint64_t *words, int64_t nwords);
+
+/* calc_seq_context (src/context.c:8-108), batched and dense: d_lctx/d_rctx are [total_bases][3]
+ * uint8 indexed by read position (the `_lctx`/`rctx` buffers of ClassPro.c:136-142).  The hot path
+ * evaluates contexts on demand and never materialises these arrays; this entry point exists for
+ * the reference's own call and for parity tests. */
+int cp_seq_context(const char *d_seq, const int64_t *d_seq_off, int nreads, int64_t total_bases,
+                   uint8_t *d_lctx, uint8_t *d_rctx, void *stream);
+
+/* Profile-scan kernel alone (the HBM-roofline kernel): d_bitmap holds ceil(total_kmers/64)+1 words. */
+int cp_scan_candidates(const cp_params *p, const uint16_t *d_prof, int64_t total_kmers,
+                       uint64_t *d_bitmap, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,126 @@
+// host_harness.cpp -- TEST-ONLY.  Compiles the product's scalar device functions (cp_math.h, cp_ctx.h,
+// cp_wall.h, cp_class.h) and host setup (cp_host_setup.h) for the host, with a plain sequential
+// orchestration, so their logic can be unit-tested against the oracle in a GPU-less container.
+// This library is never loaded by the product (classpro_amd/), only by tests/.
+#include <cstring>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include "../classpro_amd/csrc/cp_host_setup.h"
+#include "../classpro_amd/csrc/cp_wall.h"
+#include "../classpro_amd/csrc/cp_class.h"
+
+extern "C" {
+
+void hh_seq_context(const char *seq, int rlen, unsigned char *lctx, unsigned char *rctx)
+{ for (int i = 0; i < rlen; i++)
+    for (int t = 0; t < 3; t++)
+      { lctx[i*3+t] = (unsigned char)cp_lctx(seq,rlen,i,t);
+        rctx[i*3+t] = (unsigned char)cp_rctx(seq,rlen,i,t);
+      }
+}
+
+double hh_bessi(int n, double x) { return cp_bessi(n,x); }
+
+void *hh_params_new(int K, int read_len, int hcov, int dcov)
+{ cp_dev_params *P = (cp_dev_params *)malloc(sizeof(cp_dev_params));
+  if (cp_host_fill_params(P,K,read_len,hcov,dcov) != CP_OK) { free(P); return NULL; }
+  return P;
+}
+void hh_params_free(void *P) { free(P); }
+const unsigned char *hh_params_cthres(void *P) { return &((cp_dev_params *)P)->cthres[0][0][0][0][0]; }
+const double *hh_params_logfact(void *P) { return ((cp_dev_params *)P)->logfact; }
+int hh_hist_covs(const int64_t *h, int low, int high, int64_t il, int64_t ih, int c, int *hc, int *dc)
+{ return cp_host_hist_covs(h,low,high,il,ih,c,hc,dc); }
+int hh_decode_profile(const uint8_t *code, int64_t len, uint16_t *out, int cap)
+{ return cp_host_decode_profile(code,len,out,cap); }
+
+static void sort_e(cp_eintvl *v, int n)
+{ std::stable_sort(v,v+n,[](const cp_eintvl &a, const cp_eintvl &b)
+    { if (a.b != b.b) return a.b < b.b; return a.e < b.e; });
+}
+
+// Sequential orchestration of the scalar device functions for one read (mirrors what the kernels do
+// with lanes).  Returns N or -1 on list overflow.
+int hh_classify_read(void *Pv, const char *seq, int rlen, const uint16_t *prof, char *labels,
+                     cp_intvl *intvl, int cap, int *M_out, cp_intvl *rintvl, int8_t *fw, int8_t *bw)
+{ const cp_dev_params *P = (const cp_dev_params *)Pv;
+  const int K = P->K, plen = rlen-(K-1);
+  for (int i = 0; i < K-1 && i < rlen; i++) labels[i] = 'N';
+  if (plen <= 0) return 0;
+  std::vector<uint8_t> wall(plen+1,0);
+  std::vector<double> perror((size_t)(plen+1)*4,-INFINITY);
+  int ecap = 16*plen+64;
+  std::vector<cp_eintvl> ev(ecap), ov(ecap);
+  cp_read R;
+  R.P = P; R.prof = prof; R.seq = seq; R.plen = plen; R.rlen = rlen;
+  R.wall = wall.data(); R.perror = perror.data(); R.eintvl = ev.data(); R.ointvl = ov.data();
+  R.ecap = ecap; R.eidx = R.oidx = 0; R.overflow = 0;
+
+  for (int i = 1; i < plen; i++)
+    { int a = prof[i-1], b = prof[i];
+      if ((a < b ? a : b) >= P->cov[CP_REPEAT]) continue;
+      if (abs(a-b) < CP_MIN_CNT_CHANGE) continue;
+      cp_wall_candidate(&R,i);
+    }
+  int NS = R.eidx, NO = R.oidx;
+  for (int i = 0; i < NO; i++) { wall[ov[i].b] &= ~CP_W_WALL_O; wall[ov[i].e] &= ~CP_W_WALL_O; }
+  for (int i = 0; i < NS; i++) for (int j = ev[i].b+1; j < ev[i].e; j++) wall[j] &= ~CP_W_WALL_O;
+  sort_e(ev.data(),NS); NS = cp_dedupe_sorted(ev.data(),NS);
+  int midx = NS;
+  for (int i = 1; i < plen; i++)
+    { if (!((wall[i] & CP_W_WALL_O) && !(wall[i] & CP_W_WALL_S))) continue;
+      if (wall[i] & CP_W_PAIRED_M) continue;
+      cp_wall_mult(&R,i,NS,&midx);
+    }
+  for (int i = NS; i < midx; i++) for (int j = ev[i].b+1; j < ev[i].e; j++) wall[j] &= ~CP_W_WALL_O;
+  if (NS < midx) { NS = midx; sort_e(ev.data(),NS); }
+  NS = cp_merge_eintvl(&R,NS);
+  sort_e(ev.data(),NS);
+  if (R.overflow) return -1;
+  for (int i = 0; i < NS; i++) for (int j = ev[i].b; j < ev[i].e; j++) wall[j] |= CP_W_ERROR;
+  int N = 0, b = 0;
+  for (int i = 1; i <= plen; i++)
+    if (i == plen || ((wall[i-1] & CP_W_ERROR) != 0) != ((wall[i] & CP_W_ERROR) != 0)
+        || (!(wall[i] & CP_W_ERROR) && (wall[i] & CP_W_WALL_O)))
+      { if (N >= cap) return -1;
+        cp_make_interval(&R,NS,b,i,&intvl[N]);
+        N++; b = i;
+      }
+  int M = 0;
+  std::vector<int> relmap;
+  for (int idx = 0; idx < N; idx++)
+    if (cp_rel_interval(P,prof,seq,rlen,&intvl[idx],idx))
+      { intvl[idx].is_rel = 1; rintvl[M++] = intvl[idx]; relmap.push_back(idx); }
+  *M_out = M;
+  if (M > 0)
+    { std::vector<int8_t> parent((size_t)M*4), asg(M);
+      std::vector<int> eff(M);
+      std::vector<uint8_t> rpos(M);
+      double hf = cp_rel_dir_full(P,rintvl,M,plen,1,parent.data(),eff.data(),rpos.data(),fw);
+      double hb = cp_rel_dir_full(P,rintvl,M,plen,0,parent.data(),eff.data(),rpos.data(),bw);
+      cp_rel_reconcile(fw,bw,M,hf,hb,asg.data());
+      for (int r = 0; r < M; r++) { rintvl[r].asgn = asg[r]; intvl[relmap[r]].asgn = asg[r]; }
+    }
+  { std::vector<int> ord(N);
+    std::vector<uint8_t> fixed(N);
+    for (int i = 0; i < N; i++)
+      { ord[i] = i;
+        fixed[i] = intvl[i].is_rel && (intvl[i].asgn == CP_HAPLO || intvl[i].asgn == CP_DIPLO);
+      }
+    std::stable_sort(ord.begin(),ord.end(),[&](int x, int y)
+      { int kx = intvl[x].cb < intvl[x].ce ? intvl[x].cb : intvl[x].ce;
+        int ky = intvl[y].cb < intvl[y].ce ? intvl[y].cb : intvl[y].ce;
+        return kx < ky; });
+    for (int i = N-1; i >= 0; i--) if (!fixed[ord[i]]) cp_update_state(P,ord[i],intvl,N);
+    for (int i = 0; i < N; i++)    if (!fixed[ord[i]]) cp_update_state(P,ord[i],intvl,N);
+  }
+  static const char stoc[5] = { 'E','R','H','D','?' };
+  for (int i = 0; i < N; i++)
+    for (int j = intvl[i].b; j < intvl[i].e; j++)
+      labels[K-1+j] = stoc[(int)intvl[i].asgn];
+  return N;
+}
+
+}
