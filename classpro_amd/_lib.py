@@ -1,0 +1,67 @@
+"""Loader for the C-ABI library (classpro_amd/libclasspro_amd.so, built from csrc/ by build.py).
+
+Fails loudly when the library is missing: there is no CPU or PyTorch fallback for the hot path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libclasspro_amd.so")
+
+# every symbol include/classpro_amd.h declares
+SYMBOLS = [
+    "cp_last_error", "cp_version", "cp_hist_covs", "cp_params_create", "cp_params_destroy",
+    "cp_params_export", "cp_decode_profile", "cp_workspace_create", "cp_workspace_destroy",
+    "cp_workspace_bytes", "cp_classify_batch", "cp_workspace_check", "cp_run_stages", "cp_get_counts",
+    "cp_get_intervals", "cp_get_rel_asgn", "cp_get_bitmap", "cp_seq_context", "cp_scan_candidates",
+]
+
+_lib = None
+
+
+class ClassProError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("classpro_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "classpro_amd: %s not found. Build it with `python -m classpro_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    L.cp_last_error.restype = C.c_char_p
+    L.cp_version.restype = C.c_char_p
+    L.cp_hist_covs.argtypes = [vp, i32, i32, i64, i64, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.cp_params_create.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
+    L.cp_params_destroy.argtypes = [vp]
+    L.cp_params_destroy.restype = None
+    L.cp_params_export.argtypes = [vp] + [vp] * 7
+    L.cp_decode_profile.argtypes = [vp, i64, vp, i32]
+    L.cp_workspace_create.argtypes = [C.POINTER(vp)]
+    L.cp_workspace_destroy.argtypes = [vp]
+    L.cp_workspace_destroy.restype = None
+    L.cp_workspace_bytes.argtypes = [vp]
+    L.cp_workspace_bytes.restype = C.c_size_t
+    L.cp_classify_batch.argtypes = [vp, vp, vp, vp, vp, vp, i32, i64, i64, vp, vp]
+    L.cp_workspace_check.argtypes = [vp]
+    L.cp_run_stages.argtypes = [vp, vp, vp, vp, vp, vp, i32, i64, i64, vp, i32, vp]
+    L.cp_get_counts.argtypes = [vp, vp, vp, vp, vp]
+    L.cp_get_intervals.argtypes = [vp, vp, vp, i64]
+    L.cp_get_rel_asgn.argtypes = [vp, vp, vp, i64]
+    L.cp_get_bitmap.argtypes = [vp, vp, i64]
+    L.cp_seq_context.argtypes = [vp, vp, i32, i64, vp, vp, vp]
+    L.cp_scan_candidates.argtypes = [vp, vp, i64, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc < 0:
+        raise ClassProError(rc, lib().cp_last_error().decode(errors="replace"))
+    return rc

@@ -1,0 +1,174 @@
+"""Host-side Python mirror of the reference's per-read interface, batched, over the C ABI.
+
+Names follow the reference (ClassPro.c:229-271): calc_seq_context, find_wall, find_rel_intvl,
+classify_rel, classify_unrel; `Classifier.classify` is the whole read loop body for a batch.
+PyTorch is used only to own device memory and streams; every computation is a HIP kernel in
+libclasspro_amd.so.  Nothing here imports oracle/.
+"""
+import ctypes as C
+import numpy as np
+import torch
+
+from ._lib import lib, check
+
+STAGE_SCAN, STAGE_WALL, STAGE_REL, STAGE_CLASS_REL, STAGE_CLASS_ALL, STAGE_LABELS = 1, 2, 3, 4, 5, 6
+
+INTVL_DTYPE = np.dtype({
+    "names":   ["b", "e", "cb", "ce", "ccb", "cce", "is_rel", "asgn", "pe", "peo_b", "peo_e"],
+    "formats": ["<i4", "<i4", "<u2", "<u2", "<u2", "<u2", "u1", "i1", "<f8", "<f8", "<f8"],
+    "offsets": [0, 4, 8, 10, 12, 14, 16, 17, 24, 32, 40],
+    "itemsize": 48,
+})
+
+
+def hist_covs(hist, low, high, ilowcnt=0, ihighcnt=0, coverage=0):
+    """process_global_hist (hist.c:28): (H,D) coverage from a FASTK histogram or from -c."""
+    h = np.ascontiguousarray(hist, dtype=np.int64)
+    hc, dc = C.c_int(), C.c_int()
+    check(lib().cp_hist_covs(h.ctypes.data, low, high, ilowcnt, ihighcnt, coverage, C.byref(hc), C.byref(dc)))
+    return hc.value, dc.value
+
+
+def decode_profile(code, cap=60000):
+    """Fetch_Profile's decoder (libfastk.c:1467) for one read's code string."""
+    buf = np.frombuffer(bytes(code), dtype=np.uint8)
+    out = np.zeros(cap, np.uint16)
+    n = check(lib().cp_decode_profile(buf.ctypes.data if len(buf) else None, len(buf), out.ctypes.data, cap))
+    return n, out[:min(n, cap)]
+
+
+class Batch:
+    """A batch of reads resident in HBM in the flat layout of include/classpro_amd.h."""
+
+    def __init__(self, seq, seq_off, prof, prof_off, device="cuda:0"):
+        self.device = torch.device(device)
+        self.nreads = len(seq_off) - 1
+        self.total_bases = int(seq_off[-1])
+        self.total_kmers = int(prof_off[-1])
+        self.seq_off_h = np.ascontiguousarray(seq_off, np.int64)
+        self.prof_off_h = np.ascontiguousarray(prof_off, np.int64)
+        dev = self.device
+        self.seq = torch.from_numpy(np.ascontiguousarray(seq, np.uint8)).to(dev)
+        self.prof = torch.from_numpy(np.ascontiguousarray(prof, np.uint16).view(np.int16)).to(dev)
+        self.seq_off = torch.from_numpy(self.seq_off_h).to(dev)
+        self.prof_off = torch.from_numpy(self.prof_off_h).to(dev)
+        self.labels = torch.zeros(max(self.total_bases, 1), dtype=torch.uint8, device=dev)
+
+    @classmethod
+    def from_reads(cls, seqs, profiles, device="cuda:0"):
+        from .synth import pack_batch
+        return cls(*pack_batch(seqs, profiles), device=device)
+
+
+class Classifier:
+    """Global setup (ClassPro.c:536-554) + batched hot path."""
+
+    def __init__(self, K=40, read_len=20000, hcov=20, dcov=40, device="cuda:0"):
+        self.L = lib()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("classpro_amd runs on a HIP device only")
+        torch.cuda.set_device(self.device)
+        self.K, self.read_len = K, read_len
+        p = C.c_void_p()
+        check(self.L.cp_params_create(K, read_len, hcov, dcov, C.byref(p)))
+        self.p = p
+        w = C.c_void_p()
+        check(self.L.cp_workspace_create(C.byref(w)))
+        self.ws = w
+
+    def close(self):
+        if getattr(self, "ws", None):
+            self.L.cp_workspace_destroy(self.ws)
+            self.ws = None
+        if getattr(self, "p", None):
+            self.L.cp_params_destroy(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- tables ----
+    def export(self):
+        cov = (C.c_int * 4)()
+        dr, cmax, hc = C.c_double(), C.c_int(), C.c_double()
+        cth = np.zeros((3, 21, 256, 2, 2), np.uint8)
+        pe = np.zeros((3, 21), np.float64)
+        lf = np.zeros(32768, np.float64)
+        check(self.L.cp_params_export(self.p, cov, C.byref(dr), C.byref(cmax), C.byref(hc),
+                                      cth.ctypes.data, pe.ctypes.data, lf.ctypes.data))
+        return dict(cov=list(cov), dr_ratio=dr.value, cmax=cmax.value, hc_erate=hc.value,
+                    cthres=cth, pe=pe, logfact=lf)
+
+    # ---- pipeline ----
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def run(self, b, last_stage=STAGE_LABELS):
+        check(self.L.cp_run_stages(self.p, self.ws, b.seq.data_ptr(), b.seq_off.data_ptr(),
+                                   b.prof.data_ptr(), b.prof_off.data_ptr(), b.nreads, b.total_bases,
+                                   b.total_kmers, b.labels.data_ptr(), last_stage, self._stream()))
+
+    def classify(self, b, check_overflow=True):
+        """ClassPro.c:229-271 for every read of the batch; returns the label bytes (host)."""
+        check(self.L.cp_classify_batch(self.p, self.ws, b.seq.data_ptr(), b.seq_off.data_ptr(),
+                                       b.prof.data_ptr(), b.prof_off.data_ptr(), b.nreads, b.total_bases,
+                                       b.total_kmers, b.labels.data_ptr(), self._stream()))
+        if check_overflow:
+            check(self.L.cp_workspace_check(self.ws))
+        return b.labels[:b.total_bases].cpu().numpy()
+
+    def check(self):
+        check(self.L.cp_workspace_check(self.ws))
+
+    def workspace_bytes(self):
+        return int(self.L.cp_workspace_bytes(self.ws))
+
+    # ---- stage read-back (parity tests) ----
+    def counts(self, b):
+        n = b.nreads
+        nc, ni, nr = (np.zeros(n, np.int32) for _ in range(3))
+        off = np.zeros(n + 1, np.int64)
+        check(self.L.cp_get_counts(self.ws, nc.ctypes.data, ni.ctypes.data, nr.ctypes.data, off.ctypes.data))
+        return nc, ni, nr, off
+
+    def intervals(self, b):
+        """Per-read lists of (intvl[N], rintvl[M]) after a run of at least STAGE_WALL / STAGE_REL."""
+        nc, ni, nr, off = self.counts(b)
+        tot = int(off[-1])
+        iv = np.zeros(max(tot, 1), INTVL_DTYPE)
+        rv = np.zeros(max(tot, 1), INTVL_DTYPE)
+        check(self.L.cp_get_intervals(self.ws, iv.ctypes.data, rv.ctypes.data, max(tot, 1)))
+        out = []
+        for r in range(b.nreads):
+            o = int(off[r])
+            out.append((iv[o:o + ni[r]].copy(), rv[o:o + nr[r]].copy()))
+        return out
+
+    def rel_asgn(self, b):
+        nc, ni, nr, off = self.counts(b)
+        tot = int(off[-1])
+        fw = np.zeros(max(tot, 1), np.int8)
+        bw = np.zeros(max(tot, 1), np.int8)
+        check(self.L.cp_get_rel_asgn(self.ws, fw.ctypes.data, bw.ctypes.data, max(tot, 1)))
+        return [(fw[int(off[r]):int(off[r]) + nr[r]].copy(), bw[int(off[r]):int(off[r]) + nr[r]].copy())
+                for r in range(b.nreads)]
+
+    def bitmap(self, b):
+        nw = b.total_kmers // 64 + 1
+        w = np.zeros(nw, np.uint64)
+        check(self.L.cp_get_bitmap(self.ws, w.ctypes.data, nw))
+        return w
+
+    def seq_context(self, b):
+        """calc_seq_context (context.c:8), dense, per read: list of (lctx[rlen,3], rctx[rlen,3])."""
+        l = torch.zeros((max(b.total_bases, 1), 3), dtype=torch.uint8, device=self.device)
+        r = torch.zeros_like(l)
+        check(self.L.cp_seq_context(b.seq.data_ptr(), b.seq_off.data_ptr(), b.nreads, b.total_bases,
+                                    l.data_ptr(), r.data_ptr(), self._stream()))
+        lh, rh = l.cpu().numpy(), r.cpu().numpy()
+        so = b.seq_off_h
+        return [(lh[so[i]:so[i + 1]], rh[so[i]:so[i + 1]]) for i in range(b.nreads)]

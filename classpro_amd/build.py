@@ -1,0 +1,38 @@
+"""Build libclasspro_amd.so in-tree: hipcc cross-compiles gfx950 without a GPU.
+
+    python -m classpro_amd.build [--force]
+"""
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+OUT = os.path.join(_HERE, "libclasspro_amd.so")
+# -ffp-contract=off: the decision path compares doubles against thresholds and truncates them to
+# ints (class_rel.c:449,483); fused multiply-adds would change those values.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+
+
+def _newest_src():
+    t = 0.0
+    for root, _d, files in os.walk(CSRC):
+        for f in files:
+            t = max(t, os.path.getmtime(os.path.join(root, f)))
+    t = max(t, os.path.getmtime(os.path.join(_HERE, "..", "include", "classpro_amd.h")))
+    return t
+
+
+def build(force=False, verbose=False):
+    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= _newest_src():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, "capi.hip"), "-o", OUT]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,371 @@
+// capi.hip -- host side of the C ABI (include/classpro_amd.h): parameter upload, device scratch
+// management and kernel launches.  No torch, no CPU compute path: every stage is a HIP kernel and
+// every entry point fails with CP_EHIP when the device call fails.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include "cp_host_setup.h"
+#include "kernels.hip"
+
+static thread_local std::string g_err;
+static int set_err(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIPCHK(call)                                                                       \
+  do { hipError_t e_ = (call);                                                             \
+       if (e_ != hipSuccess)                                                               \
+         return set_err(CP_EHIP,std::string(#call)+": "+hipGetErrorString(e_));            \
+     } while (0)
+
+extern "C" const char *cp_last_error(void) { return g_err.c_str(); }
+extern "C" const char *cp_version(void) { return "classpro_amd 0.1 (gfx950)"; }
+
+// ---------------------------------------------------------------------------------------------
+struct cp_params
+  { cp_dev_params  host;
+    cp_dev_params *dev;
+  };
+
+extern "C" int cp_hist_covs(const int64_t *hist, int low, int high, int64_t ilowcnt, int64_t ihighcnt,
+                            int coverage_opt, int *hcov, int *dcov)
+{ if (!hcov || !dcov || (coverage_opt <= 0 && !hist))
+    return set_err(CP_EINVAL,"cp_hist_covs: null argument");
+  int rc = cp_host_hist_covs(hist,low,high,ilowcnt,ihighcnt,coverage_opt,hcov,dcov);
+  if (rc == CP_ENOPEAK)
+    return set_err(rc,"[ERROR] Could not find any peak count >= 10 in the histogram. Revise data and use the `-c` option.");
+  if (rc != CP_OK)
+    return set_err(rc,"cp_hist_covs: unsupported histogram range");
+  return CP_OK;
+}
+
+extern "C" int cp_params_create(int K, int read_len, int hcov, int dcov, cp_params **out)
+{ if (!out) return set_err(CP_EINVAL,"cp_params_create: null out");
+  cp_params *p = (cp_params *)malloc(sizeof(cp_params));
+  if (!p) return set_err(CP_ENOMEM,"cp_params_create: out of memory");
+  int rc = cp_host_fill_params(&p->host,K,read_len,hcov,dcov);
+  if (rc != CP_OK)
+    { char buf[128];
+      if (rc == CP_ERCOV) snprintf(buf,sizeof(buf),"Too high REPEAT coverage (%d) > 255",p->host.cov[CP_REPEAT]);
+      else                snprintf(buf,sizeof(buf),"cp_params_create: invalid argument");
+      free(p);
+      return set_err(rc,buf);
+    }
+  p->dev = NULL;
+  hipError_t e = hipMalloc((void **)&p->dev,sizeof(cp_dev_params));
+  if (e == hipSuccess)
+    e = hipMemcpy(p->dev,&p->host,sizeof(cp_dev_params),hipMemcpyHostToDevice);
+  if (e != hipSuccess)
+    { if (p->dev) (void)hipFree(p->dev);
+      free(p);
+      return set_err(CP_EHIP,std::string("cp_params_create: ")+hipGetErrorString(e));
+    }
+  *out = p;
+  return CP_OK;
+}
+
+extern "C" void cp_params_destroy(cp_params *p)
+{ if (!p) return;
+  if (p->dev) (void)hipFree(p->dev);
+  free(p);
+}
+
+extern "C" int cp_params_export(const cp_params *p, int *cov4, double *dr_ratio, int *cmax, double *hc_erate,
+                                uint8_t *cthres, double *pe, double *logfact)
+{ if (!p) return set_err(CP_EINVAL,"cp_params_export: null params");
+  if (cov4) memcpy(cov4,p->host.cov,sizeof(int)*4);
+  if (dr_ratio) *dr_ratio = p->host.dr_ratio;
+  if (cmax) *cmax = p->host.cmax;
+  if (hc_erate) *hc_erate = p->host.hc_erate;
+  if (cthres) memcpy(cthres,p->host.cthres,sizeof(p->host.cthres));
+  if (pe) memcpy(pe,p->host.pe,sizeof(p->host.pe));
+  if (logfact) memcpy(logfact,p->host.logfact,sizeof(p->host.logfact));
+  return CP_OK;
+}
+
+extern "C" int cp_decode_profile(const uint8_t *code, int64_t len, uint16_t *profile, int cap)
+{ if (len < 0 || (len > 0 && !code) || (cap > 0 && !profile))
+    return set_err(CP_EINVAL,"cp_decode_profile: bad argument");
+  return cp_host_decode_profile(code,len,profile,cap);
+}
+
+// ---------------------------------------------------------------------------------------------
+//  Workspace: device scratch grown on demand (never shrunk), reused across batches.
+// ---------------------------------------------------------------------------------------------
+struct dbuf { void *p; size_t cap; };
+
+struct cp_workspace
+  { dbuf bitmap, ncand, nintvl, nrel, ioff, eoff, wall, perror, eintvl, ointvl, intvl, rintvl,
+         relmap, parent, eff, rpos, asgn, ord, err;
+    int64_t *h_totals;        // pinned: [totalI, totalE]
+    int32_t *h_err;           // pinned
+    // shape of the last run
+    int      nreads;
+    int64_t  total_kmers, total_bases, totalI, totalE, nwords;
+    int      last_stage;
+    hipStream_t stream;
+  };
+
+static int ensure(dbuf &b, size_t need)
+{ if (need <= b.cap) return CP_OK;
+  if (b.p) { (void)hipFree(b.p); b.p = NULL; b.cap = 0; }
+  size_t want = need+need/8+256;
+  hipError_t e = hipMalloc(&b.p,want);
+  if (e != hipSuccess)
+    { char m[160];
+      snprintf(m,sizeof(m),"hipMalloc(%zu bytes): %s",want,hipGetErrorString(e));
+      return set_err(CP_ENOMEM,m);
+    }
+  b.cap = want;
+  return CP_OK;
+}
+#define ENSURE(b,n) do { int rc_ = ensure(b,(size_t)(n)); if (rc_ != CP_OK) return rc_; } while (0)
+
+extern "C" int cp_workspace_create(cp_workspace **out)
+{ if (!out) return set_err(CP_EINVAL,"cp_workspace_create: null out");
+  cp_workspace *ws = (cp_workspace *)calloc(1,sizeof(cp_workspace));
+  if (!ws) return set_err(CP_ENOMEM,"cp_workspace_create: out of memory");
+  hipError_t e = hipHostMalloc((void **)&ws->h_totals,2*sizeof(int64_t),hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&ws->h_err,sizeof(int32_t),hipHostMallocDefault);
+  if (e != hipSuccess)
+    { free(ws);
+      return set_err(CP_EHIP,std::string("cp_workspace_create: ")+hipGetErrorString(e));
+    }
+  *out = ws;
+  return CP_OK;
+}
+
+extern "C" void cp_workspace_destroy(cp_workspace *ws)
+{ if (!ws) return;
+  dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->wall,&ws->perror,
+                  &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
+                  &ws->asgn,&ws->ord,&ws->err };
+  for (dbuf *b : all) if (b->p) (void)hipFree(b->p);
+  if (ws->h_totals) (void)hipHostFree(ws->h_totals);
+  if (ws->h_err) (void)hipHostFree(ws->h_err);
+  free(ws);
+}
+
+extern "C" size_t cp_workspace_bytes(const cp_workspace *ws)
+{ if (!ws) return 0;
+  const dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->wall,&ws->perror,
+                        &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
+                        &ws->asgn,&ws->ord,&ws->err };
+  size_t s = 0;
+  for (const dbuf *b : all) s += b->cap;
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int scan_grid(int64_t total)
+{ int64_t groups = total >> 3;
+  int64_t blocks = (groups+256*SCAN_UNROLL-1)/(256*SCAN_UNROLL);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256*8) blocks = 256*8;               // 8 blocks per CU, grid-stride beyond that
+  return (int)blocks;
+}
+
+static int launch_scan(const cp_dev_params *hostP, const uint16_t *d_prof, int64_t total, uint64_t *d_bitmap,
+                       int64_t nwords, hipStream_t st)
+{ if (((uintptr_t)d_prof) & 15)
+    return set_err(CP_EINVAL,"profile buffer must be 16-byte aligned");
+  int64_t first = total >> 3;                        // bytes from here to the end must start out zero
+  HIPCHK(hipMemsetAsync((uint8_t *)d_bitmap+first,0,(size_t)(nwords*8-first),st));
+  hipLaunchKernelGGL(k_scan_candidates,dim3(scan_grid(total)),dim3(256),0,st,
+                     d_prof,total,hostP->cov[CP_REPEAT],(uint8_t *)d_bitmap);
+  HIPCHK(hipGetLastError());
+  return CP_OK;
+}
+
+extern "C" int cp_scan_candidates(const cp_params *p, const uint16_t *d_prof, int64_t total_kmers,
+                                  uint64_t *d_bitmap, void *stream)
+{ if (!p || !d_prof || !d_bitmap || total_kmers < 0)
+    return set_err(CP_EINVAL,"cp_scan_candidates: bad argument");
+  return launch_scan(&p->host,d_prof,total_kmers,d_bitmap,total_kmers/64+1,(hipStream_t)stream);
+}
+
+extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
+                             const char *d_seq, const int64_t *d_seq_off,
+                             const uint16_t *d_prof, const int64_t *d_prof_off,
+                             int nreads, int64_t total_bases, int64_t total_kmers,
+                             char *d_labels, int last_stage, void *stream)
+{ if (!p || !ws || !d_seq || !d_seq_off || !d_prof || !d_prof_off || nreads < 0 || total_bases < 0 || total_kmers < 0)
+    return set_err(CP_EINVAL,"cp_run_stages: bad argument");
+  if (last_stage < CP_STAGE_SCAN || last_stage > CP_STAGE_LABELS)
+    return set_err(CP_EINVAL,"cp_run_stages: bad stage");
+  if (last_stage == CP_STAGE_LABELS && !d_labels)
+    return set_err(CP_EINVAL,"cp_run_stages: labels buffer required");
+  hipStream_t st = (hipStream_t)stream;
+  ws->nreads = nreads; ws->total_kmers = total_kmers; ws->total_bases = total_bases;
+  ws->totalI = ws->totalE = 0; ws->last_stage = last_stage; ws->stream = st;
+  ws->nwords = total_kmers/64+2;
+  if (nreads == 0)
+    return CP_OK;
+
+  // ---- stage 1: candidate scan + capacities ------------------------------------------------
+  ENSURE(ws->bitmap,ws->nwords*8);
+  ENSURE(ws->ncand,(size_t)nreads*4);
+  ENSURE(ws->nintvl,(size_t)nreads*4);
+  ENSURE(ws->nrel,(size_t)nreads*4);
+  ENSURE(ws->ioff,((size_t)nreads+1)*8);
+  ENSURE(ws->eoff,((size_t)nreads+1)*8);
+  ENSURE(ws->err,16);
+  HIPCHK(hipMemsetAsync(ws->err.p,0,16,st));
+  HIPCHK(hipMemsetAsync(ws->nintvl.p,0,(size_t)nreads*4,st));
+  HIPCHK(hipMemsetAsync(ws->nrel.p,0,(size_t)nreads*4,st));
+  int rc = launch_scan(&p->host,d_prof,total_kmers,(uint64_t *)ws->bitmap.p,ws->nwords,st);
+  if (rc != CP_OK) return rc;
+  hipLaunchKernelGGL(k_count_caps,dim3(nreads),dim3(WAVE),0,st,
+                     (const uint64_t *)ws->bitmap.p,d_prof_off,nreads,
+                     (int32_t *)ws->ncand.p,(int64_t *)ws->ioff.p,(int64_t *)ws->eoff.p);
+  hipLaunchKernelGGL(k_prefix_caps,dim3(1),dim3(1024),0,st,(int64_t *)ws->ioff.p,(int64_t *)ws->eoff.p,nreads);
+  HIPCHK(hipGetLastError());
+  if (last_stage == CP_STAGE_SCAN)
+    return CP_OK;
+
+  // the only host round trip of the pipeline: scratch sizes depend on the data
+  HIPCHK(hipMemcpyAsync(&ws->h_totals[0],(int64_t *)ws->ioff.p+nreads,8,hipMemcpyDeviceToHost,st));
+  HIPCHK(hipMemcpyAsync(&ws->h_totals[1],(int64_t *)ws->eoff.p+nreads,8,hipMemcpyDeviceToHost,st));
+  HIPCHK(hipStreamSynchronize(st));
+  const int64_t totalI = ws->h_totals[0], totalE = ws->h_totals[1];
+  ws->totalI = totalI; ws->totalE = totalE;
+
+  // ---- stage 2: find_wall ----------------------------------------------------------------------
+  const int64_t ncell = total_kmers+nreads;
+  ENSURE(ws->wall,ncell);
+  ENSURE(ws->perror,(size_t)ncell*4*8);
+  ENSURE(ws->eintvl,(size_t)totalE*sizeof(cp_eintvl));
+  ENSURE(ws->ointvl,(size_t)totalE*sizeof(cp_eintvl));
+  ENSURE(ws->intvl,(size_t)totalI*sizeof(cp_intvl));
+  HIPCHK(hipMemsetAsync(ws->wall.p,0,(size_t)ncell,st));
+  hipLaunchKernelGGL(k_fill_f64,dim3(256*8),dim3(256),0,st,(double *)ws->perror.p,ncell*4,-INFINITY);
+  hipLaunchKernelGGL(k_find_wall,dim3(nreads),dim3(WAVE),0,st,
+                     p->dev,d_seq,d_seq_off,d_prof,d_prof_off,nreads,(const uint64_t *)ws->bitmap.p,
+                     (uint8_t *)ws->wall.p,(double *)ws->perror.p,(cp_eintvl *)ws->eintvl.p,(cp_eintvl *)ws->ointvl.p,
+                     (const int64_t *)ws->eoff.p,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,
+                     (int32_t *)ws->nintvl.p,(int32_t *)ws->err.p);
+  HIPCHK(hipGetLastError());
+  if (last_stage == CP_STAGE_WALL)
+    return CP_OK;
+
+  // ---- stage 3: find_rel_intvl -------------------------------------------------------------------
+  ENSURE(ws->rintvl,(size_t)totalI*sizeof(cp_intvl));
+  ENSURE(ws->relmap,(size_t)totalI*4);
+  hipLaunchKernelGGL(k_find_rel,dim3(nreads),dim3(WAVE),0,st,
+                     p->dev,d_seq,d_seq_off,d_prof,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,
+                     (int32_t *)ws->relmap.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,(int32_t *)ws->nrel.p);
+  HIPCHK(hipGetLastError());
+  if (last_stage == CP_STAGE_REL)
+    return CP_OK;
+
+  // ---- stage 4: classify_rel -------------------------------------------------------------------
+  ENSURE(ws->parent,(size_t)totalI*2*4);
+  ENSURE(ws->eff,(size_t)totalI*2*4);
+  ENSURE(ws->rpos,(size_t)totalI*2);
+  ENSURE(ws->asgn,(size_t)totalI*2);
+  HIPCHK(hipMemsetAsync(ws->asgn.p,0xff,(size_t)totalI*2,st));
+  hipLaunchKernelGGL(k_classify_rel,dim3(nreads),dim3(WAVE),0,st,
+                     p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
+                     (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->parent.p,(int32_t *)ws->eff.p,
+                     (uint8_t *)ws->rpos.p,(int8_t *)ws->asgn.p,totalI);
+  HIPCHK(hipGetLastError());
+  if (last_stage == CP_STAGE_CLASS_REL)
+    return CP_OK;
+
+  // ---- stage 5: classify_unrel -------------------------------------------------------------------
+  ENSURE(ws->ord,(size_t)totalI*4);
+  hipLaunchKernelGGL(k_classify_unrel,dim3(nreads),dim3(WAVE),0,st,
+                     p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
+                     (int32_t *)ws->ord.p);
+  HIPCHK(hipGetLastError());
+  if (last_stage == CP_STAGE_CLASS_ALL)
+    return CP_OK;
+
+  // ---- stage 6: labels ---------------------------------------------------------------------------
+  hipLaunchKernelGGL(k_paint_labels,dim3(nreads),dim3(WAVE),0,st,
+                     p->dev,d_seq_off,nreads,(const cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,
+                     (const int32_t *)ws->nintvl.p,d_labels);
+  HIPCHK(hipGetLastError());
+  return CP_OK;
+}
+
+extern "C" int cp_classify_batch(const cp_params *p, cp_workspace *ws,
+                                 const char *d_seq, const int64_t *d_seq_off,
+                                 const uint16_t *d_prof, const int64_t *d_prof_off,
+                                 int nreads, int64_t total_bases, int64_t total_kmers,
+                                 char *d_labels, void *stream)
+{ return cp_run_stages(p,ws,d_seq,d_seq_off,d_prof,d_prof_off,nreads,total_bases,total_kmers,d_labels,
+                       CP_STAGE_LABELS,stream);
+}
+
+// Waits for the last run on `ws` and reports scratch overflow (E-interval list or interval array).
+// The reference aborts in the same situation ("# E-intvls >= plen", wall.c:783-788).
+extern "C" int cp_workspace_check(cp_workspace *ws)
+{ if (!ws) return set_err(CP_EINVAL,"cp_workspace_check: null workspace");
+  if (ws->nreads == 0) return CP_OK;
+  HIPCHK(hipMemcpyAsync(ws->h_err,ws->err.p,4,hipMemcpyDeviceToHost,ws->stream));
+  HIPCHK(hipStreamSynchronize(ws->stream));
+  if (*ws->h_err)
+    { char m[96];
+      snprintf(m,sizeof(m),"scratch overflow in find_wall (flags=%d): too many E-intervals for a read",*ws->h_err);
+      return set_err(CP_EOVERFLOW,m);
+    }
+  return CP_OK;
+}
+
+extern "C" int cp_get_counts(cp_workspace *ws, int32_t *n_cand, int32_t *n_intvl, int32_t *n_rel, int64_t *cap_off)
+{ if (!ws) return set_err(CP_EINVAL,"cp_get_counts: null workspace");
+  int rc = cp_workspace_check(ws);
+  if (rc != CP_OK) return rc;
+  size_t n = (size_t)ws->nreads;
+  if (n == 0) return CP_OK;
+  if (n_cand)  HIPCHK(hipMemcpy(n_cand,ws->ncand.p,n*4,hipMemcpyDeviceToHost));
+  if (n_intvl) HIPCHK(hipMemcpy(n_intvl,ws->nintvl.p,n*4,hipMemcpyDeviceToHost));
+  if (n_rel)   HIPCHK(hipMemcpy(n_rel,ws->nrel.p,n*4,hipMemcpyDeviceToHost));
+  if (cap_off) HIPCHK(hipMemcpy(cap_off,ws->ioff.p,(n+1)*8,hipMemcpyDeviceToHost));
+  return CP_OK;
+}
+
+extern "C" int cp_get_intervals(cp_workspace *ws, cp_intvl *intvl, cp_intvl *rintvl, int64_t capacity)
+{ if (!ws) return set_err(CP_EINVAL,"cp_get_intervals: null workspace");
+  if (capacity < ws->totalI) return set_err(CP_EINVAL,"cp_get_intervals: capacity too small");
+  int rc = cp_workspace_check(ws);
+  if (rc != CP_OK) return rc;
+  size_t bytes = (size_t)ws->totalI*sizeof(cp_intvl);
+  if (bytes == 0) return CP_OK;
+  if (intvl && ws->last_stage >= CP_STAGE_WALL) HIPCHK(hipMemcpy(intvl,ws->intvl.p,bytes,hipMemcpyDeviceToHost));
+  if (rintvl && ws->last_stage >= CP_STAGE_REL) HIPCHK(hipMemcpy(rintvl,ws->rintvl.p,bytes,hipMemcpyDeviceToHost));
+  return CP_OK;
+}
+
+extern "C" int cp_get_rel_asgn(cp_workspace *ws, int8_t *fw, int8_t *bw, int64_t capacity)
+{ if (!ws) return set_err(CP_EINVAL,"cp_get_rel_asgn: null workspace");
+  if (capacity < ws->totalI) return set_err(CP_EINVAL,"cp_get_rel_asgn: capacity too small");
+  if (ws->last_stage < CP_STAGE_CLASS_REL) return set_err(CP_EINVAL,"cp_get_rel_asgn: stage not run");
+  int rc = cp_workspace_check(ws);
+  if (rc != CP_OK) return rc;
+  size_t n = (size_t)ws->totalI;
+  if (n == 0) return CP_OK;
+  if (fw) HIPCHK(hipMemcpy(fw,ws->asgn.p,n,hipMemcpyDeviceToHost));
+  if (bw) HIPCHK(hipMemcpy(bw,(int8_t *)ws->asgn.p+n,n,hipMemcpyDeviceToHost));
+  return CP_OK;
+}
+
+extern "C" int cp_get_bitmap(cp_workspace *ws, uint64_t *words, int64_t nwords)
+{ if (!ws || !words) return set_err(CP_EINVAL,"cp_get_bitmap: null argument");
+  if (nwords > ws->nwords) nwords = ws->nwords;
+  HIPCHK(hipStreamSynchronize(ws->stream));
+  if (nwords > 0) HIPCHK(hipMemcpy(words,ws->bitmap.p,(size_t)nwords*8,hipMemcpyDeviceToHost));
+  return CP_OK;
+}
+
+extern "C" int cp_seq_context(const char *d_seq, const int64_t *d_seq_off, int nreads, int64_t total_bases,
+                              uint8_t *d_lctx, uint8_t *d_rctx, void *stream)
+{ if (!d_seq || !d_seq_off || !d_lctx || !d_rctx || nreads < 0)
+    return set_err(CP_EINVAL,"cp_seq_context: bad argument");
+  (void)total_bases;
+  if (nreads == 0) return CP_OK;
+  hipLaunchKernelGGL(k_seq_context,dim3(nreads),dim3(256),0,(hipStream_t)stream,d_seq,d_seq_off,nreads,d_lctx,d_rctx);
+  HIPCHK(hipGetLastError());
+  return CP_OK;
+}

@@ -100,6 +100,11 @@ int cp_classify_batch(const cp_params *p, cp_workspace *ws,
                       int nreads, int64_t total_bases, int64_t total_kmers,
                       char *d_labels, void *stream);
 
+/* Waits for the last run on `ws` and returns CP_EOVERFLOW if a read needed more E-interval /
+ * interval scratch than its capacity (the reference aborts likewise: "# E-intvls >= plen",
+ * src/wall.c:783-788).  Call after cp_classify_batch before trusting the labels. */
+int cp_workspace_check(cp_workspace *ws);
+
 /* Stage entry points (the reference's per-read internal contract, batched).  They run the
  * pipeline up to and including the named stage and keep the results in `ws`:
  *   CP_STAGE_SCAN      candidate scan of find_wall (wall.c:590-607): bitmap of wall candidates
