@@ -16,6 +16,12 @@
 
 #define CP_NONE (-1)
 
+#ifdef __HIPCC__
+#define CP_HDM __host__ __device__ __forceinline__
+#else
+#define CP_HDM inline
+#endif
+
 struct cp_cell                       // one DP cell = (interval i, state s); ClassPro.h:210-219 per cell
   { double dp;                       // normalised log score, -inf = unreachable
     double dhr;                      // D/H ratio on the best path (dh_ratio), -inf = none yet
@@ -25,22 +31,26 @@ struct cp_cell                       // one DP cell = (interval i, state s); Cla
     int    lastHbD, lastDbH;         // last H before lastD / last D before lastH
   };
 
+// Hot fields of a reliable interval (the DP never needs more).
+struct cp_riv { int b, e, ccb, cce; double pe; };
+CP_HD cp_riv cp_riv_of(const cp_intvl &I) { cp_riv r; r.b = I.b; r.e = I.e; r.ccb = I.ccb; r.cce = I.cce; r.pe = I.pe; return r; }
+
 // class_rel.c:45-58 accessors.  fw: positions grow with the path; bw: the mirror.
 CP_HD int cp_pred(int x, int F)   { return F ? x-1 : x+1; }
 CP_HD int cp_offs(int x, int F)   { return F ? x-CP_OFFSET : x+CP_OFFSET; }
-CP_HD int cp_beg_pos(const cp_intvl &I, int F) { return F ? I.b : I.e-1; }
-CP_HD int cp_beg_cnt(const cp_intvl &I, int F) { return F ? I.ccb : I.cce; }
-CP_HD int cp_end_pos(const cp_intvl &I, int F) { return F ? I.e-1 : I.b; }
-CP_HD int cp_end_cnt(const cp_intvl &I, int F) { return F ? I.cce : I.ccb; }
+CP_HD int cp_beg_pos(const cp_riv &I, int F) { return F ? I.b : I.e-1; }
+CP_HD int cp_beg_cnt(const cp_riv &I, int F) { return F ? I.ccb : I.cce; }
+CP_HD int cp_end_pos(const cp_riv &I, int F) { return F ? I.e-1 : I.b; }
+CP_HD int cp_end_cnt(const cp_riv &I, int F) { return F ? I.cce : I.ccb; }
 
 // class_rel.c:158-170
-CP_HD double cp_logp_e(const cp_dev_params *P, const cp_intvl &I, const int *COV)
+CP_HD double cp_logp_e(const cp_dev_params *P, const cp_riv &I, const int *COV)
 { double logp_po = cp_logp_poisson(P,I.ccb,COV[CP_ERROR])+cp_logp_poisson(P,I.cce,COV[CP_ERROR])+CP_E_PO_BASE;
   return (logp_po > I.pe) ? logp_po : I.pe;
 }
 
 // class_rel.c:172-211
-CP_HD double cp_logp_r(const cp_dev_params *P, const cp_intvl &I, int pred_r_cnt, int F, const int *COV)
+CP_HD double cp_logp_r(const cp_dev_params *P, const cp_riv &I, int pred_r_cnt, int F, const int *COV)
 { int beg_cnt = cp_beg_cnt(I,F);
   double logp = (beg_cnt < pred_r_cnt) ? cp_logp_binom_pre(P,beg_cnt,pred_r_cnt,P->r_lp,P->r_l1mp) : -INFINITY;
   if (logp > CP_R_LOGP)
@@ -52,7 +62,7 @@ CP_HD double cp_logp_r(const cp_dev_params *P, const cp_intvl &I, int pred_r_cnt
 }
 
 // class_rel.c:213-240.  With a D/H ratio on the path only the D-anchored transition survives.
-CP_HD double cp_logp_h(const cp_dev_params *P, const cp_intvl &I, const cp_cell &pr, int F)
+CP_HD double cp_logp_h(const cp_dev_params *P, const cp_riv &I, const cp_cell &pr, int F)
 { int beg_pos = cp_beg_pos(I,F), beg_cnt = cp_beg_cnt(I,F);
   if (pr.dhr != -INFINITY)
     return cp_logp_trans(P,cp_pred(pr.pos[CP_DIPLO],F),beg_pos,pr.cnt[CP_DIPLO],(int)(pr.dhr*beg_cnt),pr.cnt[CP_DIPLO]);
@@ -60,11 +70,11 @@ CP_HD double cp_logp_h(const cp_dev_params *P, const cp_intvl &I, const cp_cell 
 }
 
 // class_rel.c:242-270.  Line 264 overwrites the ratio branch: always the D-anchored transition.
-CP_HD double cp_logp_d(const cp_dev_params *P, const cp_intvl &I, const cp_cell &pr, int F)
+CP_HD double cp_logp_d(const cp_dev_params *P, const cp_riv &I, const cp_cell &pr, int F)
 { return cp_logp_trans(P,cp_pred(pr.pos[CP_DIPLO],F),cp_beg_pos(I,F),pr.cnt[CP_DIPLO],cp_beg_cnt(I,F),pr.cnt[CP_DIPLO]); }
 
 // class_rel.c:272-277: transition s@pred -> t@i
-CP_HD double cp_calc_logp(const cp_dev_params *P, int t, const cp_intvl &I, const cp_cell &pr, int F, const int *COV)
+CP_HD double cp_calc_logp(const cp_dev_params *P, int t, const cp_riv &I, const cp_cell &pr, int F, const int *COV)
 { if (t == CP_ERROR)      return cp_logp_e(P,I,COV);
   else if (t == CP_HAPLO) return cp_logp_h(P,I,pr,F);
   else if (t == CP_DIPLO) return cp_logp_d(P,I,pr,F);
@@ -73,7 +83,7 @@ CP_HD double cp_calc_logp(const cp_dev_params *P, int t, const cp_intvl &I, cons
 
 // calc_dh_ratio (class_rel.c:113-156) from the anchor indices: i1 = this interval (state init_s),
 // i2 = nearest earlier interval of the other class, i3 = nearest interval of init_s before i2.
-CP_HD double cp_dh_ratio(int init_s, const cp_intvl &I1, const cp_intvl &I2, const cp_intvl &I3, int F)
+CP_HD double cp_dh_ratio(int init_s, const cp_riv &I1, const cp_riv &I2, const cp_riv &I3, int F)
 { int s1p = cp_beg_pos(I1,F), s1c = cp_beg_cnt(I1,F);
   int tp  = cp_end_pos(I2,F), tc  = cp_end_cnt(I2,F);
   int s2p = cp_end_pos(I3,F), s2c = cp_end_cnt(I3,F);
@@ -85,14 +95,15 @@ CP_HD double cp_dh_ratio(int init_s, const cp_intvl &I1, const cp_intvl &I2, con
   return (init_s == CP_DIPLO) ? est/tc : tc/est;
 }
 
-// class_rel.c:80-96 with s fixed (best target of source s) or t fixed (best source of target t)
-CP_HD int cp_argmax_tr(const cp_cell *prev, const double tr[4][4], int s, int t, double *best)
+// class_rel.c:80-96 with s fixed (best target of source s) or t fixed (best source of target t).
+// dp[4] = scores of the previous interval's cells, tr = normalised log transition matrix [s*4+t].
+CP_HD int cp_argmax_tr(const double *dp, const double *tr, int s, int t, double *best)
 { double max_logp = -INFINITY;
   int max_x = CP_N_STATE;
   for (int x = 0; x < 4; x++)
     { int _s = (s < CP_N_STATE) ? s : x;
       int _t = (t < CP_N_STATE) ? t : x;
-      double logp = prev[_s].dp+tr[_s][_t];
+      double logp = dp[_s]+tr[_s*4+_t];
       if (max_logp < logp)
         { max_logp = logp;
           max_x = x;
@@ -102,7 +113,120 @@ CP_HD int cp_argmax_tr(const cp_cell *prev, const double tr[4][4], int s, int t,
   return max_x;
 }
 
-// One direction of _classify_rel (class_rel.c:515-614) for a read.
+// First cell of a pass for state s (class_rel.c:544-580), before the normalisation of :582-586.
+CP_HD void cp_rel_init_cell(const cp_dev_params *P, int s, const cp_riv &I, int i, int plen, int F,
+                            const int *COV, cp_cell *c)
+{ const int POS_INIT = cp_offs(F ? 0 : plen,F);
+  const int ep = cp_end_pos(I,F), ec = cp_end_cnt(I,F), bc = cp_beg_cnt(I,F);
+  for (int t = 0; t < 4; t++)
+    { c->pos[t] = POS_INIT;
+      c->cnt[t] = COV[t];
+    }
+  c->dhr = -INFINITY;
+  c->lastH = c->lastD = c->lastHbD = c->lastDbH = CP_NONE;
+  if (s == CP_ERROR)
+    c->dp = cp_logp_e(P,I,COV);
+  else if (s == CP_REPEAT)
+    { c->dp = cp_logp_r(P,I,c->cnt[CP_REPEAT],F,COV);
+      c->pos[CP_REPEAT] = ep;
+      c->cnt[CP_REPEAT] = ec < COV[CP_REPEAT] ? ec : COV[CP_REPEAT];
+    }
+  else if (s == CP_HAPLO)
+    { c->dp = cp_logp_poisson(P,bc,COV[CP_HAPLO]);
+      c->pos[CP_HAPLO] = ep;
+      c->cnt[CP_HAPLO] = ec;
+      c->pos[CP_DIPLO] = cp_offs(ep,F);
+      c->cnt[CP_DIPLO] = (ec+COV[CP_HAPLO]) & 0xffff;
+      c->lastH = i;
+    }
+  else
+    { c->dp = cp_logp_poisson(P,bc,COV[CP_DIPLO]);
+      c->pos[CP_HAPLO] = cp_offs(ep,F);
+      c->cnt[CP_HAPLO] = ((ec/2 > ec-COV[CP_HAPLO]) ? ec/2 : ec-COV[CP_HAPLO]) & 0xffff;
+      c->pos[CP_DIPLO] = ep;
+      c->cnt[CP_DIPLO] = ec;
+      c->lastD = i;
+    }
+}
+
+// "Only R reachable" step (class_rel.c:349-380) for state s: the cell is carried over and the path
+// gains one more interval of state s (whose data stands in for the predecessor's).
+CP_HD void cp_rel_only_r_cell(int s, int i, cp_cell *c)
+{ if (c->dp == -INFINITY)
+    return;
+  if (s == CP_HAPLO)      { c->lastDbH = c->lastD; c->lastH = i; }
+  else if (s == CP_DIPLO) { c->lastHbD = c->lastH; c->lastD = i; }
+  c->dhr = -INFINITY;                                    // dh_ratio[i][s] is left at its reset value (:520-522)
+}
+
+// New cell for target state t at interval i given its best predecessor (class_rel.c:390-499).
+// View gives the hot fields of the interval standing in for path index k: view(k) -> cp_riv.
+template <class View>
+CP_HD void cp_rel_target_cell(const cp_dev_params *P, int t, int i, const cp_riv &I, int F, const int *COV,
+                              int max_s, double max_logp, const cp_cell *prev, const View &view, cp_cell *out)
+{ cp_cell c;
+  c.dp = max_logp;
+  c.dhr = -INFINITY;
+  if (max_s == CP_N_STATE)
+    { for (int k = 0; k < 4; k++) { c.pos[k] = 0; c.cnt[k] = 0; }
+      c.lastH = c.lastD = c.lastHbD = c.lastDbH = CP_NONE;
+      *out = c;
+      return;
+    }
+  const cp_cell pr = prev[max_s];
+  const int end_pos = cp_end_pos(I,F), end_cnt = cp_end_cnt(I,F);
+  c.lastH = pr.lastH; c.lastD = pr.lastD; c.lastHbD = pr.lastHbD; c.lastDbH = pr.lastDbH;
+  for (int k = 0; k < 4; k++) { c.pos[k] = pr.pos[k]; c.cnt[k] = pr.cnt[k]; }
+
+  if (t == CP_ERROR)
+    { /* anchors R,H,D carried over (:409-412) */ }
+  else if (t == CP_REPEAT)
+    { c.pos[CP_HAPLO] = c.pos[CP_DIPLO] = cp_offs(end_pos,F);          // counts carried over (:415-418)
+      int r_cnt = end_cnt < COV[CP_REPEAT] ? end_cnt : COV[CP_REPEAT];
+      if (!(pr.cnt[CP_REPEAT] < r_cnt))
+        { c.pos[CP_REPEAT] = cp_offs(end_pos,F);
+          c.cnt[CP_REPEAT] = r_cnt;
+        }
+    }
+  else
+    { const int other = (t == CP_HAPLO) ? CP_DIPLO : CP_HAPLO;
+      const int i2 = (t == CP_HAPLO) ? pr.lastD : pr.lastH;               // nearest other-class anchor
+      const int i3 = (t == CP_HAPLO) ? pr.lastHbD : pr.lastDbH;           // nearest same-class anchor before it
+      int curr_t = end_cnt, curr_o;
+      if (i2 == CP_NONE || i3 == CP_NONE)                                 // r == -inf (:423-438 / :466-481)
+        { if (i2 != CP_NONE)
+            curr_o = pr.cnt[other];
+          else if (t == CP_HAPLO)
+            curr_o = curr_t+COV[CP_HAPLO];
+          else
+            curr_o = (curr_t/2 > curr_t-COV[CP_HAPLO]) ? curr_t/2 : curr_t-COV[CP_HAPLO];
+        }
+      else
+        { double r = cp_dh_ratio(t,I,view(i2),view(i3),F);
+          curr_o = (t == CP_HAPLO) ? (int)(r*curr_t) : (int)((double)curr_t/r);
+          c.dhr = r;
+        }
+      int curr_d = (t == CP_HAPLO) ? curr_o : curr_t;
+      int curr_h = (t == CP_HAPLO) ? curr_t : curr_o;
+      int curr_r = (int)(P->dr_ratio*curr_d);
+      c.pos[CP_HAPLO] = c.pos[CP_DIPLO] = c.pos[CP_REPEAT] = cp_offs(end_pos,F);
+      c.cnt[CP_HAPLO]  = curr_h & 0xffff;
+      c.cnt[CP_DIPLO]  = curr_d & 0xffff;
+      c.cnt[CP_REPEAT] = curr_r & 0xffff;
+      if (t == CP_HAPLO) { c.lastDbH = pr.lastD; c.lastH = i; }
+      else               { c.lastHbD = pr.lastH; c.lastD = i; }
+    }
+  if (!((c.cnt[CP_HAPLO] < c.cnt[CP_DIPLO]) && (c.cnt[CP_DIPLO] < c.cnt[CP_REPEAT])))   // :496-498
+    c.dp = -INFINITY;
+  *out = c;
+}
+
+struct cp_aos_view                   // path index -> hot fields, through the `eff` indirection
+  { const cp_intvl *rintvl; const int *eff;
+    CP_HDM cp_riv operator()(int k) const { return cp_riv_of(rintvl[eff[k]]); }
+  };
+
+// One direction of _classify_rel (class_rel.c:515-614) for a read, sequential form.
 //   rintvl[M]   reliable intervals (read-only)
 //   parent[M*4] back-pointers, eff[M] index of the interval whose data stands in for i (the
 //               reference overwrites arg->intvl[i] with its predecessor at "only R" steps, :351)
@@ -111,35 +235,13 @@ CP_HD void cp_rel_direction(const cp_dev_params *P, const cp_intvl *rintvl, int 
                             const int *COV, int8_t *parent, int *eff, uint8_t *rpos, int8_t *asgn)
 { cp_cell prev[4], cur[4];
   int i = F ? 0 : M-1;
-  const int POS_INIT = cp_offs(F ? 0 : plen,F);
+  cp_aos_view view; view.rintvl = rintvl; view.eff = eff;
 
-  { const cp_intvl I = rintvl[i];                        // init, class_rel.c:544-586
-    const int ep = cp_end_pos(I,F), ec = cp_end_cnt(I,F), bc = cp_beg_cnt(I,F);
+  { const cp_riv I = cp_riv_of(rintvl[i]);                // init, class_rel.c:544-586
     for (int s = 0; s < 4; s++)
-      { for (int t = 0; t < 4; t++)
-          { prev[s].pos[t] = POS_INIT;
-            prev[s].cnt[t] = COV[t];
-          }
-        prev[s].dhr = -INFINITY;
-        prev[s].lastH = prev[s].lastD = prev[s].lastHbD = prev[s].lastDbH = CP_NONE;
+      { cp_rel_init_cell(P,s,I,i,plen,F,COV,&prev[s]);
         parent[i*4+s] = (int8_t)s;
       }
-    prev[CP_ERROR].dp = cp_logp_e(P,I,COV);
-    prev[CP_REPEAT].dp = cp_logp_r(P,I,prev[CP_REPEAT].cnt[CP_REPEAT],F,COV);
-    prev[CP_REPEAT].pos[CP_REPEAT] = ep;
-    prev[CP_REPEAT].cnt[CP_REPEAT] = ec < COV[CP_REPEAT] ? ec : COV[CP_REPEAT];
-    prev[CP_HAPLO].dp = cp_logp_poisson(P,bc,COV[CP_HAPLO]);
-    prev[CP_HAPLO].pos[CP_HAPLO] = ep;
-    prev[CP_HAPLO].cnt[CP_HAPLO] = ec;
-    prev[CP_HAPLO].pos[CP_DIPLO] = cp_offs(ep,F);
-    prev[CP_HAPLO].cnt[CP_DIPLO] = (ec+COV[CP_HAPLO]) & 0xffff;
-    prev[CP_HAPLO].lastH = i;
-    prev[CP_DIPLO].dp = cp_logp_poisson(P,bc,COV[CP_DIPLO]);
-    prev[CP_DIPLO].pos[CP_HAPLO] = cp_offs(ep,F);
-    prev[CP_DIPLO].cnt[CP_HAPLO] = ((ec/2 > ec-COV[CP_HAPLO]) ? ec/2 : ec-COV[CP_HAPLO]) & 0xffff;
-    prev[CP_DIPLO].pos[CP_DIPLO] = ep;
-    prev[CP_DIPLO].cnt[CP_DIPLO] = ec;
-    prev[CP_DIPLO].lastD = i;
     double psum = 0.;
     for (int s = 0; s < 4; s++)
       psum += exp(prev[s].dp);
@@ -154,37 +256,35 @@ CP_HD void cp_rel_direction(const cp_dev_params *P, const cp_intvl *rintvl, int 
       i = F ? i+1 : i-1;
       if ((F && i >= M) || (!F && i < 0))
         break;
-      const cp_intvl I = rintvl[i];
-      const int end_pos = cp_end_pos(I,F), end_cnt = cp_end_cnt(I,F);
+      const cp_riv I = cp_riv_of(rintvl[i]);
       rpos[i] = 0;
       eff[i] = i;
 
-      double tr[4][4];                                   // :300-336
+      double tr[16], dp[4];                              // :300-336
       for (int s = 0; s < 4; s++)
-        { if (prev[s].dp == -INFINITY)
-            { for (int t = 0; t < 4; t++) tr[s][t] = 0.;
+        { dp[s] = prev[s].dp;
+          if (prev[s].dp == -INFINITY)
+            { for (int t = 0; t < 4; t++) tr[s*4+t] = 0.;
               continue;
             }
           for (int t = 0; t < 4; t++)
-            tr[s][t] = exp(cp_calc_logp(P,t,I,prev[s],F,COV));
+            tr[s*4+t] = exp(cp_calc_logp(P,t,I,prev[s],F,COV));
         }
       double psum = 0.;
-      for (int s = 0; s < 4; s++)
-        for (int t = 0; t < 4; t++)
-          psum += tr[s][t];
+      for (int k = 0; k < 16; k++)
+        psum += tr[k];
       if (psum == 0.)                                    // :324-333 (DEBUG build keeps going with E)
         { for (int s = 0; s < 4; s++)
-            tr[s][CP_ERROR] = 1.;
+            tr[s*4+CP_ERROR] = 1.;
           psum = 4.;
         }
-      for (int s = 0; s < 4; s++)
-        for (int t = 0; t < 4; t++)
-          tr[s][t] = log(tr[s][t]/psum);
+      for (int k = 0; k < 16; k++)
+        tr[k] = log(tr[k]/psum);
 
       bool only_r = true;                                // :348-380
       for (int s = 0; s < 4; s++)
         { double dummy;
-          int maxt = cp_argmax_tr(prev,tr,s,CP_N_STATE,&dummy);
+          int maxt = cp_argmax_tr(dp,tr,s,CP_N_STATE,&dummy);
           if (maxt != CP_N_STATE && maxt != CP_REPEAT)
             { only_r = false;
               break;
@@ -195,83 +295,25 @@ CP_HD void cp_rel_direction(const cp_dev_params *P, const cp_intvl *rintvl, int 
           eff[i] = eff[i_pred];
           for (int s = 0; s < 4; s++)
             { parent[i*4+s] = (int8_t)s;
-              if (prev[s].dp == -INFINITY)
-                continue;
-              // the path gains one more cell of state s whose interval data is the predecessor's
-              if (s == CP_HAPLO)      { prev[s].lastDbH = prev[s].lastD; prev[s].lastH = i; }
-              else if (s == CP_DIPLO) { prev[s].lastHbD = prev[s].lastH; prev[s].lastD = i; }
-              prev[s].dhr = -INFINITY;                   // dh_ratio[i][s] is left at its reset value (:520-522)
+              cp_rel_only_r_cell(s,i,&prev[s]);
             }
           continue;
         }
 
       { double dummy;                                    // :382-386
-        int maxs_h = cp_argmax_tr(prev,tr,CP_N_STATE,CP_HAPLO,&dummy);
-        int maxs_d = cp_argmax_tr(prev,tr,CP_N_STATE,CP_DIPLO,&dummy);
+        int maxs_h = cp_argmax_tr(dp,tr,CP_N_STATE,CP_HAPLO,&dummy);
+        int maxs_d = cp_argmax_tr(dp,tr,CP_N_STATE,CP_DIPLO,&dummy);
         if (maxs_h == CP_HAPLO && maxs_d == CP_DIPLO)
-          { double mn = tr[CP_HAPLO][CP_HAPLO] < tr[CP_DIPLO][CP_DIPLO] ? tr[CP_HAPLO][CP_HAPLO] : tr[CP_DIPLO][CP_DIPLO];
-            tr[CP_HAPLO][CP_HAPLO] = tr[CP_DIPLO][CP_DIPLO] = mn;
+          { double mn = tr[CP_HAPLO*4+CP_HAPLO] < tr[CP_DIPLO*4+CP_DIPLO] ? tr[CP_HAPLO*4+CP_HAPLO] : tr[CP_DIPLO*4+CP_DIPLO];
+            tr[CP_HAPLO*4+CP_HAPLO] = tr[CP_DIPLO*4+CP_DIPLO] = mn;
           }
       }
 
       for (int t = 0; t < 4; t++)                        // :390-499
         { double max_logp;
-          int max_s = cp_argmax_tr(prev,tr,CP_N_STATE,t,&max_logp);
-          cp_cell &c = cur[t];
-          c.dp = max_logp;
-          c.dhr = -INFINITY;
-          if (max_s == CP_N_STATE)
-            { parent[i*4+t] = (int8_t)t;
-              for (int k = 0; k < 4; k++) { c.pos[k] = 0; c.cnt[k] = 0; }
-              c.lastH = c.lastD = c.lastHbD = c.lastDbH = CP_NONE;
-              continue;
-            }
-          const cp_cell &pr = prev[max_s];
-          parent[i*4+t] = (int8_t)max_s;
-          c.lastH = pr.lastH; c.lastD = pr.lastD; c.lastHbD = pr.lastHbD; c.lastDbH = pr.lastDbH;
-          for (int k = 0; k < 4; k++) { c.pos[k] = pr.pos[k]; c.cnt[k] = pr.cnt[k]; }
-
-          if (t == CP_ERROR)
-            { /* anchors R,H,D carried over (:409-412) */ }
-          else if (t == CP_REPEAT)
-            { c.pos[CP_HAPLO] = c.pos[CP_DIPLO] = cp_offs(end_pos,F);      // counts carried over (:415-418)
-              int r_cnt = end_cnt < COV[CP_REPEAT] ? end_cnt : COV[CP_REPEAT];
-              if (!(pr.cnt[CP_REPEAT] < r_cnt))
-                { c.pos[CP_REPEAT] = cp_offs(end_pos,F);
-                  c.cnt[CP_REPEAT] = r_cnt;
-                }
-            }
-          else
-            { const int other = (t == CP_HAPLO) ? CP_DIPLO : CP_HAPLO;
-              const int i2 = (t == CP_HAPLO) ? pr.lastD : pr.lastH;           // nearest other-class anchor
-              const int i3 = (t == CP_HAPLO) ? pr.lastHbD : pr.lastDbH;       // nearest same-class anchor before it
-              int curr_t = end_cnt, curr_o;
-              if (i2 == CP_NONE || i3 == CP_NONE)                             // r == -inf (:423-438 / :466-481)
-                { if (i2 != CP_NONE)
-                    curr_o = pr.cnt[other];
-                  else if (t == CP_HAPLO)
-                    curr_o = curr_t+COV[CP_HAPLO];
-                  else
-                    curr_o = (curr_t/2 > curr_t-COV[CP_HAPLO]) ? curr_t/2 : curr_t-COV[CP_HAPLO];
-                }
-              else
-                { double r = cp_dh_ratio(t,I,rintvl[eff[i2]],rintvl[eff[i3]],F);
-                  // (r == -inf cannot come out of a finite interpolation; mirrors :439-442 / :482-485)
-                  curr_o = (t == CP_HAPLO) ? (int)(r*curr_t) : (int)((double)curr_t/r);
-                  c.dhr = r;
-                }
-              int curr_d = (t == CP_HAPLO) ? curr_o : curr_t;
-              int curr_h = (t == CP_HAPLO) ? curr_t : curr_o;
-              int curr_r = (int)(P->dr_ratio*curr_d);
-              c.pos[CP_HAPLO] = c.pos[CP_DIPLO] = c.pos[CP_REPEAT] = cp_offs(end_pos,F);
-              c.cnt[CP_HAPLO]  = curr_h & 0xffff;
-              c.cnt[CP_DIPLO]  = curr_d & 0xffff;
-              c.cnt[CP_REPEAT] = curr_r & 0xffff;
-              if (t == CP_HAPLO) { c.lastDbH = pr.lastD; c.lastH = i; }
-              else               { c.lastHbD = pr.lastH; c.lastD = i; }
-            }
-          if (!((c.cnt[CP_HAPLO] < c.cnt[CP_DIPLO]) && (c.cnt[CP_DIPLO] < c.cnt[CP_REPEAT])))   // :496-498
-            c.dp = -INFINITY;
+          int max_s = cp_argmax_tr(dp,tr,CP_N_STATE,t,&max_logp);
+          parent[i*4+t] = (int8_t)(max_s == CP_N_STATE ? t : max_s);
+          cp_rel_target_cell(P,t,i,I,F,COV,max_s,max_logp,prev,view,&cur[t]);
         }
       for (int t = 0; t < 4; t++)
         prev[t] = cur[t];
@@ -292,51 +334,56 @@ CP_HD void cp_rel_direction(const cp_dev_params *P, const cp_intvl *rintvl, int 
     }
 }
 
-// classify_rel_fw / classify_rel_bw (class_rel.c:623-845): one direction plus the coverage
-// heuristics; returns hdrr.
-CP_HD double cp_rel_dir_full(const cp_dev_params *P, const cp_intvl *rintvl, int M, int plen, int F,
-                             int8_t *parent, int *eff, uint8_t *rpos, int8_t *asgn)
+// Coverage heuristics after a pass (class_rel.c:629-735 / :743-845), split in two so that the
+// lane-parallel kernel can re-run the DP in between.
+//   part 1: "no H" check; returns true when the pass must be repeated with COV[H], COV[D] adjusted.
+template <class Rv>   // Rv(i) -> cp_riv of reliable interval i
+CP_HD bool cp_rel_post1(const cp_dev_params *P, const Rv &rv, int M, int F, const int8_t *asgn, int *COV)
 { const int *G = P->cov;
-  int COV[4] = { G[0], G[1], G[2], G[3] };
-  cp_rel_direction(P,rintvl,M,plen,F,COV,parent,eff,rpos,asgn);
-
-  bool no_h = true;
   for (int i = 0; i < M; i++)
-    if (asgn[i] == CP_HAPLO) no_h = false;
-  if (no_h)
-    { int l, lsum = 0, csum = 0, seed = -1;
+    if (asgn[i] == CP_HAPLO) return false;
+  int l, lsum = 0, csum = 0, seed = -1;
+  for (int i = 0; i < M; i++)
+    if (asgn[i] == CP_DIPLO)
+      { cp_riv I = rv(i);
+        l = I.e-I.b;
+        lsum += l;
+        csum += (I.ccb+I.cce)*l/2;
+        if (F) { if (seed == -1) seed = i; }             // first D (:641-642)
+        else   seed = i;                                 // last D  (:757)
+      }
+  if (seed < 0) return false;
+  double mean_dcov = (double)csum/lsum;
+  if (!(mean_dcov < G[CP_DIPLO])) return false;
+  cp_riv S = rv(seed);
+  COV[CP_HAPLO] = F ? S.ccb : S.cce;
+  COV[CP_DIPLO] = (COV[CP_HAPLO]+G[CP_HAPLO]) & 0xffff;
+  return true;
+}
+
+//   part 2: after an optional re-run (`rerun`), the remaining relabelling rules; returns hdrr.
+template <class Rv>
+CP_HD double cp_rel_post2(const cp_dev_params *P, const Rv &rv, int M, int F, int8_t *asgn, bool rerun)
+{ const int *G = P->cov;
+  (void)F;
+  if (rerun)                                                 // :651-669
+    { bool no_h = true;
       for (int i = 0; i < M; i++)
-        if (asgn[i] == CP_DIPLO)
-          { l = rintvl[i].e-rintvl[i].b;
-            lsum += l;
-            csum += (rintvl[i].ccb+rintvl[i].cce)*l/2;
-            if (F) { if (seed == -1) seed = i; }             // first D (:641-642)
-            else   seed = i;                                 // last D  (:757)
-          }
-      if (seed >= 0)
-        { double mean_dcov = (double)csum/lsum;
-          if (mean_dcov < G[CP_DIPLO])
-            { COV[CP_HAPLO] = F ? rintvl[seed].ccb : rintvl[seed].cce;
-              COV[CP_DIPLO] = (COV[CP_HAPLO]+G[CP_HAPLO]) & 0xffff;
-              cp_rel_direction(P,rintvl,M,plen,F,COV,parent,eff,rpos,asgn);
-              no_h = true;
-              for (int i = 0; i < M; i++)
-                if (asgn[i] == CP_HAPLO) no_h = false;
-              if (no_h)
-                { lsum = 0; csum = 0;
-                  for (int i = 0; i < M; i++)
-                    if (asgn[i] == CP_DIPLO)
-                      { l = rintvl[i].e-rintvl[i].b;
-                        lsum += l;
-                        csum += (rintvl[i].ccb+rintvl[i].cce)*l/2;
-                      }
-                  mean_dcov = (double)csum/lsum;
-                  if (fabs(mean_dcov-G[CP_HAPLO]) <= fabs(mean_dcov-G[CP_DIPLO]))
-                    for (int i = 0; i < M; i++)
-                      if (asgn[i] == CP_DIPLO)
-                        asgn[i] = CP_HAPLO;
-                }
-            }
+        if (asgn[i] == CP_HAPLO) no_h = false;
+      if (no_h)
+        { int l, lsum = 0, csum = 0;
+          for (int i = 0; i < M; i++)
+            if (asgn[i] == CP_DIPLO)
+              { cp_riv I = rv(i);
+                l = I.e-I.b;
+                lsum += l;
+                csum += (I.ccb+I.cce)*l/2;
+              }
+          double mean_dcov = (double)csum/lsum;
+          if (fabs(mean_dcov-G[CP_HAPLO]) <= fabs(mean_dcov-G[CP_DIPLO]))
+            for (int i = 0; i < M; i++)
+              if (asgn[i] == CP_DIPLO)
+                asgn[i] = CP_HAPLO;
         }
     }
 
@@ -346,9 +393,10 @@ CP_HD double cp_rel_dir_full(const cp_dev_params *P, const cp_intvl *rintvl, int
     if (all_h)
       { int l, lsum = 0, csum = 0;
         for (int i = 0; i < M; i++)
-          { l = rintvl[i].e-rintvl[i].b;
+          { cp_riv I = rv(i);
+            l = I.e-I.b;
             lsum += l;
-            csum += (rintvl[i].ccb+rintvl[i].cce)*l/2;
+            csum += (I.ccb+I.cce)*l/2;
           }
         double mean_hcov = (double)csum/lsum;
         if (fabs(mean_hcov-G[CP_HAPLO]) >= fabs(mean_hcov-G[CP_DIPLO]))
@@ -364,9 +412,10 @@ CP_HD double cp_rel_dir_full(const cp_dev_params *P, const cp_intvl *rintvl, int
       { int l, lsum = 0, csum = 0;
         for (int i = 0; i < M; i++)
           if (asgn[i] == CP_HAPLO)
-            { l = rintvl[i].e-rintvl[i].b;
+            { cp_riv I = rv(i);
+              l = I.e-I.b;
               lsum += l;
-              csum += (rintvl[i].ccb+rintvl[i].cce)*l/2;
+              csum += (I.ccb+I.cce)*l/2;
             }
         double mean_hcov = (double)csum/lsum;
         if (fabs(mean_hcov-G[CP_HAPLO]) >= fabs(mean_hcov-G[CP_DIPLO]))
@@ -388,8 +437,28 @@ CP_HD double cp_rel_dir_full(const cp_dev_params *P, const cp_intvl *rintvl, int
           last_h = i;
         }
     }
-  return (first_d >= 0 && first_h >= 0)
-         ? ((double)rintvl[first_d].ccb/rintvl[first_h].ccb)/((double)rintvl[last_d].cce/rintvl[last_h].cce) : 1.;
+  if (!(first_d >= 0 && first_h >= 0))
+    return 1.;
+  return ((double)rv(first_d).ccb/rv(first_h).ccb)/((double)rv(last_d).cce/rv(last_h).cce);
+}
+
+struct cp_aos_rv
+  { const cp_intvl *rintvl;
+    CP_HDM cp_riv operator()(int i) const { return cp_riv_of(rintvl[i]); }
+  };
+
+// classify_rel_fw / classify_rel_bw (class_rel.c:623-845): one direction plus the coverage
+// heuristics, sequential form; returns hdrr.
+CP_HD double cp_rel_dir_full(const cp_dev_params *P, const cp_intvl *rintvl, int M, int plen, int F,
+                             int8_t *parent, int *eff, uint8_t *rpos, int8_t *asgn)
+{ const int *G = P->cov;
+  int COV[4] = { G[0], G[1], G[2], G[3] };
+  cp_aos_rv rv; rv.rintvl = rintvl;
+  cp_rel_direction(P,rintvl,M,plen,F,COV,parent,eff,rpos,asgn);
+  bool rerun = cp_rel_post1(P,rv,M,F,asgn,COV);
+  if (rerun)
+    cp_rel_direction(P,rintvl,M,plen,F,COV,parent,eff,rpos,asgn);
+  return cp_rel_post2(P,rv,M,F,asgn,rerun);
 }
 
 // Reconcile forward and backward (class_rel.c:904-938).  fw/bw are the two assignments; the choice

@@ -28,6 +28,8 @@
 #include "cp_class.h"
 
 #define WAVE 64
+#define REL_MAXM 512            // reads with more reliable intervals use the sequential kernel
+#define UNREL_MAXN 768          // reads with more intervals use the sequential kernel
 
 // Make one lane's global stores visible to the other lanes of the same wave (blocks are one wave).
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
@@ -391,7 +393,7 @@ k_classify_rel(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ 
   if (r >= nreads) return;
   const int lane = lane_id();
   const int M = nrel[r];
-  if (M == 0) return;
+  if (M <= REL_MAXM) return;                               // small reads: k_classify_rel_lds
   const int plen = (int)(prof_off[r+1]-prof_off[r]);
   const int64_t o = ioff[r];
   cp_intvl *rintvl = rintvl_all+o;
@@ -452,6 +454,7 @@ k_classify_unrel(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__re
   if (r >= nreads) return;
   const int lane = lane_id();
   const int N = nintvl[r];
+  if (N <= UNREL_MAXN) return;                             // small reads: k_classify_unrel_lds
   cp_intvl *intvl = intvl_all+ioff[r];
   int32_t *ord = ord_all+ioff[r];
   for (int k = lane; k < N; k += WAVE)                   // ord[rank] = index | fixed<<31
@@ -474,6 +477,435 @@ k_classify_unrel(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__re
         if (!(ord[i] >> 30))
           cp_update_state(P,ord[i] & 0x3fffffff,intvl,N);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+//  k_classify_rel_lds: class_rel.c:871-963, lane-parallel form for reads with M <= REL_MAXM.
+//
+//  The forward pass runs on lanes 0-15 and the backward pass on lanes 16-31 at the same time; inside
+//  a pass lane (s,t) evaluates the transition s@pred -> t@i (the 8 H/D transitions are one Bessel
+//  recurrence each, class_rel.c:213-270), so one DP step costs one recurrence instead of sixteen
+//  evaluations in sequence.  Interval fields, DP cells, back-pointers and both assignments live in
+//  LDS (15.6 KB per wave); HBM is touched for pe (once per step) and for the results.
+// ---------------------------------------------------------------------------------------------
+struct rel_lds_t
+  { int      b[REL_MAXM], e[REL_MAXM];
+    uint16_t ccb[REL_MAXM], cce[REL_MAXM];
+    int8_t   parent[2][REL_MAXM*4];
+    int16_t  eff[2][REL_MAXM];
+    uint8_t  rpos[2][REL_MAXM];
+    int8_t   asgn[2][REL_MAXM];
+    cp_cell  cell[2][2][4];              // [direction][buffer][state]
+    double   tr[2][16];                  // [direction][s*4+t]
+  };
+
+struct rel_lds_view                      // path index -> hot fields through `eff`
+  { const rel_lds_t *S; int d;
+    __device__ __forceinline__ cp_riv operator()(int k) const
+    { int j = S->eff[d][k];
+      cp_riv r; r.b = S->b[j]; r.e = S->e[j]; r.ccb = S->ccb[j]; r.cce = S->cce[j]; r.pe = 0.;
+      return r;
+    }
+  };
+
+struct rel_lds_rv
+  { const rel_lds_t *S;
+    __device__ __forceinline__ cp_riv operator()(int i) const
+    { cp_riv r; r.b = S->b[i]; r.e = S->e[i]; r.ccb = S->ccb[i]; r.cce = S->cce[i]; r.pe = 0.;
+      return r;
+    }
+  };
+
+// One DP pass (_classify_rel, class_rel.c:515-614) for the directions whose lanes have active == true.
+__device__ void rel_dp_pass(const cp_dev_params *P, rel_lds_t &S, const cp_intvl *rintvl, int M, int plen,
+                            bool active, const int *COV)
+{ const int lane = lane_id();
+  const int d = (lane >> 4) & 1, F = (d == 0);
+  const int l16 = lane & 15, s = l16 >> 2, t = l16 & 3;
+  const bool in_grp = active && lane < 32;
+  rel_lds_view view; view.S = &S; view.d = d;
+  rel_lds_rv rv; rv.S = &S;
+
+  int i = F ? 0 : M-1;
+  if (in_grp && l16 < 4)                                   // init, class_rel.c:544-580
+    { cp_riv I = rv(i);
+      I.pe = rintvl[i].pe;
+      cp_cell c;
+      cp_rel_init_cell(P,l16,I,i,plen,F,COV,&c);
+      S.cell[d][0][l16] = c;
+      S.tr[d][l16] = exp(c.dp);
+      S.parent[d][i*4+l16] = (int8_t)l16;
+      if (l16 == 0)
+        { S.rpos[d][i] = 0;
+          S.eff[d][i] = (int16_t)i;
+        }
+    }
+  wave_sync();
+  if (in_grp && l16 < 4)                                   // :582-586
+    { double psum = 0.;
+      for (int x = 0; x < 4; x++)
+        psum += S.tr[d][x];
+      S.cell[d][0][l16].dp = log(S.tr[d][l16]/psum);
+    }
+  wave_sync();
+
+  int cur = 0;
+  for (int k = 1; k < M; k++)                              // _update, class_rel.c:279-513
+    { const int i_pred = i;
+      i = F ? k : M-1-k;
+      cp_riv I = rv(i);
+      double v = 0.;
+      if (in_grp)                                          // :300-319: 16 transitions, one lane each
+        { if (t == CP_ERROR)
+            I.pe = rintvl[i].pe;
+          const cp_cell &pr = S.cell[d][cur][s];
+          if (pr.dp != -INFINITY)
+            v = exp(cp_calc_logp(P,t,I,pr,F,COV));
+          S.tr[d][l16] = v;
+        }
+      wave_sync();
+      double nv = 0.;
+      if (in_grp)                                          // :320-336
+        { double psum = 0.;
+          for (int x = 0; x < 16; x++)
+            psum += S.tr[d][x];
+          if (psum == 0.)
+            { if (t == CP_ERROR) v = 1.;
+              psum = 4.;
+            }
+          nv = log(v/psum);
+        }
+      wave_sync();
+      if (in_grp)
+        S.tr[d][l16] = nv;
+      wave_sync();
+      if (in_grp && l16 < 4)                               // :348-499: one lane per state
+        { double dp[4], tr[16];
+          for (int x = 0; x < 4; x++)  dp[x] = S.cell[d][cur][x].dp;
+          for (int x = 0; x < 16; x++) tr[x] = S.tr[d][x];
+          bool only_r = true;
+          for (int x = 0; x < 4; x++)
+            { double dummy;
+              int maxt = cp_argmax_tr(dp,tr,x,CP_N_STATE,&dummy);
+              if (maxt != CP_N_STATE && maxt != CP_REPEAT)
+                only_r = false;
+            }
+          cp_cell c;
+          if (only_r)
+            { c = S.cell[d][cur][l16];
+              cp_rel_only_r_cell(l16,i,&c);
+              S.parent[d][i*4+l16] = (int8_t)l16;
+              if (l16 == 0)
+                { S.rpos[d][i] = 1;
+                  S.eff[d][i] = S.eff[d][i_pred];
+                }
+            }
+          else
+            { double dummy, max_logp;
+              int maxs_h = cp_argmax_tr(dp,tr,CP_N_STATE,CP_HAPLO,&dummy);
+              int maxs_d = cp_argmax_tr(dp,tr,CP_N_STATE,CP_DIPLO,&dummy);
+              if (maxs_h == CP_HAPLO && maxs_d == CP_DIPLO)
+                { double a = tr[CP_HAPLO*4+CP_HAPLO], bb = tr[CP_DIPLO*4+CP_DIPLO];
+                  double mn = a < bb ? a : bb;
+                  tr[CP_HAPLO*4+CP_HAPLO] = tr[CP_DIPLO*4+CP_DIPLO] = mn;
+                }
+              int max_s = cp_argmax_tr(dp,tr,CP_N_STATE,l16,&max_logp);
+              S.parent[d][i*4+l16] = (int8_t)(max_s == CP_N_STATE ? l16 : max_s);
+              if (l16 == 0)
+                { S.rpos[d][i] = 0;
+                  S.eff[d][i] = (int16_t)i;
+                }
+              cp_rel_target_cell(P,l16,i,I,F,COV,max_s,max_logp,&S.cell[d][cur][0],view,&c);
+            }
+          S.cell[d][cur^1][l16] = c;
+        }
+      wave_sync();
+      cur ^= 1;
+    }
+
+  if (in_grp && l16 == 0)                                  // traceback, class_rel.c:606-613
+    { double max_logp = -INFINITY;
+      int st = CP_ERROR;
+      for (int x = 0; x < 4; x++)
+        if (max_logp < S.cell[d][cur][x].dp)
+          { max_logp = S.cell[d][cur][x].dp;
+            st = x;
+          }
+      if (F)
+        for (int k = M-1; k >= 0; k--)
+          { S.asgn[d][k] = S.rpos[d][k] ? (int8_t)CP_REPEAT : (int8_t)st;
+            st = S.parent[d][k*4+st];
+          }
+      else
+        for (int k = 0; k < M; k++)
+          { S.asgn[d][k] = S.rpos[d][k] ? (int8_t)CP_REPEAT : (int8_t)st;
+            st = S.parent[d][k*4+st];
+          }
+    }
+  wave_sync();
+}
+
+__global__ void __launch_bounds__(WAVE)
+k_classify_rel_lds(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ prof_off, int nreads,
+                   cp_intvl *__restrict__ intvl_all, cp_intvl *__restrict__ rintvl_all, const int32_t *__restrict__ relmap_all,
+                   const int64_t *__restrict__ ioff, const int32_t *__restrict__ nrel,
+                   int8_t *__restrict__ asgn_all, int64_t totalI)
+{ __shared__ rel_lds_t S;
+  const int r = blockIdx.x;
+  if (r >= nreads) return;
+  const int lane = lane_id();
+  const int M = nrel[r];
+  if (M == 0 || M > REL_MAXM) return;                      // big reads: k_classify_rel
+  const int plen = (int)(prof_off[r+1]-prof_off[r]);
+  const int64_t o = ioff[r];
+  cp_intvl *rintvl = rintvl_all+o;
+  for (int k = lane; k < M; k += WAVE)
+    { S.b[k] = rintvl[k].b; S.e[k] = rintvl[k].e;
+      S.ccb[k] = rintvl[k].ccb; S.cce[k] = rintvl[k].cce;
+    }
+  wave_sync();
+
+  const int d = (lane >> 4) & 1, F = (d == 0);
+  const bool lead = (lane < 32) && ((lane & 15) == 0);
+  int COV[4] = { P->cov[0], P->cov[1], P->cov[2], P->cov[3] };
+  rel_lds_rv rv; rv.S = &S;
+  rel_dp_pass(P,S,rintvl,M,plen,true,COV);
+
+  int rerun = 0;                                           // class_rel.c:629-650
+  if (lead)
+    rerun = cp_rel_post1(P,rv,M,F,S.asgn[d],COV) ? 1 : 0;
+  rerun = __shfl(rerun,d*16);
+  COV[CP_HAPLO] = __shfl(COV[CP_HAPLO],d*16);
+  COV[CP_DIPLO] = __shfl(COV[CP_DIPLO],d*16);
+  if (__ballot(rerun != 0))
+    rel_dp_pass(P,S,rintvl,M,plen,rerun != 0,COV);
+  double hdrr = 1.;
+  if (lead)
+    hdrr = cp_rel_post2(P,rv,M,F,S.asgn[d],rerun != 0);
+  const double hf = __shfl(hdrr,0), hb = __shfl(hdrr,16);
+  wave_sync();
+
+  int take_bw = 0;                                         // class_rel.c:904-938
+  if (lane == 0)
+    { const int8_t *fw = S.asgn[0], *bw = S.asgn[1];
+      bool eq = true;
+      for (int i = 0; i < M; i++)
+        if (fw[i] != bw[i]) { eq = false; break; }
+      if (!eq)
+        { bool pre = (fw[0] == 1);
+          if (pre)
+            { int i = 0;
+              while (i < M && fw[i]) i++;
+              while (i < M) { if (fw[i]) { pre = false; break; } i++; }
+            }
+          if (!pre)
+            { bool suf = (fw[M-1] == 1);
+              if (suf)
+                { int i = M-2;
+                  while (i >= 0 && fw[i]) i--;
+                  while (i >= 0) { if (fw[i]) { suf = false; break; } i--; }
+                }
+              if (suf) take_bw = 1;
+              else if (!(fabs(hf-1.) <= fabs(hb-1.))) take_bw = 1;
+            }
+        }
+    }
+  take_bw = __shfl(take_bw,0);
+  cp_intvl *intvl = intvl_all+o;
+  const int32_t *relmap = relmap_all+o;
+  int8_t *gfw = asgn_all+o, *gbw = asgn_all+totalI+o;
+  for (int i = lane; i < M; i += WAVE)                     // class_rel.c:949-960
+    { int8_t f = S.asgn[0][i], w = S.asgn[1][i];
+      int8_t a = take_bw ? w : f;
+      gfw[i] = f; gbw[i] = w;
+      rintvl[i].asgn = a;
+      intvl[relmap[i]].asgn = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+//  k_classify_unrel_lds: class_unrel.c:248-300, lane-parallel form for reads with N <= UNREL_MAXN.
+//
+//  Interval fields sit in LDS; "nearest reliable interval of class s" (find_nn_u, a linear scan in
+//  the reference) is a bit scan over two LDS bitsets kept up to date as classes change.  The two
+//  sweeps stay sequential (every update reads its neighbours' current classes), but inside one
+//  update the eight expensive terms -- {H,D} x {left,right} x {Skellam transition, binomial tail}
+//  (class_unrel.c:115-175) -- are evaluated by eight lanes at once.
+// ---------------------------------------------------------------------------------------------
+struct unrel_lds_t
+  { int      b[UNREL_MAXN], e[UNREL_MAXN];
+    uint16_t cb[UNREL_MAXN], ce[UNREL_MAXN], ccb[UNREL_MAXN], cce[UNREL_MAXN];
+    int8_t   asgn[UNREL_MAXN];
+    uint8_t  isrel[UNREL_MAXN];
+    int16_t  ord[UNREL_MAXN];            // sorted index, bit 14 = fixed
+    uint64_t rel[2][UNREL_MAXN/64];      // [0] reliable & H, [1] reliable & D
+  };
+
+__device__ __forceinline__ int bits_left(const uint64_t *bits, int idx)       // nearest set bit < idx
+{ int w = idx >> 6;
+  uint64_t m = bits[w] & ((1ull << (idx & 63))-1);
+  while (true)
+    { if (m) return (w << 6)+63-__clzll((long long)m);
+      if (--w < 0) return -1;
+      m = bits[w];
+    }
+}
+__device__ __forceinline__ int bits_right(const uint64_t *bits, int idx, int nwords)   // nearest set bit > idx
+{ int w = idx >> 6;
+  uint64_t m = bits[w] & ~((2ull << (idx & 63))-1);
+  while (true)
+    { if (m) return (w << 6)+__ffsll((long long)m)-1;
+      if (++w >= nwords) return -1;
+      m = bits[w];
+    }
+}
+
+// est_cov's first half (class_unrel.c:30-43) on the LDS tables; -1 = no reliable neighbour
+__device__ __forceinline__ int unrel_est1(const unrel_lds_t &S, int x, int l, int r)
+{ if (l != -1 && r != -1)
+    return (int)(uint16_t)cp_linear_interpolation(x,S.e[l]-1,S.cce[l],S.b[r],S.ccb[r]);
+  else if (l != -1) return S.cce[l];
+  else if (r != -1) return S.ccb[r];
+  return -1;
+}
+
+__global__ void __launch_bounds__(WAVE)
+k_classify_unrel_lds(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__restrict__ intvl_all,
+                     const int64_t *__restrict__ ioff, const int32_t *__restrict__ nintvl)
+{ __shared__ unrel_lds_t S;
+  const int r = blockIdx.x;
+  if (r >= nreads) return;
+  const int lane = lane_id();
+  const int N = nintvl[r];
+  if (N == 0 || N > UNREL_MAXN) return;                    // big reads: k_classify_unrel
+  cp_intvl *intvl = intvl_all+ioff[r];
+  const int nwords = (N+63) >> 6;
+  const int REP = P->cov[CP_REPEAT];
+
+  for (int base = 0; base < N; base += WAVE)
+    { int k = base+lane;
+      bool h = false, dd = false;
+      if (k < N)
+        { const cp_intvl I = intvl[k];
+          S.b[k] = I.b; S.e[k] = I.e; S.cb[k] = I.cb; S.ce[k] = I.ce; S.ccb[k] = I.ccb; S.cce[k] = I.cce;
+          S.asgn[k] = I.asgn; S.isrel[k] = I.is_rel;
+          h  = I.is_rel && I.asgn == CP_HAPLO;
+          dd = I.is_rel && I.asgn == CP_DIPLO;
+        }
+      uint64_t mh = __ballot(h), md = __ballot(dd);
+      if (lane == 0)
+        { S.rel[0][base >> 6] = mh;
+          S.rel[1][base >> 6] = md;
+        }
+    }
+  wave_sync();
+  for (int k = lane; k < N; k += WAVE)                     // stable sort by min(cb,ce), class_unrel.c:252-258
+    { const int key = S.cb[k] < S.ce[k] ? S.cb[k] : S.ce[k];
+      int rank = 0;
+      for (int m = 0; m < N; m++)
+        { int km = S.cb[m] < S.ce[m] ? S.cb[m] : S.ce[m];
+          rank += (km < key || (km == key && m < k)) ? 1 : 0;
+        }
+      int fixed = (S.isrel[k] && (S.asgn[k] == CP_HAPLO || S.asgn[k] == CP_DIPLO)) ? 1 : 0;
+      S.ord[rank] = (int16_t)(k | (fixed << 14));
+    }
+  wave_sync();
+
+  for (int pass = 0; pass < 2; pass++)                     // class_unrel.c:260-274
+    for (int it = 0; it < N; it++)
+      { const int oi = S.ord[pass == 0 ? N-1-it : it];
+        if (oi & (1 << 14))
+          continue;
+        const int idx = oi;
+        const int Ib = S.b[idx], Ie = S.e[idx], Icb = S.cb[idx], Ice = S.ce[idx];
+        int snew;
+        if ((Icb > Ice ? Icb : Ice) >= REP)                // update_state, class_unrel.c:195-199
+          snew = CP_REPEAT;
+        else
+          { const int lH = bits_left(S.rel[0],idx), rH = bits_right(S.rel[0],idx,nwords);
+            const int lD = bits_left(S.rel[1],idx), rD = bits_right(S.rel[1],idx,nwords);
+            // lanes 0-7: class (H,D) x side (L,R) x kind (0: max(er,sf), 1: sf_er)   class_unrel.c:123-163
+            const int s2 = (lane >> 2) & 1, side = (lane >> 1) & 1, kind = lane & 1;
+            const int s = s2 ? CP_DIPLO : CP_HAPLO;
+            const int l_rel = s2 ? lD : lH, r_rel = s2 ? rD : rH;
+            double val = -INFINITY;
+            if (lane < 8)
+              { if (kind == 0)
+                  { double er = -INFINITY, sf = -INFINITY;
+                    if (side == 0)
+                      { if (idx-1 >= 0 && S.asgn[idx-1] == (int8_t)s) er = intvl[idx].peo_b;
+                        if (l_rel != -1) sf = cp_logp_trans(P,S.e[l_rel]-1,Ib,S.cce[l_rel],Icb,S.cce[l_rel]);
+                      }
+                    else
+                      { if (idx+1 < N && S.asgn[idx+1] == (int8_t)s) er = intvl[idx].peo_e;
+                        if (r_rel != -1) sf = cp_logp_trans(P,Ie-1,S.b[r_rel],Ice,S.ccb[r_rel],S.ccb[r_rel]);
+                      }
+                    val = (er > sf) ? er : sf;
+                  }
+                else
+                  { const int x = side ? Ie-1 : Ib, c = side ? Ice : Icb;
+                    int est = unrel_est1(S,x,l_rel,r_rel);     // est_cov, class_unrel.c:27-51
+                    if (est < 0)
+                      { int cov = unrel_est1(S,x,s2 ? lH : lD,s2 ? rH : rD);
+                        if (cov < 0) cov = 0;
+                        est = (cov > 0) ? (((s == CP_HAPLO) ? cov/2 : cov*2) & 0xffff) : P->cov[s];
+                      }
+                    if (est >= c)
+                      val = log(cp_p_errorin(P,CP_OTHERS,0.1,P->u_lpe,P->u_l1mpe,est,c));
+                  }
+              }
+            double v1 = __shfl_down(val,1);
+            double sidev = (val > v1) ? val : v1;              // MAX(MAX(er,sf),sf_er) on lanes with kind 0
+            double vr = __shfl_down(sidev,2);
+            double logp_l = sidev, logp_r = vr, logp_s;        // meaningful on lanes 0 (H) and 4 (D)
+            if (logp_l == -INFINITY && logp_r == -INFINITY)    // class_unrel.c:165-173
+              { logp_l = cp_logp_poisson(P,Icb,P->cov[s]);
+                logp_r = cp_logp_poisson(P,Ice,P->cov[s]);
+              }
+            else if (logp_l == -INFINITY) logp_l = logp_r;
+            else if (logp_r == -INFINITY) logp_r = logp_l;
+            logp_s = logp_l+logp_r;
+            const double vH = __shfl(logp_s,0), vD = __shfl(logp_s,4);
+            // E and R are table look-ups (class_unrel.c:53-113)
+            const double pe = intvl[idx].pe;
+            const double po = cp_logp_poisson(P,Icb,P->cov[CP_ERROR])+cp_logp_poisson(P,Ice,P->cov[CP_ERROR])+CP_E_PO_BASE;
+            const double vE = (pe > po) ? pe : po;
+            double vR;
+            { int dcov_l, dcov_r;
+              if (lD == -1 && rD == -1) dcov_l = dcov_r = P->cov[CP_DIPLO];
+              else if (lD == -1)        dcov_l = dcov_r = S.cb[rD];
+              else if (rD == -1)        dcov_l = dcov_r = S.ce[lD];
+              else                      { dcov_l = S.ce[lD]; dcov_r = S.cb[rD]; }
+              int rcov_l = (uint16_t)(P->dr_ratio*dcov_l);
+              int rcov_r = (uint16_t)(P->dr_ratio*dcov_r);
+              if (Icb >= rcov_l || Ice >= rcov_r)
+                vR = CP_R_LOGP;
+              else
+                vR = cp_logp_binom_pre(P,Icb,rcov_l,P->r_lp,P->r_l1mp)+cp_logp_binom_pre(P,Ice,rcov_r,P->r_lp,P->r_l1mp);
+            }
+            double logpmax = -INFINITY;                        // class_unrel.c:208-218: E,R,H,D with strict <
+            snew = -1;
+            if (logpmax < vE) { logpmax = vE; snew = CP_ERROR; }
+            if (logpmax < vR) { logpmax = vR; snew = CP_REPEAT; }
+            if (logpmax < vH) { logpmax = vH; snew = CP_HAPLO; }
+            if (logpmax < vD) { logpmax = vD; snew = CP_DIPLO; }
+          }
+        wave_sync();                                           // everyone has read the old state
+        if (lane == 0 && snew >= 0)
+          { const int old = S.asgn[idx];
+            if (S.isrel[idx] && old != snew)
+              { const uint64_t bit = 1ull << (idx & 63);
+                if (old == CP_HAPLO) S.rel[0][idx >> 6] &= ~bit;
+                if (old == CP_DIPLO) S.rel[1][idx >> 6] &= ~bit;
+                if (snew == CP_HAPLO) S.rel[0][idx >> 6] |= bit;
+                if (snew == CP_DIPLO) S.rel[1][idx >> 6] |= bit;
+              }
+            S.asgn[idx] = (int8_t)snew;
+          }
+        wave_sync();
+      }
+  for (int k = lane; k < N; k += WAVE)
+    intvl[k].asgn = S.asgn[k];
 }
 
 // ---------------------------------------------------------------------------------------------

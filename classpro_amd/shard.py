@@ -1,0 +1,36 @@
+"""Read sharding across GPUs.
+
+Reads are independent once the global scalars are known, so the N-GPU path is: contiguous read ranges
+balanced by *bases* (not reads), one process per GPU, no collective on the data path, and an ordered
+host-side gather of the per-shard label fragments -- the role merge_files plays for the reference's
+per-thread temp files (io.c:70-112).
+"""
+import numpy as np
+
+
+def plan_shards(seq_off, world):
+    """Boundaries b[0..world] (read indices): shard r = reads [b[r], b[r+1]), about equal in bases."""
+    seq_off = np.asarray(seq_off, dtype=np.int64)
+    n = len(seq_off) - 1
+    total = int(seq_off[-1]) if n > 0 else 0
+    b = [0]
+    for r in range(1, world):
+        target = total * r // world
+        b.append(int(np.searchsorted(seq_off, target, side="left")) if n else 0)
+    b.append(n)
+    for i in range(1, len(b)):
+        b[i] = min(max(b[i], b[i - 1]), n)
+    return b
+
+
+def gather_fragments(fragment, rank, world, group=None):
+    """Concatenate per-rank label fragments in rank order on rank 0 (host side, gloo or nccl group)."""
+    import torch.distributed as dist
+    frag = np.ascontiguousarray(fragment, dtype=np.uint8)
+    if world == 1:
+        return frag
+    out = [None] * world if rank == 0 else None
+    dist.gather_object(frag, out, dst=0, group=group)
+    if rank == 0:
+        return np.concatenate(out)
+    return None

@@ -17,6 +17,7 @@
 #include <string.h>
 #include <math.h>
 #include <pthread.h>
+#include <malloc.h>
 #include "classpro_oracle.h"
 
 #define MINI(a,b) ((a) < (b) ? (a) : (b))
@@ -1817,9 +1818,12 @@ int cpo_classify_read(const cpo_params *p, const char *seq, int rlen, const uint
 
   cpo_seq_context(seq,rlen,lctx,rctx);
   int N = cpo_find_wall(p,profile,plen,lctx,rctx,intvl,icap);
-  if (N < 0)
-    { fprintf(stderr,"cpo_classify_read: E-interval overflow (reference would exit)\n");
-      exit(1);
+  if (N < 0)                                        /* "# E-intvls >= plen": the reference exits (wall.c:783-788) */
+    { for (int j = 0; j < plen; j++)
+        labels[K-1+j] = '!';
+      free(lctx); free(rctx); free(intvl); free(rintvl);
+      if (M_out) *M_out = 0;
+      return -1;
     }
   int M = cpo_find_rel_intvl(p,intvl,N,rintvl,profile,plen,lctx,rctx);
   cpo_classify_rel(p,rintvl,M,intvl,N,plen,NULL,NULL);
@@ -1860,6 +1864,10 @@ void cpo_classify_batch(const cpo_params *p, const char *seq, const int64_t *seq
                         const uint16_t *prof, const int64_t *prof_off, int nreads,
                         char *labels, int nthreads)
 { if (nthreads < 1) nthreads = 1;
+  /* keep the per-read scratch of every thread in its malloc arena (no mmap/munmap per read), the
+     moral equivalent of the reference allocating its scratch once per thread (ClassPro.c:114-143) */
+  mallopt(M_MMAP_THRESHOLD,1<<30);
+  mallopt(M_TRIM_THRESHOLD,1<<30);
   int nparts = nreads/nthreads + (nreads%nthreads == 0 ? 0 : 1);
   pthread_t *th = malloc(sizeof(pthread_t)*nthreads);
   batch_arg *arg = malloc(sizeof(batch_arg)*nthreads);

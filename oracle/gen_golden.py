@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE's own code (oracle/_ref, built by oracle/Makefile
+from /root/reference/src).  Run in the build container (the reference tree does not travel):
+
+    python oracle/gen_golden.py
+
+Vectors (inputs + the reference's outputs; data only, no reference source):
+  prims.npz     bessi / logp_poisson / logp_skellam / logp_binom / binom_test_g / logp_trans known answers,
+                logfact[0..4095], GLOBAL_COV / DR_RATIO for several (H,D)
+  context.npz   calc_seq_context lctx/rctx for crafted + random low-complexity strings
+  classify.npz  classify_rel (fw, bw, reconciled) and classify_unrel outputs for interval sets
+                (the interval sets are produced by the oracle's find_wall/find_rel_intvl on seeded synthetic reads)
+  fastk.npz     process_global_hist (H,D) and Fetch_Profile output for FASTK files written by classpro_amd.fastk
+"""
+import os
+import sys
+import tempfile
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:] = [q for q in sys.path if os.path.abspath(q or ".") != os.path.join(ROOT, "oracle")]
+sys.path.insert(0, ROOT)
+from oracle.oracle import Oracle, Ref, INTVL_DTYPE, ref_available  # noqa: E402
+from classpro_amd import synth, fastk  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def prims():
+    rng = np.random.default_rng(101)
+    R = Ref(20000, 20, 40)
+    n = rng.integers(0, 90, 400); x = np.concatenate([rng.uniform(0, 5, 200), rng.uniform(0, 200, 200)])
+    bess = np.array([R.bessi(int(a), float(b)) for a, b in zip(n, x)])
+    k = rng.integers(0, 400, 400); lam = rng.integers(1, 120, 400)
+    pois = np.array([R.logp_poisson(int(a), int(b)) for a, b in zip(k, lam)])
+    sk_k = rng.integers(-60, 60, 400); sk_l = rng.uniform(0.001, 80, 400)
+    skel = np.array([R.logp_skellam(int(a), float(b)) for a, b in zip(sk_k, sk_l)])
+    bn = rng.integers(1, 300, 400); bk = (rng.random(400) * (bn + 1)).astype(np.int64)
+    bp = rng.choice([0.004, 0.01, 0.034, 0.1, 0.802, 0.99], 400)
+    binom = np.array([R.logp_binom(int(a), int(b), float(c)) for a, b, c in zip(bk, bn, bp)])
+    btest = np.array([R.binom_test_g(int(a), int(b), float(c)) for a, b, c in zip(bk, bn, bp)])
+    tb = rng.integers(0, 20000, 400); te = rng.integers(0, 20000, 400)
+    tcb = rng.integers(1, 80, 400); tce = rng.integers(1, 80, 400); tcov = rng.integers(1, 80, 400)
+    trans = np.array([R.logp_trans(int(a), int(b), int(c), int(d), int(e)) for a, b, c, d, e in zip(tb, te, tcb, tce, tcov)])
+    lf = R.logfact()[:4096]
+    covs = []
+    for h, d in ((20, 40), (19, 38), (30, 60), (12, 25), (50, 99)):
+        g, dr = Ref(20000, h, d).globals()
+        covs.append(g + [dr])
+    np.savez_compressed(os.path.join(OUT, "prims.npz"), bess_n=n, bess_x=x, bess=bess, pois_k=k, pois_l=lam, pois=pois,
+                        sk_k=sk_k, sk_l=sk_l, skel=skel, bn=bn, bk=bk, bp=bp, binom=binom, btest=btest,
+                        tb=tb, te=te, tcb=tcb, tce=tce, tcov=tcov, trans=trans, logfact=lf,
+                        covs=np.array(covs, dtype=np.float64))
+
+
+def context():
+    rng = np.random.default_rng(102)
+    R = Ref()
+    AL = np.frombuffer(b"ACGT", np.uint8)
+    seqs = [b"A", b"AC", b"AAAAAAAAAA", b"ACACACACACAC", b"ACGACGACGACGACG", b"AACACACGGGTATATATTTT",
+            b"ACACAGAGAG", b"CAACAC", b"A" * 140, b"AC" * 140 + b"G", b"ACG" * 135 + b"T", b"TTTACGACGACGAAA"]
+    for it in range(120):
+        L = int(rng.integers(1, 160))
+        s = bytes(AL[rng.integers(0, int(rng.integers(1, 5)), size=L)])
+        if it % 2:
+            u = bytes(AL[rng.integers(0, 4, size=int(rng.integers(1, 4)))])
+            s = s[:L // 2] + u * int(rng.integers(2, 30)) + s[L // 2:]
+        seqs.append(s)
+    off = np.zeros(len(seqs) + 1, np.int64)
+    ls, rs = [], []
+    for i, s in enumerate(seqs):
+        l, r = R.seq_context(s)
+        ls.append(l); rs.append(r)
+        off[i + 1] = off[i] + len(s)
+    np.savez_compressed(os.path.join(OUT, "context.npz"), seq=np.frombuffer(b"".join(seqs), np.uint8), off=off,
+                        lctx=np.concatenate(ls), rctx=np.concatenate(rs))
+
+
+def classify():
+    cases = []
+    for seed, h, d, kw in ((21, 20, 40, dict(genome_len=120000, cov=40, read_len=9000)),
+                           (22, 15, 30, dict(genome_len=80000, cov=30, read_len=7000, het=0.004)),
+                           (23, 30, 60, dict(genome_len=60000, cov=60, read_len=12000, err_sub=0.002))):
+        ds = synth.make_dataset(seed=seed, **kw)
+        O = Oracle(40, 20000, h, d)
+        R = Ref(20000, h, d)
+        for s, p in list(zip(ds["seqs"], ds["profiles"]))[:14]:
+            l, r = O.seq_context(s)
+            iv = O.find_wall(p, l, r)
+            iv2, riv = O.find_rel_intvl(iv, p, l, r)
+            r1, i1 = R.classify(riv, iv2, len(p), stage=1)
+            r2, i2 = R.classify(riv, iv2, len(p), stage=2)
+            fw = R.classify_rel_dir(riv, len(p), True)[0] if len(riv) else np.zeros(0, np.int8)
+            bw = R.classify_rel_dir(riv, len(p), False)[0] if len(riv) else np.zeros(0, np.int8)
+            cases.append((h, d, len(p), iv2, riv, r1["asgn"].copy(), i1["asgn"].copy(), i2["asgn"].copy(), fw, bw))
+    arrs = {"n": np.array(len(cases))}
+    for k, c in enumerate(cases):
+        arrs["meta%d" % k] = np.array(c[:3])
+        arrs["intvl%d" % k] = c[3].view(np.uint8)
+        arrs["rintvl%d" % k] = c[4].view(np.uint8)
+        arrs["rel_rasgn%d" % k] = c[5]
+        arrs["rel_iasgn%d" % k] = c[6]
+        arrs["all_iasgn%d" % k] = c[7]
+        arrs["fw%d" % k] = c[8]
+        arrs["bw%d" % k] = c[9]
+    np.savez_compressed(os.path.join(OUT, "classify.npz"), **arrs)
+
+
+def fastk_files():
+    R = Ref()
+    ds = synth.make_dataset(genome_len=60000, cov=40, read_len=5000, seed=31)
+    rng = np.random.default_rng(32)
+    profs = [p for p in ds["profiles"][:40]]
+    # exercise every code form: long runs, big jumps (15-bit deltas), counts >= 128, near 32767
+    weird = np.concatenate([np.full(200, 5), [300, 301, 32767, 32700, 1, 1, 1, 129, 128, 127], rng.integers(1, 32767, 50),
+                            np.full(70, 4000)]).astype(np.uint16)
+    profs.append(weird)
+    profs.append(np.array([7], np.uint16))
+    with tempfile.TemporaryDirectory() as td:
+        fastk.write_fastk(td, "syn", 40, profs, ds["hist"], nparts=2)
+        h, d = R.hist_covs(os.path.join(td, "syn"), 0)
+        h2, d2 = R.hist_covs(os.path.join(td, "syn"), 37)
+        k, got = R.fetch_profiles(os.path.join(td, "syn"))
+        _, codes = fastk.read_fastk_codes(td, "syn")
+    assert k == 40 and len(got) == len(profs)
+    for a, b in zip(got, profs):
+        assert np.array_equal(a, b), "FASTK writer/reference reader round trip failed"
+    low, high, il, ih, hist = ds["hist"]
+    off = np.zeros(len(profs) + 1, np.int64)
+    coff = np.zeros(len(profs) + 1, np.int64)
+    for i, (p, c) in enumerate(zip(got, codes)):
+        off[i + 1] = off[i] + len(p)
+        coff[i + 1] = coff[i] + len(c)
+    np.savez_compressed(os.path.join(OUT, "fastk.npz"), hist=hist, low=low, high=high, ilow=il, ihigh=ih,
+                        covs=np.array([h, d, h2, d2]), cov_opt=np.array(37),
+                        prof=np.concatenate(got), prof_off=off,
+                        codes=np.frombuffer(b"".join(codes), np.uint8), code_off=coff)
+
+
+if __name__ == "__main__":
+    if not ref_available() and not os.path.exists("/root/reference/src/ClassPro.h"):
+        sys.exit("oracle/_ref is not built and /root/reference is absent")
+    os.makedirs(OUT, exist_ok=True)
+    prims(); context(); classify(); fastk_files()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -169,6 +169,8 @@ class Oracle:
         M = C.c_int()
         n = self.L.cpo_classify_read(C.c_void_p(self.p), _p(s, C.c_char), C.c_int(rlen), _p(profile, C.c_uint16),
                                      _p(labels, C.c_char), iv.ctypes.data_as(C.c_void_p), C.c_int(cap), C.byref(M))
+        if n < 0:
+            raise OverflowError("# E-intvls >= plen: the reference exits on this read (wall.c:783-788)")
         lab = labels.tobytes()
         return (lab, iv[:n].copy(), M.value) if want_intvl else lab
 

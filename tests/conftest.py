@@ -1,0 +1,53 @@
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Product library (cross-compiled for gfx950) + oracle."""
+    from classpro_amd import build
+    build.build()
+    from oracle import oracle
+    oracle.build()
+    return True
+
+
+@pytest.fixture(scope="session")
+def harness(built):
+    """tests/host_harness.cpp: the product's scalar device functions compiled for the host (test-only)."""
+    import ctypes as C
+    src = os.path.join(ROOT, "tests", "host_harness.cpp")
+    out = os.path.join(ROOT, "tests", "_host_harness.so")
+    deps = [src] + [os.path.join(ROOT, "classpro_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "classpro_amd", "csrc"))]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-o", out, src])
+    H = C.CDLL(out)
+    H.hh_params_new.restype = C.c_void_p
+    H.hh_params_cthres.restype = C.c_void_p
+    H.hh_params_logfact.restype = C.c_void_p
+    H.hh_bessi.restype = C.c_double
+    H.hh_bessi.argtypes = [C.c_int, C.c_double]
+    return H
+
+
+@pytest.fixture(scope="session")
+def small_ds():
+    from classpro_amd import synth
+    return synth.make_dataset(genome_len=120000, cov=40, read_len=8000, seed=5)
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name))

@@ -1,0 +1,209 @@
+"""Parity of the HIP path (through the C ABI) with the oracle on a real MI355X.  `-m gpu`.
+
+Bar: integer / index / byte outputs are bit-exact.  The only floating-point outputs of the stage
+API (cp_intvl.pe, .peo_b, .peo_e = logs of probabilities) may differ from the oracle in the last
+bits because the device's exp/log are ocml's, not glibc's; tolerance rtol = 1e-12 (observed: <= 4 ulp).
+Label strings on the fixed-seed sets below are required to be byte-identical.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+K = 40
+FLOAT_RTOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def torch_dev(built):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    return torch
+
+
+@pytest.fixture(scope="module")
+def ds_a():
+    from classpro_amd import synth
+    return synth.make_dataset(genome_len=200000, cov=40, read_len=10000, seed=5), 20, 40
+
+
+@pytest.fixture(scope="module")
+def ds_b():
+    from classpro_amd import synth
+    return synth.make_dataset(genome_len=100000, cov=60, read_len=7000, seed=8, het=0.004, err_sub=0.002), 30, 60
+
+
+def oracle_stages(O, ds):
+    out = []
+    for s, p in zip(ds["seqs"], ds["profiles"]):
+        l, r = O.seq_context(s)
+        iv = O.find_wall(p, l, r)
+        iv2, riv = O.find_rel_intvl(iv, p, l, r)
+        ro, io, fw, bw = O.classify_rel(riv, iv2, len(p))
+        out.append(dict(wall=iv, rel=(iv2, riv), crel=(ro, io, fw, bw), call=O.classify_unrel(io)))
+    return out
+
+
+def close(a, b):
+    fin = np.isfinite(b)
+    return np.array_equal(np.isfinite(a), fin) and np.array_equal(a[~fin], b[~fin]) and np.allclose(a[fin], b[fin], rtol=FLOAT_RTOL, atol=0)
+
+
+@pytest.mark.parametrize("which", ["a", "b"])
+def test_stage_parity(torch_dev, ds_a, ds_b, which):
+    from classpro_amd.api import (Classifier, Batch, STAGE_SCAN, STAGE_WALL, STAGE_REL, STAGE_CLASS_REL, STAGE_CLASS_ALL)
+    from classpro_amd import synth
+    from oracle.oracle import Oracle
+    ds, h, d = ds_a if which == "a" else ds_b
+    O = Oracle(K, 20000, h, d)
+    clf = Classifier(K, 20000, h, d)
+    ex = clf.export()
+    cov, dr, cmax, hc = O.scalars()
+    assert ex["cov"] == cov and ex["dr_ratio"] == dr and ex["cmax"] == cmax and ex["hc_erate"] == hc
+    assert np.array_equal(ex["cthres"], O.cthres()) and np.array_equal(ex["logfact"], O.logfact()) and np.array_equal(ex["pe"], O.pe())
+    seq, so, prof, po = synth.pack_batch(ds["seqs"], ds["profiles"])
+    b = Batch(seq, so, prof, po)
+    want = oracle_stages(O, ds)
+
+    # candidate scan: bit g <=> min(c[g-1],c[g]) < R and |c[g-1]-c[g]| >= 3   (wall.c:592-608)
+    clf.run(b, STAGE_SCAN)
+    bits = np.unpackbits(clf.bitmap(b).view(np.uint8), bitorder="little")[:b.total_kmers]
+    p = prof.astype(np.int64)
+    exp = np.zeros(b.total_kmers, np.uint8)
+    exp[1:] = (np.minimum(p[1:], p[:-1]) < cov[1]) & (np.abs(p[1:] - p[:-1]) >= 3)
+    inner = np.ones(b.total_kmers, bool)
+    inner[po[:-1]] = False
+    assert np.array_equal(bits[inner], exp[inner])
+
+    clf.run(b, STAGE_WALL)
+    for (iv, _), w in zip(clf.intervals(b), want):
+        o = w["wall"]
+        assert len(iv) == len(o)
+        for f in ("b", "e", "cb", "ce"):
+            assert np.array_equal(iv[f], o[f]), f
+        for f in ("pe", "peo_b", "peo_e"):
+            assert close(iv[f], o[f]), f
+
+    clf.run(b, STAGE_REL)
+    for (iv, riv), w in zip(clf.intervals(b), want):
+        o_iv, o_riv = w["rel"]
+        assert np.array_equal(iv["is_rel"], o_iv["is_rel"]) and len(riv) == len(o_riv)
+        for f in ("b", "e", "cb", "ce", "ccb", "cce"):
+            assert np.array_equal(riv[f], o_riv[f]), f
+
+    clf.run(b, STAGE_CLASS_REL)
+    got = clf.intervals(b)
+    for (iv, riv), (fw, bw), w in zip(got, clf.rel_asgn(b), want):
+        ro, io, ofw, obw = w["crel"]
+        assert np.array_equal(fw, ofw) and np.array_equal(bw, obw)
+        assert np.array_equal(riv["asgn"], ro["asgn"]) and np.array_equal(iv["asgn"], io["asgn"])
+
+    clf.run(b, STAGE_CLASS_ALL)
+    for (iv, _), w in zip(clf.intervals(b), want):
+        assert np.array_equal(iv["asgn"], w["call"]["asgn"])
+
+    lab = clf.classify(b)
+    ref = O.classify_batch(seq, so, prof, po, nthreads=8)
+    assert np.array_equal(lab, ref)                      # byte-identical label strings
+    clf.close()
+
+
+def test_context_golden_on_device(torch_dev):
+    """calc_seq_context through the ABI against vectors produced by the reference's own context.c."""
+    from conftest import load_golden
+    from classpro_amd.api import Classifier, Batch
+    g = load_golden("context.npz")
+    off = g["off"].astype(np.int64)
+    n = len(off) - 1
+    po = np.concatenate([[0], np.cumsum(np.maximum(np.diff(off) - (K - 1), 0))]).astype(np.int64)
+    clf = Classifier(K, 20000, 20, 40)
+    b = Batch(g["seq"], off, np.ones(max(int(po[-1]), 1), np.uint16)[:int(po[-1])], po)
+    for i, (l, r) in enumerate(clf.seq_context(b)):
+        assert np.array_equal(l, g["lctx"][off[i]:off[i + 1]]) and np.array_equal(r, g["rctx"][off[i]:off[i + 1]])
+    clf.close()
+
+
+def test_edge_reads(torch_dev):
+    """Shortest legal reads (rlen == K), flat / all-repeat / all-error / ramp profiles, homopolymer and
+    microsatellite reads, an isolated sequencing error, a heterozygous stretch."""
+    from classpro_amd.api import Classifier, Batch
+    from classpro_amd import synth
+    from oracle.oracle import Oracle
+    AL = np.frombuffer(b"ACGT", np.uint8)
+    rng = np.random.default_rng(11)
+    O = Oracle(K, 20000, 20, 40)
+    seqs, profs, labs = [], [], []
+    cases = []
+    for plen in (1, 2, 3, 39, 40, 41, 200, 1000):
+        rlen = plen + K - 1
+        seq = bytes(AL[rng.integers(0, 4, rlen)])
+        cases += [(seq, np.full(plen, 40, np.uint16)), (seq, np.full(plen, 500, np.uint16)), (seq, np.full(plen, 1, np.uint16)),
+                  (seq, (1 + np.arange(plen) % 90).astype(np.uint16)),
+                  (b"A" * rlen, rng.integers(1, 80, plen).astype(np.uint16)),
+                  ((b"AC" * rlen)[:rlen], rng.integers(1, 80, plen).astype(np.uint16)),
+                  ((b"ACG" * rlen)[:rlen], rng.integers(1, 300, plen).astype(np.uint16))]
+    p = np.full(3000, 40, np.uint16)
+    p[1000:1039] = 1
+    p[2000:2500] = 20
+    cases.append((bytes(AL[rng.integers(0, 4, 3039)]), p))
+    p = np.full(5000, 32767, np.uint16)                   # maximum count everywhere
+    p[100:150] = 3
+    cases.append((bytes(AL[rng.integers(0, 4, 5039)]), p))
+    for s, p in cases:
+        try:
+            labs.append(O.classify_read(s, p))
+        except OverflowError:                             # the reference aborts on this read
+            continue
+        seqs.append(s)
+        profs.append(p)
+    assert len(seqs) >= len(cases) - 6
+    clf = Classifier(K, 20000, 20, 40)
+    b = Batch.from_reads(seqs, profs)
+    got = clf.classify(b).tobytes()
+    assert got == b"".join(labs)
+    # empty batch is a no-op
+    e = Batch(np.zeros(0, np.uint8), np.zeros(1, np.int64), np.zeros(0, np.uint16), np.zeros(1, np.int64))
+    assert len(clf.classify(e)) == 0
+    clf.close()
+
+
+def test_scale_properties(torch_dev):
+    """~50 Mbases: label alphabet, N-prefix, idempotence, batch-split and read-order invariance, and a
+    sampled comparison with the oracle (tolerance: <= 1e-6 of positions, FP near-ties only)."""
+    from classpro_amd.api import Classifier, Batch
+    from classpro_amd import synth
+    from oracle.oracle import Oracle
+    ds = synth.make_dataset(genome_len=1_250_000, cov=40, read_len=20000, seed=41, het=0.001, n_repeats=16, min_len=3000)
+    seq, so, prof, po = synth.pack_batch(ds["seqs"], ds["profiles"])
+    n = len(so) - 1
+    clf = Classifier(K, 20000, 19, 38)
+    b = Batch(seq, so, prof, po)
+    lab = clf.classify(b)
+    lab2 = clf.classify(b)
+    assert np.array_equal(lab, lab2)                      # idempotent / deterministic
+    starts = so[:-1]
+    pref = np.concatenate([np.arange(s, s + K - 1) for s in starts])
+    assert np.all(lab[pref] == ord("N"))
+    body = np.ones(len(lab), bool)
+    body[pref] = False
+    assert set(np.unique(lab[body]).tolist()) <= set(b"EHDR")
+    # split into two batches: same labels (reads are independent; scratch offsets differ)
+    h = n // 2
+    b1 = Batch(seq[:so[h]], so[:h + 1], prof[:po[h]], po[:h + 1])
+    b2 = Batch(seq[so[h]:], so[h:] - so[h], prof[po[h]:], po[h:] - po[h])
+    assert np.array_equal(np.concatenate([clf.classify(b1), clf.classify(b2)]), lab)
+    # reversed read order
+    order = np.arange(n)[::-1]
+    rs = [ds["seqs"][i] for i in order]
+    rp = [ds["profiles"][i] for i in order]
+    lr = clf.classify(Batch.from_reads(rs, rp))
+    o2 = np.concatenate([[0], np.cumsum([len(x) for x in rs])])
+    for j, i in enumerate(order[:200]):
+        assert np.array_equal(lr[o2[j]:o2[j + 1]], lab[so[i]:so[i + 1]])
+    # sampled oracle comparison
+    m = min(n, 600)
+    want = Oracle(K, 20000, 19, 38).classify_batch(seq[:so[m]], so[:m + 1], prof[:po[m]], po[:m + 1], nthreads=8)
+    bad = int((lab[:so[m]] != want).sum())
+    assert bad <= 1e-6 * so[m], "%d mismatching positions of %d" % (bad, so[m])
+    clf.close()

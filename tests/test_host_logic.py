@@ -1,0 +1,170 @@
+"""Host logic and the product's scalar device functions (compiled for the host by tests/host_harness.cpp)
+against the oracle.  No GPU needed."""
+import ctypes as C
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle.oracle import Oracle, INTVL_DTYPE
+from classpro_amd import fastk, synth
+
+AL = np.frombuffer(b"ACGT", np.uint8)
+
+
+def hh_ctx(H, s):
+    rlen = len(s)
+    l = np.zeros((rlen, 3), np.uint8)
+    r = np.zeros((rlen, 3), np.uint8)
+    H.hh_seq_context(C.c_char_p(s), rlen, l.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p))
+    return l, r
+
+
+def test_closed_form_context_random(harness):
+    """cp_ctx.h evaluates contexts in closed form; the oracle runs the reference's sequential pass."""
+    O = Oracle()
+    rng = np.random.default_rng(1)
+    for it in range(4000):
+        L = int(rng.integers(1, 300))
+        s = bytes(AL[rng.integers(0, int(rng.integers(1, 5)), size=L)])
+        k = it % 4
+        if k == 1:
+            u = bytes(AL[rng.integers(0, 4, size=int(rng.integers(1, 4)))])
+            s = s[:L // 3] + u * int(rng.integers(1, 60)) + s[L // 3:]
+        elif k == 2:
+            parts = []
+            for _ in range(int(rng.integers(1, 6))):
+                u = bytes(AL[rng.integers(0, 4, size=int(rng.integers(1, 4)))])
+                parts += [u * int(rng.integers(1, 12)), bytes(AL[rng.integers(0, 4, size=int(rng.integers(0, 4)))])]
+            s = b"".join(parts) or b"A"
+        elif k == 3 and it % 40 == 3:          # runs beyond the 127 cap
+            u = bytes(AL[rng.integers(0, 4, size=int(rng.integers(1, 4)))])
+            s = s[:5] + u * int(rng.integers(100, 300)) + s[5:]
+        a, b = O.seq_context(s), hh_ctx(harness, s)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), s
+
+
+def test_closed_form_context_golden(harness):
+    g = load_golden("context.npz")
+    off = g["off"]
+    for i in range(len(off) - 1):
+        s = g["seq"][off[i]:off[i + 1]].tobytes()
+        l, r = hh_ctx(harness, s)
+        assert np.array_equal(l, g["lctx"][off[i]:off[i + 1]]) and np.array_equal(r, g["rctx"][off[i]:off[i + 1]])
+
+
+def test_host_tables(harness):
+    for h, d in ((20, 40), (19, 38), (30, 60), (12, 25)):
+        O = Oracle(40, 20000, h, d)
+        P = harness.hh_params_new(40, 20000, h, d)
+        ct = np.ctypeslib.as_array(C.cast(harness.hh_params_cthres(C.c_void_p(P)), C.POINTER(C.c_uint8)), shape=(3, 21, 256, 2, 2))
+        lf = np.ctypeslib.as_array(C.cast(harness.hh_params_logfact(C.c_void_p(P)), C.POINTER(C.c_double)), shape=(32768,))
+        assert np.array_equal(ct, O.cthres()) and np.array_equal(lf, O.logfact())
+        harness.hh_params_free(C.c_void_p(P))
+    assert not harness.hh_params_new(40, 20000, 100, 200)
+
+
+def test_host_hist_and_decode(harness):
+    g = load_golden("fastk.npz")
+    h, d = C.c_int(), C.c_int()
+    hist = np.ascontiguousarray(g["hist"], np.int64)
+    rc = harness.hh_hist_covs(hist.ctypes.data_as(C.c_void_p), int(g["low"]), int(g["high"]), C.c_int64(int(g["ilow"])),
+                              C.c_int64(int(g["ihigh"])), 0, C.byref(h), C.byref(d))
+    assert rc == 0 and (h.value, d.value) == (int(g["covs"][0]), int(g["covs"][1]))
+    po, co = g["prof_off"], g["code_off"]
+    out = np.zeros(60000, np.uint16)
+    for i in range(len(po) - 1):
+        code = np.ascontiguousarray(g["codes"][co[i]:co[i + 1]])
+        n = harness.hh_decode_profile(code.ctypes.data_as(C.c_void_p), C.c_int64(len(code)), out.ctypes.data_as(C.c_void_p), 60000)
+        assert n == po[i + 1] - po[i] and np.array_equal(out[:n], g["prof"][po[i]:po[i + 1]])
+        # truncated buffer: same count, nothing written past the cap (libfastk.c:1492-1495,1522-1525)
+        if n > 10:
+            out2 = np.full(60000, 9999, np.uint16)
+            n2 = harness.hh_decode_profile(code.ctypes.data_as(C.c_void_p), C.c_int64(len(code)), out2.ctypes.data_as(C.c_void_p), 10)
+            assert n2 == n and np.all(out2[10:] == 9999)
+
+
+def test_fastk_encode_roundtrip():
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        n = int(rng.integers(1, 400))
+        c = rng.integers(1, 60, n)
+        if rng.random() < 0.3:
+            c[rng.integers(0, n, 3)] = rng.integers(1, 32767, 3)
+        c = np.repeat(c, rng.integers(1, 5, n))[:n].astype(np.uint16)
+        assert np.array_equal(fastk.decode_profile(fastk.encode_profile(c)), c)
+
+
+def run_harness_read(H, P, s, p):
+    rlen = len(s)
+    cap = rlen + 2
+    lab = np.zeros(rlen, np.uint8)
+    iv = np.zeros(cap, INTVL_DTYPE)
+    riv = np.zeros(cap, INTVL_DTYPE)
+    fw = np.zeros(cap, np.int8)
+    bw = np.zeros(cap, np.int8)
+    M = C.c_int()
+    sb = np.frombuffer(s, np.uint8)
+    N = H.hh_classify_read(C.c_void_p(P), sb.ctypes.data_as(C.c_void_p), rlen, p.ctypes.data_as(C.c_void_p),
+                           lab.ctypes.data_as(C.c_void_p), iv.ctypes.data_as(C.c_void_p), cap, C.byref(M),
+                           riv.ctypes.data_as(C.c_void_p), fw.ctypes.data_as(C.c_void_p), bw.ctypes.data_as(C.c_void_p))
+    return N, lab.tobytes(), iv[:max(N, 0)], riv[:M.value], fw[:M.value], bw[:M.value]
+
+
+@pytest.mark.parametrize("seed,h,d,kw", [
+    (5, 20, 40, dict(genome_len=150000, cov=40, read_len=10000)),
+    (7, 25, 50, dict(genome_len=100000, cov=50, read_len=6000, het=0.004)),
+    (9, 15, 30, dict(genome_len=100000, cov=30, read_len=15000, het=0.001, err_sub=0.002, err_indel=0.002)),
+])
+def test_device_functions_vs_oracle(harness, seed, h, d, kw):
+    """Every stage of the product's scalar device code (on-demand context, O(1) path trackers, ...)
+    must reproduce the oracle bit for bit when compiled for the host (same libm)."""
+    ds = synth.make_dataset(seed=seed, **kw)
+    O = Oracle(40, 20000, h, d)
+    P = harness.hh_params_new(40, 20000, h, d)
+    for s, p in zip(ds["seqs"], ds["profiles"]):
+        lab_o, iv_o, M_o = O.classify_read(s, p, want_intvl=True)
+        l, r = O.seq_context(s)
+        ivr, riv_o = O.find_rel_intvl(O.find_wall(p, l, r), p, l, r)
+        ro, _io, fw_o, bw_o = O.classify_rel(riv_o, ivr, len(p))
+        N, lab, iv, riv, fw, bw = run_harness_read(harness, P, s, p)
+        assert N == len(iv_o) and lab == lab_o
+        for f in ("b", "e", "cb", "ce", "is_rel", "asgn", "pe", "peo_b", "peo_e"):
+            assert np.array_equal(iv[f], iv_o[f]), f
+        assert len(riv) == M_o
+        for f in ("b", "e", "ccb", "cce", "asgn"):
+            assert np.array_equal(riv[f], ro[f]), f
+        assert np.array_equal(fw, fw_o) and np.array_equal(bw, bw_o)
+    harness.hh_params_free(C.c_void_p(P))
+
+
+def test_edge_reads(harness):
+    """Flat, all-repeat, ramp and single-k-mer profiles; homopolymer and microsatellite reads."""
+    O = Oracle(40, 20000, 20, 40)
+    P = harness.hh_params_new(40, 20000, 20, 40)
+    rng = np.random.default_rng(11)
+    cases = []
+    for plen in (1, 2, 3, 39, 40, 41, 200):
+        rlen = plen + 39
+        seq = bytes(AL[rng.integers(0, 4, rlen)])
+        cases.append((seq, np.full(plen, 40, np.uint16)))
+        cases.append((seq, np.full(plen, 500, np.uint16)))
+        cases.append((seq, np.full(plen, 1, np.uint16)))
+        cases.append((seq, (1 + np.arange(plen) % 90).astype(np.uint16)))
+        cases.append((b"A" * rlen, rng.integers(1, 80, plen).astype(np.uint16)))
+        cases.append(((b"AC" * rlen)[:rlen], rng.integers(1, 80, plen).astype(np.uint16)))
+    p = np.full(3000, 40, np.uint16)
+    p[1000:1039] = 1                              # one clean sequencing error
+    p[2000:2500] = 20                             # a heterozygous stretch
+    cases.append((bytes(AL[rng.integers(0, 4, 3039)]), p))
+    n_ok = 0
+    for s, p in cases:
+        try:
+            lab_o = O.classify_read(s, p)
+        except OverflowError:                     # the reference aborts on this read ("# E-intvls >= plen")
+            continue
+        n_ok += 1
+        N, lab, *_ = run_harness_read(harness, P, s, p)
+        assert N >= 0 and lab == lab_o
+        assert set(lab[39:]) <= set(b"EHDR") and lab[:39] == b"N" * min(39, len(s))
+    assert n_ok >= len(cases) - 4
+    harness.hh_params_free(C.c_void_p(P))
