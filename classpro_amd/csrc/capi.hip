@@ -189,11 +189,13 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
                              const uint16_t *d_prof, const int64_t *d_prof_off,
                              int nreads, int64_t total_bases, int64_t total_kmers,
                              char *d_labels, int last_stage, void *stream)
-{ if (!p || !ws || !d_seq || !d_seq_off || !d_prof || !d_prof_off || nreads < 0 || total_bases < 0 || total_kmers < 0)
+{ if (!p || !ws || nreads < 0 || total_bases < 0 || total_kmers < 0)
     return set_err(CP_EINVAL,"cp_run_stages: bad argument");
+  if (nreads > 0 && (!d_seq || !d_seq_off || !d_prof || !d_prof_off))
+    return set_err(CP_EINVAL,"cp_run_stages: null device pointer");
   if (last_stage < CP_STAGE_SCAN || last_stage > CP_STAGE_LABELS)
     return set_err(CP_EINVAL,"cp_run_stages: bad stage");
-  if (last_stage == CP_STAGE_LABELS && !d_labels)
+  if (last_stage == CP_STAGE_LABELS && nreads > 0 && !d_labels)
     return set_err(CP_EINVAL,"cp_run_stages: labels buffer required");
   hipStream_t st = (hipStream_t)stream;
   ws->nreads = nreads; ws->total_kmers = total_kmers; ws->total_bases = total_bases;

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Copy the judged rocprofv3 summaries of a round from gpurun_out/prof_<tag>/ into profiles/.
+
+    python scripts/summarize_profile.py r01a r01
+
+writes profiles/<name>_kernel_stats.csv (rocprofv3 --kernel-trace --stats of the default bench.py run),
+profiles/<name>_pmc.txt (FETCH_SIZE / WRITE_SIZE per kernel, separate --pmc passes),
+profiles/<name>_bench.json and profiles/scan_pmc.json (HBM bytes per position of k_scan_candidates,
+corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE is in KiB and counts 1/2 of the bytes of a
+16-B-per-lane streaming read on gfx950 -> bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE * 1024 as is).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, name = sys.argv[1], sys.argv[2]
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+shutil.copy(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, name + "_kernel_stats.csv"))
+bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+json.dump(bench, open(os.path.join(dst, name + "_bench.json"), "w"), indent=1)
+kmers = bench["roofline"]["algorithmic_bytes_per_launch"] / 2.0
+
+agg = collections.defaultdict(list)
+grid = {}
+for kind in ("fetch", "write"):
+    for r in csv.DictReader(open(glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv"))[0])):
+        agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+with open(os.path.join(dst, name + "_pmc.txt"), "w") as f:
+    f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 1 --warmup 1 --no-cpu`\n")
+    f.write("# values in KiB per dispatch as reported; gfx950 correction for streaming reads: bytes = 2*FETCH_SIZE*1024\n")
+    f.write("%-28s %-11s %6s %14s %14s %14s\n" % ("kernel", "counter", "n", "avg_KiB", "min_KiB", "max_KiB"))
+    for (k, c), v in sorted(agg.items()):
+        if k.startswith("k_"):
+            f.write("%-28s %-11s %6d %14.1f %14.1f %14.1f\n" % (k, c, len(v), sum(v) / len(v), min(v), max(v)))
+fs = agg[("k_scan_candidates", "FETCH_SIZE")]
+wsz = agg[("k_scan_candidates", "WRITE_SIZE")]
+fetch = 2.0 * 1024 * sum(fs) / len(fs)
+write = 1024.0 * sum(wsz) / len(wsz)
+json.dump({"kernel": "k_scan_candidates", "positions_per_launch": kmers,
+           "fetch_bytes_per_launch_corrected": fetch, "write_bytes_per_launch": write,
+           "hbm_bytes_per_position": (fetch + write) / kmers,
+           "source": "profiles/%s_pmc.txt (FETCH_SIZE x2 per MI355X_MICROARCH.md HBM section)" % name},
+          open(os.path.join(dst, "scan_pmc.json"), "w"), indent=1)
+print(open(os.path.join(dst, name + "_pmc.txt")).read())
+print(open(os.path.join(dst, "scan_pmc.json")).read())
