@@ -270,7 +270,11 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->parent.p,(int32_t *)ws->eff.p,
                      (uint8_t *)ws->rpos.p,(int8_t *)ws->asgn.p,totalI);
-  hipLaunchKernelGGL(k_classify_rel_lds,dim3(nreads),dim3(WAVE),0,st,
+  // size classes: M <= 256 two reads per wave, 256 < M <= 1024 one read per wave, larger: sequential kernel above
+  hipLaunchKernelGGL((k_classify_rel_grp<0,256,2>),dim3((nreads+1)/2),dim3(WAVE),0,st,
+                     p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
+                     (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI);
+  hipLaunchKernelGGL((k_classify_rel_grp<256,1024,1>),dim3(nreads),dim3(WAVE),0,st,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI);
   HIPCHK(hipGetLastError());
@@ -282,7 +286,10 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   hipLaunchKernelGGL(k_classify_unrel,dim3(nreads),dim3(WAVE),0,st,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
                      (int32_t *)ws->ord.p);
-  hipLaunchKernelGGL(k_classify_unrel_lds,dim3(nreads),dim3(WAVE),0,st,
+  // size classes: N <= 256 eight reads per wave, 256 < N <= 1024 two reads per wave, larger: sequential kernel above
+  hipLaunchKernelGGL((k_classify_unrel_grp<0,256,8>),dim3((nreads+7)/8),dim3(WAVE),0,st,
+                     p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p);
+  hipLaunchKernelGGL((k_classify_unrel_grp<256,1024,2>),dim3((nreads+1)/2),dim3(WAVE),0,st,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p);
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_CLASS_ALL)

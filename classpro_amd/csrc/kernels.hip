@@ -16,8 +16,9 @@
 //   k_fill_f64          perror := -inf
 //   k_find_wall         one wave per read: wall.c:570-958
 //   k_find_rel          one wave per read, one lane per interval: wall.c:960-1051
-//   k_classify_rel      one wave per read: class_rel.c:871-963
-//   k_classify_unrel    one wave per read: class_unrel.c:248-300
+//   k_classify_rel_grp   2 reads per wave (1 for M > 256), lane per transition: class_rel.c:871-963
+//   k_classify_unrel_grp 8 reads per wave (2 for N > 256), lane per likelihood term: class_unrel.c:248-300
+//   k_classify_rel / k_classify_unrel   sequential fallbacks for reads with > 1024 intervals
 //   k_paint_labels      one wave per read: ClassPro.c:116-119,265-271
 //   k_seq_context       dense context arrays (stage API / parity tests only): context.c:8-108
 //
@@ -28,8 +29,8 @@
 #include "cp_class.h"
 
 #define WAVE 64
-#define REL_MAXM 512            // reads with more reliable intervals use the sequential kernel
-#define UNREL_MAXN 768          // reads with more intervals use the sequential kernel
+#define REL_MAXM 1024           // reads with more reliable intervals use the sequential kernel
+#define UNREL_MAXN 1024         // reads with more intervals use the sequential kernel
 
 // Make one lane's global stores visible to the other lanes of the same wave (blocks are one wave).
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
@@ -480,51 +481,62 @@ k_classify_unrel(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__re
 }
 
 // ---------------------------------------------------------------------------------------------
-//  k_classify_rel_lds: class_rel.c:871-963, lane-parallel form for reads with M <= REL_MAXM.
+//  k_classify_rel_grp<MAXM,G>: class_rel.c:871-963, lane-parallel, G reads per wave (64/G >= 32 lanes
+//  per read) for reads with MINM < M <= MAXM.
 //
-//  The forward pass runs on lanes 0-15 and the backward pass on lanes 16-31 at the same time; inside
-//  a pass lane (s,t) evaluates the transition s@pred -> t@i (the 8 H/D transitions are one Bessel
-//  recurrence each, class_rel.c:213-270), so one DP step costs one recurrence instead of sixteen
-//  evaluations in sequence.  Interval fields, DP cells, back-pointers and both assignments live in
-//  LDS (15.6 KB per wave); HBM is touched for pe (once per step) and for the results.
+//  Per read, the forward pass runs on lanes 0-15 of its lane group and the backward pass on lanes
+//  16-31 at the same time; inside a pass lane (s,t) evaluates the transition s@pred -> t@i.  The 8
+//  H/D transitions of every read and direction meet at ONE convergent Bessel call (class_rel.c:213-270
+//  are all `logp_trans` with different arguments), so a DP step of the whole wave costs one
+//  recurrence.  Interval fields (16-bit), DP cells, back-pointers and both assignments live in LDS;
+//  HBM is touched for pe (once per step) and for the results.
 // ---------------------------------------------------------------------------------------------
-struct rel_lds_t
-  { int      b[REL_MAXM], e[REL_MAXM];
-    uint16_t ccb[REL_MAXM], cce[REL_MAXM];
-    int8_t   parent[2][REL_MAXM*4];
-    int16_t  eff[2][REL_MAXM];
-    uint8_t  rpos[2][REL_MAXM];
-    int8_t   asgn[2][REL_MAXM];
-    cp_cell  cell[2][2][4];              // [direction][buffer][state]
-    double   tr[2][16];                  // [direction][s*4+t]
+template <int MAXM, int G>
+struct rel_grp_lds
+  { uint16_t b[G][MAXM], e[G][MAXM], ccb[G][MAXM], cce[G][MAXM];
+    int8_t   parent[G][2][MAXM*4];
+    int16_t  eff[G][2][MAXM];
+    uint8_t  rpos[G][2][MAXM];
+    int8_t   asgn[G][2][MAXM];
+    cp_cell  cell[G][2][2][4];           // [read][direction][buffer][state]
+    double   tr[G][2][16];               // [read][direction][s*4+t]
   };
 
-struct rel_lds_view                      // path index -> hot fields through `eff`
-  { const rel_lds_t *S; int d;
+template <int MAXM, int G>
+struct rel_grp_view                      // path index -> hot fields through `eff`
+  { const rel_grp_lds<MAXM,G> *S; int g, d;
     __device__ __forceinline__ cp_riv operator()(int k) const
-    { int j = S->eff[d][k];
-      cp_riv r; r.b = S->b[j]; r.e = S->e[j]; r.ccb = S->ccb[j]; r.cce = S->cce[j]; r.pe = 0.;
+    { int j = S->eff[g][d][k];
+      cp_riv r; r.b = S->b[g][j]; r.e = S->e[g][j]; r.ccb = S->ccb[g][j]; r.cce = S->cce[g][j]; r.pe = 0.;
       return r;
     }
   };
 
-struct rel_lds_rv
-  { const rel_lds_t *S;
+template <int MAXM, int G>
+struct rel_grp_rv
+  { const rel_grp_lds<MAXM,G> *S; int g;
     __device__ __forceinline__ cp_riv operator()(int i) const
-    { cp_riv r; r.b = S->b[i]; r.e = S->e[i]; r.ccb = S->ccb[i]; r.cce = S->cce[i]; r.pe = 0.;
+    { cp_riv r; r.b = S->b[g][i]; r.e = S->e[g][i]; r.ccb = S->ccb[g][i]; r.cce = S->cce[g][i]; r.pe = 0.;
       return r;
     }
   };
 
-// One DP pass (_classify_rel, class_rel.c:515-614) for the directions whose lanes have active == true.
-__device__ void rel_dp_pass(const cp_dev_params *P, rel_lds_t &S, const cp_intvl *rintvl, int M, int plen,
-                            bool active, const int *COV)
-{ const int lane = lane_id();
-  const int d = (lane >> 4) & 1, F = (d == 0);
-  const int l16 = lane & 15, s = l16 >> 2, t = l16 & 3;
-  const bool in_grp = active && lane < 32;
-  rel_lds_view view; view.S = &S; view.d = d;
-  rel_lds_rv rv; rv.S = &S;
+// One DP pass (_classify_rel, class_rel.c:515-614) for every (read, direction) whose lanes have
+// active == true.  M differs per read group; the wave iterates to the largest.
+template <int MAXM, int G>
+__device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, const cp_intvl *rintvl, int M, int plen,
+                             bool active, const int *COV)
+{ constexpr int L = WAVE/G;
+  const int lane = lane_id();
+  const int g = lane/L, ql = lane%L;
+  const int d = (ql >> 4) & 1, F = (d == 0);
+  const int l16 = ql & 15, s = l16 >> 2, t = l16 & 3;
+  const bool in_grp = active && ql < 32 && M > 0;
+  rel_grp_view<MAXM,G> view; view.S = &S; view.g = g; view.d = d;
+  rel_grp_rv<MAXM,G> rv; rv.S = &S; rv.g = g;
+  int maxM = in_grp ? M : 0;
+  for (int o = 32; o > 0; o >>= 1)
+    { int x = __shfl_xor(maxM,o); maxM = x > maxM ? x : maxM; }
 
   int i = F ? 0 : M-1;
   if (in_grp && l16 < 4)                                   // init, class_rel.c:544-580
@@ -532,43 +544,71 @@ __device__ void rel_dp_pass(const cp_dev_params *P, rel_lds_t &S, const cp_intvl
       I.pe = rintvl[i].pe;
       cp_cell c;
       cp_rel_init_cell(P,l16,I,i,plen,F,COV,&c);
-      S.cell[d][0][l16] = c;
-      S.tr[d][l16] = exp(c.dp);
-      S.parent[d][i*4+l16] = (int8_t)l16;
+      S.cell[g][d][0][l16] = c;
+      S.tr[g][d][l16] = exp(c.dp);
+      S.parent[g][d][i*4+l16] = (int8_t)l16;
       if (l16 == 0)
-        { S.rpos[d][i] = 0;
-          S.eff[d][i] = (int16_t)i;
+        { S.rpos[g][d][i] = 0;
+          S.eff[g][d][i] = (int16_t)i;
         }
     }
   wave_sync();
   if (in_grp && l16 < 4)                                   // :582-586
     { double psum = 0.;
       for (int x = 0; x < 4; x++)
-        psum += S.tr[d][x];
-      S.cell[d][0][l16].dp = log(S.tr[d][l16]/psum);
+        psum += S.tr[g][d][x];
+      S.cell[g][d][0][l16].dp = log(S.tr[g][d][l16]/psum);
     }
   wave_sync();
 
   int cur = 0;
-  for (int k = 1; k < M; k++)                              // _update, class_rel.c:279-513
-    { const int i_pred = i;
-      i = F ? k : M-1-k;
-      cp_riv I = rv(i);
+  for (int k = 1; k < maxM; k++)                           // _update, class_rel.c:279-513
+    { const bool on = in_grp && k < M;
+      const int i_pred = i;
+      if (on) i = F ? k : M-1-k;
+      cp_riv I; I.b = I.e = I.ccb = I.cce = 0; I.pe = 0.;
       double v = 0.;
-      if (in_grp)                                          // :300-319: 16 transitions, one lane each
-        { if (t == CP_ERROR)
-            I.pe = rintvl[i].pe;
-          const cp_cell &pr = S.cell[d][cur][s];
-          if (pr.dp != -INFINITY)
-            v = exp(cp_calc_logp(P,t,I,pr,F,COV));
-          S.tr[d][l16] = v;
+      // ---- :300-319: 16 transitions per (read, direction), one lane each.  The H and D lanes only
+      //      prepare arguments here; the Skellam/Bessel evaluation below is one call for all of them.
+      bool live = false, is_sk = false;
+      int tb = 0, te = 0, tcb = 0, tce = 0, tcov = 0;
+      double lp = -INFINITY;
+      if (on)
+        { I = rv(i);
+          const cp_cell &pr = S.cell[g][d][cur][s];
+          live = pr.dp != -INFINITY;
+          if (live)
+            { if (t == CP_ERROR)
+                { I.pe = rintvl[i].pe;
+                  lp = cp_logp_e(P,I,COV);
+                }
+              else if (t == CP_REPEAT)
+                lp = cp_logp_r(P,I,pr.cnt[CP_REPEAT],F,COV);
+              else
+                { is_sk = true;                            // logp_h / logp_d, class_rel.c:213-270
+                  const int beg_pos = cp_beg_pos(I,F), beg_cnt = cp_beg_cnt(I,F);
+                  if (t == CP_HAPLO && pr.dhr == -INFINITY)
+                    { tb = cp_pred(pr.pos[CP_HAPLO],F); te = beg_pos; tcb = pr.cnt[CP_HAPLO]; tce = beg_cnt; tcov = pr.cnt[CP_HAPLO]; }
+                  else
+                    { tb = cp_pred(pr.pos[CP_DIPLO],F); te = beg_pos; tcb = pr.cnt[CP_DIPLO];
+                      tce = (t == CP_HAPLO) ? (int)(pr.dhr*beg_cnt) : beg_cnt;
+                      tcov = pr.cnt[CP_DIPLO];
+                    }
+                }
+            }
+        }
+      if (is_sk)
+        lp = cp_logp_trans(P,tb,te,tcb,tce,tcov);
+      if (on)
+        { if (live) v = exp(lp);
+          S.tr[g][d][l16] = v;
         }
       wave_sync();
       double nv = 0.;
-      if (in_grp)                                          // :320-336
+      if (on)                                              // :320-336
         { double psum = 0.;
           for (int x = 0; x < 16; x++)
-            psum += S.tr[d][x];
+            psum += S.tr[g][d][x];
           if (psum == 0.)
             { if (t == CP_ERROR) v = 1.;
               psum = 4.;
@@ -576,13 +616,13 @@ __device__ void rel_dp_pass(const cp_dev_params *P, rel_lds_t &S, const cp_intvl
           nv = log(v/psum);
         }
       wave_sync();
-      if (in_grp)
-        S.tr[d][l16] = nv;
+      if (on)
+        S.tr[g][d][l16] = nv;
       wave_sync();
-      if (in_grp && l16 < 4)                               // :348-499: one lane per state
-        { double dp[4], tr[16];
-          for (int x = 0; x < 4; x++)  dp[x] = S.cell[d][cur][x].dp;
-          for (int x = 0; x < 16; x++) tr[x] = S.tr[d][x];
+      if (on && l16 < 4)                                   // :348-499: one lane per state
+        { const double *tr = S.tr[g][d];
+          double dp[4];
+          for (int x = 0; x < 4; x++) dp[x] = S.cell[g][d][cur][x].dp;
           bool only_r = true;
           for (int x = 0; x < 4; x++)
             { double dummy;
@@ -592,102 +632,116 @@ __device__ void rel_dp_pass(const cp_dev_params *P, rel_lds_t &S, const cp_intvl
             }
           cp_cell c;
           if (only_r)
-            { c = S.cell[d][cur][l16];
+            { c = S.cell[g][d][cur][l16];
               cp_rel_only_r_cell(l16,i,&c);
-              S.parent[d][i*4+l16] = (int8_t)l16;
+              S.parent[g][d][i*4+l16] = (int8_t)l16;
               if (l16 == 0)
-                { S.rpos[d][i] = 1;
-                  S.eff[d][i] = S.eff[d][i_pred];
+                { S.rpos[g][d][i] = 1;
+                  S.eff[g][d][i] = S.eff[g][d][i_pred];
                 }
             }
           else
-            { double dummy, max_logp;
+            { double dummy, max_logp = -INFINITY;
               int maxs_h = cp_argmax_tr(dp,tr,CP_N_STATE,CP_HAPLO,&dummy);
               int maxs_d = cp_argmax_tr(dp,tr,CP_N_STATE,CP_DIPLO,&dummy);
-              if (maxs_h == CP_HAPLO && maxs_d == CP_DIPLO)
-                { double a = tr[CP_HAPLO*4+CP_HAPLO], bb = tr[CP_DIPLO*4+CP_DIPLO];
-                  double mn = a < bb ? a : bb;
-                  tr[CP_HAPLO*4+CP_HAPLO] = tr[CP_DIPLO*4+CP_DIPLO] = mn;
+              const bool equal = (maxs_h == CP_HAPLO && maxs_d == CP_DIPLO);          // :382-386
+              const double a = tr[CP_HAPLO*4+CP_HAPLO], bb = tr[CP_DIPLO*4+CP_DIPLO];
+              const double mn = a < bb ? a : bb;
+              int max_s = CP_N_STATE;
+              for (int x = 0; x < 4; x++)                  // best source of target l16 (:391)
+                { double w = tr[x*4+l16];
+                  if (equal && x == l16 && (x == CP_HAPLO || x == CP_DIPLO)) w = mn;
+                  double logp = dp[x]+w;
+                  if (max_logp < logp)
+                    { max_logp = logp;
+                      max_s = x;
+                    }
                 }
-              int max_s = cp_argmax_tr(dp,tr,CP_N_STATE,l16,&max_logp);
-              S.parent[d][i*4+l16] = (int8_t)(max_s == CP_N_STATE ? l16 : max_s);
+              S.parent[g][d][i*4+l16] = (int8_t)(max_s == CP_N_STATE ? l16 : max_s);
               if (l16 == 0)
-                { S.rpos[d][i] = 0;
-                  S.eff[d][i] = (int16_t)i;
+                { S.rpos[g][d][i] = 0;
+                  S.eff[g][d][i] = (int16_t)i;
                 }
-              cp_rel_target_cell(P,l16,i,I,F,COV,max_s,max_logp,&S.cell[d][cur][0],view,&c);
+              cp_rel_target_cell(P,l16,i,I,F,COV,max_s,max_logp,&S.cell[g][d][cur][0],view,&c);
             }
-          S.cell[d][cur^1][l16] = c;
+          S.cell[g][d][cur^1][l16] = c;
         }
       wave_sync();
       cur ^= 1;
     }
-
+  // the buffer holding the last interval's cells: M-1 swaps happened for this read
+  const int fin = (M > 0) ? ((M-1) & 1) : 0;
   if (in_grp && l16 == 0)                                  // traceback, class_rel.c:606-613
     { double max_logp = -INFINITY;
       int st = CP_ERROR;
       for (int x = 0; x < 4; x++)
-        if (max_logp < S.cell[d][cur][x].dp)
-          { max_logp = S.cell[d][cur][x].dp;
+        if (max_logp < S.cell[g][d][fin][x].dp)
+          { max_logp = S.cell[g][d][fin][x].dp;
             st = x;
           }
       if (F)
         for (int k = M-1; k >= 0; k--)
-          { S.asgn[d][k] = S.rpos[d][k] ? (int8_t)CP_REPEAT : (int8_t)st;
-            st = S.parent[d][k*4+st];
+          { S.asgn[g][d][k] = S.rpos[g][d][k] ? (int8_t)CP_REPEAT : (int8_t)st;
+            st = S.parent[g][d][k*4+st];
           }
       else
         for (int k = 0; k < M; k++)
-          { S.asgn[d][k] = S.rpos[d][k] ? (int8_t)CP_REPEAT : (int8_t)st;
-            st = S.parent[d][k*4+st];
+          { S.asgn[g][d][k] = S.rpos[g][d][k] ? (int8_t)CP_REPEAT : (int8_t)st;
+            st = S.parent[g][d][k*4+st];
           }
     }
   wave_sync();
 }
 
+template <int MINM, int MAXM, int G>
 __global__ void __launch_bounds__(WAVE)
-k_classify_rel_lds(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ prof_off, int nreads,
+k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ prof_off, int nreads,
                    cp_intvl *__restrict__ intvl_all, cp_intvl *__restrict__ rintvl_all, const int32_t *__restrict__ relmap_all,
                    const int64_t *__restrict__ ioff, const int32_t *__restrict__ nrel,
                    int8_t *__restrict__ asgn_all, int64_t totalI)
-{ __shared__ rel_lds_t S;
-  const int r = blockIdx.x;
-  if (r >= nreads) return;
+{ __shared__ rel_grp_lds<MAXM,G> S;
+  constexpr int L = WAVE/G;
   const int lane = lane_id();
-  const int M = nrel[r];
-  if (M == 0 || M > REL_MAXM) return;                      // big reads: k_classify_rel
-  const int plen = (int)(prof_off[r+1]-prof_off[r]);
-  const int64_t o = ioff[r];
+  const int g = lane/L, ql = lane%L;
+  const int r = blockIdx.x*G+g;
+  int M = (r < nreads) ? nrel[r] : 0;
+  if (M <= MINM || M > MAXM) M = 0;                        // other size classes / sequential kernel
+  if (__ballot(M > 0) == 0) return;
+  const int rr = (r < nreads) ? r : 0;
+  const int plen = (int)(prof_off[rr+1]-prof_off[rr]);
+  const int64_t o = ioff[rr];
   cp_intvl *rintvl = rintvl_all+o;
-  for (int k = lane; k < M; k += WAVE)
-    { S.b[k] = rintvl[k].b; S.e[k] = rintvl[k].e;
-      S.ccb[k] = rintvl[k].ccb; S.cce[k] = rintvl[k].cce;
+  for (int k = ql; k < M; k += L)
+    { S.b[g][k] = (uint16_t)rintvl[k].b; S.e[g][k] = (uint16_t)rintvl[k].e;
+      S.ccb[g][k] = rintvl[k].ccb; S.cce[g][k] = rintvl[k].cce;
     }
   wave_sync();
 
-  const int d = (lane >> 4) & 1, F = (d == 0);
-  const bool lead = (lane < 32) && ((lane & 15) == 0);
+  const int d = (ql >> 4) & 1, F = (d == 0);
+  const int leadlane = g*L+d*16;
+  const bool lead = (M > 0) && (ql < 32) && ((ql & 15) == 0);
   int COV[4] = { P->cov[0], P->cov[1], P->cov[2], P->cov[3] };
-  rel_lds_rv rv; rv.S = &S;
-  rel_dp_pass(P,S,rintvl,M,plen,true,COV);
+  rel_grp_rv<MAXM,G> rv; rv.S = &S; rv.g = g;
+  rel_grp_pass<MAXM,G>(P,S,rintvl,M,plen,M > 0,COV);
 
   int rerun = 0;                                           // class_rel.c:629-650
   if (lead)
-    rerun = cp_rel_post1(P,rv,M,F,S.asgn[d],COV) ? 1 : 0;
-  rerun = __shfl(rerun,d*16);
-  COV[CP_HAPLO] = __shfl(COV[CP_HAPLO],d*16);
-  COV[CP_DIPLO] = __shfl(COV[CP_DIPLO],d*16);
+    rerun = cp_rel_post1(P,rv,M,F,S.asgn[g][d],COV) ? 1 : 0;
+  rerun = __shfl(rerun,leadlane);
+  COV[CP_HAPLO] = __shfl(COV[CP_HAPLO],leadlane);
+  COV[CP_DIPLO] = __shfl(COV[CP_DIPLO],leadlane);
+  if (M == 0 || ql >= 32) rerun = 0;
   if (__ballot(rerun != 0))
-    rel_dp_pass(P,S,rintvl,M,plen,rerun != 0,COV);
+    rel_grp_pass<MAXM,G>(P,S,rintvl,M,plen,rerun != 0,COV);
   double hdrr = 1.;
   if (lead)
-    hdrr = cp_rel_post2(P,rv,M,F,S.asgn[d],rerun != 0);
-  const double hf = __shfl(hdrr,0), hb = __shfl(hdrr,16);
+    hdrr = cp_rel_post2(P,rv,M,F,S.asgn[g][d],rerun != 0);
+  const double hf = __shfl(hdrr,g*L), hb = __shfl(hdrr,g*L+16);
   wave_sync();
 
   int take_bw = 0;                                         // class_rel.c:904-938
-  if (lane == 0)
-    { const int8_t *fw = S.asgn[0], *bw = S.asgn[1];
+  if (M > 0 && ql == 0)
+    { const int8_t *fw = S.asgn[g][0], *bw = S.asgn[g][1];
       bool eq = true;
       for (int i = 0; i < M; i++)
         if (fw[i] != bw[i]) { eq = false; break; }
@@ -710,12 +764,12 @@ k_classify_rel_lds(const cp_dev_params *__restrict__ P, const int64_t *__restric
             }
         }
     }
-  take_bw = __shfl(take_bw,0);
+  take_bw = __shfl(take_bw,g*L);
   cp_intvl *intvl = intvl_all+o;
   const int32_t *relmap = relmap_all+o;
   int8_t *gfw = asgn_all+o, *gbw = asgn_all+totalI+o;
-  for (int i = lane; i < M; i += WAVE)                     // class_rel.c:949-960
-    { int8_t f = S.asgn[0][i], w = S.asgn[1][i];
+  for (int i = ql; i < M; i += L)                          // class_rel.c:949-960
+    { int8_t f = S.asgn[g][0][i], w = S.asgn[g][1][i];
       int8_t a = take_bw ? w : f;
       gfw[i] = f; gbw[i] = w;
       rintvl[i].asgn = a;
@@ -724,21 +778,23 @@ k_classify_rel_lds(const cp_dev_params *__restrict__ P, const int64_t *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
-//  k_classify_unrel_lds: class_unrel.c:248-300, lane-parallel form for reads with N <= UNREL_MAXN.
+//  k_classify_unrel_grp<MINN,MAXN,G>: class_unrel.c:248-300, G reads per wave (64/G >= 8 lanes per
+//  read) for reads with MINN < N <= MAXN.
 //
-//  Interval fields sit in LDS; "nearest reliable interval of class s" (find_nn_u, a linear scan in
-//  the reference) is a bit scan over two LDS bitsets kept up to date as classes change.  The two
-//  sweeps stay sequential (every update reads its neighbours' current classes), but inside one
-//  update the eight expensive terms -- {H,D} x {left,right} x {Skellam transition, binomial tail}
-//  (class_unrel.c:115-175) -- are evaluated by eight lanes at once.
+//  Interval fields (16-bit) sit in LDS; "nearest reliable interval of class s" (find_nn_u, a linear
+//  scan in the reference) is a bit scan over two LDS bitsets kept up to date as classes change.  The
+//  two sweeps stay sequential per read (every update reads its neighbours' current classes), but one
+//  wave advances G reads at once and inside an update the eight expensive terms -- {H,D} x
+//  {left,right} x {Skellam transition, binomial tail} (class_unrel.c:115-175) -- sit on eight lanes,
+//  the Skellam ones of all reads meeting at one convergent Bessel call.
 // ---------------------------------------------------------------------------------------------
-struct unrel_lds_t
-  { int      b[UNREL_MAXN], e[UNREL_MAXN];
-    uint16_t cb[UNREL_MAXN], ce[UNREL_MAXN], ccb[UNREL_MAXN], cce[UNREL_MAXN];
-    int8_t   asgn[UNREL_MAXN];
-    uint8_t  isrel[UNREL_MAXN];
-    int16_t  ord[UNREL_MAXN];            // sorted index, bit 14 = fixed
-    uint64_t rel[2][UNREL_MAXN/64];      // [0] reliable & H, [1] reliable & D
+template <int MAXN, int G>
+struct unrel_grp_lds
+  { uint16_t b[G][MAXN], e[G][MAXN], cb[G][MAXN], ce[G][MAXN], ccb[G][MAXN], cce[G][MAXN];
+    int8_t   asgn[G][MAXN];
+    uint8_t  isrel[G][MAXN];
+    int16_t  ord[G][MAXN];               // sorted index, bit 14 = fixed
+    uint64_t rel[G][2][MAXN/64];         // [0] reliable & H, [1] reliable & D
   };
 
 __device__ __forceinline__ int bits_left(const uint64_t *bits, int idx)       // nearest set bit < idx
@@ -760,112 +816,145 @@ __device__ __forceinline__ int bits_right(const uint64_t *bits, int idx, int nwo
     }
 }
 
-// est_cov's first half (class_unrel.c:30-43) on the LDS tables; -1 = no reliable neighbour
-__device__ __forceinline__ int unrel_est1(const unrel_lds_t &S, int x, int l, int r)
-{ if (l != -1 && r != -1)
-    return (int)(uint16_t)cp_linear_interpolation(x,S.e[l]-1,S.cce[l],S.b[r],S.ccb[r]);
-  else if (l != -1) return S.cce[l];
-  else if (r != -1) return S.ccb[r];
-  return -1;
-}
-
+template <int MINN, int MAXN, int G>
 __global__ void __launch_bounds__(WAVE)
-k_classify_unrel_lds(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__restrict__ intvl_all,
+k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__restrict__ intvl_all,
                      const int64_t *__restrict__ ioff, const int32_t *__restrict__ nintvl)
-{ __shared__ unrel_lds_t S;
-  const int r = blockIdx.x;
-  if (r >= nreads) return;
+{ __shared__ unrel_grp_lds<MAXN,G> S;
+  constexpr int L = WAVE/G;
+  static_assert(L >= 8 && (L % 8) == 0, "8 role lanes per read");
   const int lane = lane_id();
-  const int N = nintvl[r];
-  if (N == 0 || N > UNREL_MAXN) return;                    // big reads: k_classify_unrel
-  cp_intvl *intvl = intvl_all+ioff[r];
+  const int g = lane/L, ql = lane%L, gbase = g*L;
+  const int r = blockIdx.x*G+g;
+  int N = (r < nreads) ? nintvl[r] : 0;
+  if (N <= MINN || N > MAXN) N = 0;                        // other size classes / sequential kernel
+  if (__ballot(N > 0) == 0) return;
+  cp_intvl *intvl = intvl_all+ioff[(r < nreads) ? r : 0];
   const int nwords = (N+63) >> 6;
   const int REP = P->cov[CP_REPEAT];
+  int maxN = N;
+  for (int o = 32; o > 0; o >>= 1)
+    { int x = __shfl_xor(maxN,o); maxN = x > maxN ? x : maxN; }
 
-  for (int base = 0; base < N; base += WAVE)
-    { int k = base+lane;
+  for (int k = ql; k < MAXN/64; k += L)
+    { S.rel[g][0][k] = 0; S.rel[g][1][k] = 0; }
+  wave_sync();
+  for (int base = 0; base < maxN; base += L)               // load + bitsets, L intervals of every read per step
+    { const int k = base+ql;
       bool h = false, dd = false;
       if (k < N)
         { const cp_intvl I = intvl[k];
-          S.b[k] = I.b; S.e[k] = I.e; S.cb[k] = I.cb; S.ce[k] = I.ce; S.ccb[k] = I.ccb; S.cce[k] = I.cce;
-          S.asgn[k] = I.asgn; S.isrel[k] = I.is_rel;
+          S.b[g][k] = (uint16_t)I.b; S.e[g][k] = (uint16_t)I.e;
+          S.cb[g][k] = I.cb; S.ce[g][k] = I.ce; S.ccb[g][k] = I.ccb; S.cce[g][k] = I.cce;
+          S.asgn[g][k] = I.asgn; S.isrel[g][k] = I.is_rel;
           h  = I.is_rel && I.asgn == CP_HAPLO;
           dd = I.is_rel && I.asgn == CP_DIPLO;
         }
-      uint64_t mh = __ballot(h), md = __ballot(dd);
-      if (lane == 0)
-        { S.rel[0][base >> 6] = mh;
-          S.rel[1][base >> 6] = md;
+      const uint64_t mh = __ballot(h) >> gbase, md = __ballot(dd) >> gbase;
+      if (ql == 0 && base < N)                             // this read's L flags start at bit `base` (L | 64)
+        { const uint64_t lm = (L == 64) ? ~0ull : ((1ull << L)-1);
+          S.rel[g][0][base >> 6] |= (mh & lm) << (base & 63);
+          S.rel[g][1][base >> 6] |= (md & lm) << (base & 63);
         }
     }
   wave_sync();
-  for (int k = lane; k < N; k += WAVE)                     // stable sort by min(cb,ce), class_unrel.c:252-258
-    { const int key = S.cb[k] < S.ce[k] ? S.cb[k] : S.ce[k];
+  for (int k = ql; k < N; k += L)                          // stable sort by min(cb,ce), class_unrel.c:252-258
+    { const int key = S.cb[g][k] < S.ce[g][k] ? S.cb[g][k] : S.ce[g][k];
       int rank = 0;
       for (int m = 0; m < N; m++)
-        { int km = S.cb[m] < S.ce[m] ? S.cb[m] : S.ce[m];
+        { int km = S.cb[g][m] < S.ce[g][m] ? S.cb[g][m] : S.ce[g][m];
           rank += (km < key || (km == key && m < k)) ? 1 : 0;
         }
-      int fixed = (S.isrel[k] && (S.asgn[k] == CP_HAPLO || S.asgn[k] == CP_DIPLO)) ? 1 : 0;
-      S.ord[rank] = (int16_t)(k | (fixed << 14));
+      int fixed = (S.isrel[g][k] && (S.asgn[g][k] == CP_HAPLO || S.asgn[g][k] == CP_DIPLO)) ? 1 : 0;
+      S.ord[g][rank] = (int16_t)(k | (fixed << 14));
     }
   wave_sync();
 
+  // role of this lane inside its read's group: class (H,D) x side (L,R) x kind (0: max(er,sf), 1: sf_er)
+  const int s2 = (ql >> 2) & 1, side = (ql >> 1) & 1, kind = ql & 1;
+  const int s = s2 ? CP_DIPLO : CP_HAPLO;
   for (int pass = 0; pass < 2; pass++)                     // class_unrel.c:260-274
-    for (int it = 0; it < N; it++)
-      { const int oi = S.ord[pass == 0 ? N-1-it : it];
-        if (oi & (1 << 14))
-          continue;
-        const int idx = oi;
-        const int Ib = S.b[idx], Ie = S.e[idx], Icb = S.cb[idx], Ice = S.ce[idx];
-        int snew;
-        if ((Icb > Ice ? Icb : Ice) >= REP)                // update_state, class_unrel.c:195-199
-          snew = CP_REPEAT;
-        else
-          { const int lH = bits_left(S.rel[0],idx), rH = bits_right(S.rel[0],idx,nwords);
-            const int lD = bits_left(S.rel[1],idx), rD = bits_right(S.rel[1],idx,nwords);
-            // lanes 0-7: class (H,D) x side (L,R) x kind (0: max(er,sf), 1: sf_er)   class_unrel.c:123-163
-            const int s2 = (lane >> 2) & 1, side = (lane >> 1) & 1, kind = lane & 1;
-            const int s = s2 ? CP_DIPLO : CP_HAPLO;
-            const int l_rel = s2 ? lD : lH, r_rel = s2 ? rD : rH;
-            double val = -INFINITY;
-            if (lane < 8)
-              { if (kind == 0)
-                  { double er = -INFINITY, sf = -INFINITY;
-                    if (side == 0)
-                      { if (idx-1 >= 0 && S.asgn[idx-1] == (int8_t)s) er = intvl[idx].peo_b;
-                        if (l_rel != -1) sf = cp_logp_trans(P,S.e[l_rel]-1,Ib,S.cce[l_rel],Icb,S.cce[l_rel]);
+    for (int it = 0; it < maxN; it++)
+      { bool on = it < N;
+        int idx = 0;
+        if (on)
+          { const int oi = S.ord[g][pass == 0 ? N-1-it : it];
+            on = !(oi & (1 << 14));
+            idx = oi & 0x3fff;
+          }
+        int snew = -1;
+        bool do_sf = false, do_bin = false;
+        int tb = 0, te = 0, tcb = 0, tce = 0, tcov = 0, est = 0, c = 0;
+        int Icb = 0, Ice = 0, lD = -1, rD = -1;
+        double er = -INFINITY;
+        if (on)
+          { const int Ib = S.b[g][idx], Ie = S.e[g][idx];
+            Icb = S.cb[g][idx]; Ice = S.ce[g][idx];
+            if ((Icb > Ice ? Icb : Ice) >= REP)            // update_state, class_unrel.c:195-199
+              { snew = CP_REPEAT;
+                on = false;
+              }
+            else
+              { const int lH = bits_left(S.rel[g][0],idx), rH = bits_right(S.rel[g][0],idx,nwords);
+                lD = bits_left(S.rel[g][1],idx); rD = bits_right(S.rel[g][1],idx,nwords);
+                const int l_rel = s2 ? lD : lH, r_rel = s2 ? rD : rH;
+                if (ql < 8)                                // class_unrel.c:123-163, arguments only
+                  { if (kind == 0)
+                      { if (side == 0)
+                          { if (idx-1 >= 0 && S.asgn[g][idx-1] == (int8_t)s) er = intvl[idx].peo_b;
+                            if (l_rel != -1)
+                              { do_sf = true; tb = S.e[g][l_rel]-1; te = Ib; tcb = S.cce[g][l_rel]; tce = Icb; tcov = tcb; }
+                          }
+                        else
+                          { if (idx+1 < N && S.asgn[g][idx+1] == (int8_t)s) er = intvl[idx].peo_e;
+                            if (r_rel != -1)
+                              { do_sf = true; tb = Ie-1; te = S.b[g][r_rel]; tcb = Ice; tce = S.ccb[g][r_rel]; tcov = tce; }
+                          }
                       }
                     else
-                      { if (idx+1 < N && S.asgn[idx+1] == (int8_t)s) er = intvl[idx].peo_e;
-                        if (r_rel != -1) sf = cp_logp_trans(P,Ie-1,S.b[r_rel],Ice,S.ccb[r_rel],S.ccb[r_rel]);
+                      { const int x = side ? Ie-1 : Ib;
+                        c = side ? Ice : Icb;
+                        // est_cov, class_unrel.c:27-51: this class's neighbours, else the other class's
+                        int ll = l_rel, rr = r_rel, e1 = -1;
+                        for (int rep = 0; rep < 2 && e1 < 0; rep++)
+                          { if (ll != -1 && rr != -1)
+                              e1 = (int)(uint16_t)cp_linear_interpolation(x,S.e[g][ll]-1,S.cce[g][ll],S.b[g][rr],S.ccb[g][rr]);
+                            else if (ll != -1) e1 = S.cce[g][ll];
+                            else if (rr != -1) e1 = S.ccb[g][rr];
+                            if (e1 < 0)
+                              { if (rep == 0) { ll = s2 ? lH : lD; rr = s2 ? rH : rD; }
+                                else e1 = -2;
+                              }
+                            else if (rep == 1)
+                              e1 = (e1 > 0) ? (((s == CP_HAPLO) ? e1/2 : e1*2) & 0xffff) : -2;
+                          }
+                        est = (e1 >= 0) ? e1 : P->cov[s];
+                        do_bin = est >= c;
                       }
-                    val = (er > sf) ? er : sf;
-                  }
-                else
-                  { const int x = side ? Ie-1 : Ib, c = side ? Ice : Icb;
-                    int est = unrel_est1(S,x,l_rel,r_rel);     // est_cov, class_unrel.c:27-51
-                    if (est < 0)
-                      { int cov = unrel_est1(S,x,s2 ? lH : lD,s2 ? rH : rD);
-                        if (cov < 0) cov = 0;
-                        est = (cov > 0) ? (((s == CP_HAPLO) ? cov/2 : cov*2) & 0xffff) : P->cov[s];
-                      }
-                    if (est >= c)
-                      val = log(cp_p_errorin(P,CP_OTHERS,0.1,P->u_lpe,P->u_l1mpe,est,c));
                   }
               }
+          }
+        // one convergent call per kind for every read of the wave
+        double val = -INFINITY;
+        if (do_sf)
+          val = cp_logp_trans(P,tb,te,tcb,tce,tcov);
+        if (do_bin)
+          val = log(cp_p_errorin(P,CP_OTHERS,0.1,P->u_lpe,P->u_l1mpe,est,c));
+        if (on)
+          { if (ql < 8 && kind == 0)
+              val = (er > val) ? er : val;
             double v1 = __shfl_down(val,1);
             double sidev = (val > v1) ? val : v1;              // MAX(MAX(er,sf),sf_er) on lanes with kind 0
             double vr = __shfl_down(sidev,2);
-            double logp_l = sidev, logp_r = vr, logp_s;        // meaningful on lanes 0 (H) and 4 (D)
+            double logp_l = sidev, logp_r = vr;                // meaningful on role lanes 0 (H) and 4 (D)
             if (logp_l == -INFINITY && logp_r == -INFINITY)    // class_unrel.c:165-173
               { logp_l = cp_logp_poisson(P,Icb,P->cov[s]);
                 logp_r = cp_logp_poisson(P,Ice,P->cov[s]);
               }
             else if (logp_l == -INFINITY) logp_l = logp_r;
             else if (logp_r == -INFINITY) logp_r = logp_l;
-            logp_s = logp_l+logp_r;
-            const double vH = __shfl(logp_s,0), vD = __shfl(logp_s,4);
+            const double logp_s = logp_l+logp_r;
+            const double vH = __shfl(logp_s,gbase), vD = __shfl(logp_s,gbase+4);
             // E and R are table look-ups (class_unrel.c:53-113)
             const double pe = intvl[idx].pe;
             const double po = cp_logp_poisson(P,Icb,P->cov[CP_ERROR])+cp_logp_poisson(P,Ice,P->cov[CP_ERROR])+CP_E_PO_BASE;
@@ -873,9 +962,9 @@ k_classify_unrel_lds(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
             double vR;
             { int dcov_l, dcov_r;
               if (lD == -1 && rD == -1) dcov_l = dcov_r = P->cov[CP_DIPLO];
-              else if (lD == -1)        dcov_l = dcov_r = S.cb[rD];
-              else if (rD == -1)        dcov_l = dcov_r = S.ce[lD];
-              else                      { dcov_l = S.ce[lD]; dcov_r = S.cb[rD]; }
+              else if (lD == -1)        dcov_l = dcov_r = S.cb[g][rD];
+              else if (rD == -1)        dcov_l = dcov_r = S.ce[g][lD];
+              else                      { dcov_l = S.ce[g][lD]; dcov_r = S.cb[g][rD]; }
               int rcov_l = (uint16_t)(P->dr_ratio*dcov_l);
               int rcov_r = (uint16_t)(P->dr_ratio*dcov_r);
               if (Icb >= rcov_l || Ice >= rcov_r)
@@ -884,28 +973,27 @@ k_classify_unrel_lds(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
                 vR = cp_logp_binom_pre(P,Icb,rcov_l,P->r_lp,P->r_l1mp)+cp_logp_binom_pre(P,Ice,rcov_r,P->r_lp,P->r_l1mp);
             }
             double logpmax = -INFINITY;                        // class_unrel.c:208-218: E,R,H,D with strict <
-            snew = -1;
             if (logpmax < vE) { logpmax = vE; snew = CP_ERROR; }
             if (logpmax < vR) { logpmax = vR; snew = CP_REPEAT; }
             if (logpmax < vH) { logpmax = vH; snew = CP_HAPLO; }
             if (logpmax < vD) { logpmax = vD; snew = CP_DIPLO; }
           }
-        wave_sync();                                           // everyone has read the old state
-        if (lane == 0 && snew >= 0)
-          { const int old = S.asgn[idx];
-            if (S.isrel[idx] && old != snew)
+        wave_sync();                                           // every read's lanes have read the old state
+        if (ql == 0 && snew >= 0)
+          { const int old = S.asgn[g][idx];
+            if (S.isrel[g][idx] && old != snew)
               { const uint64_t bit = 1ull << (idx & 63);
-                if (old == CP_HAPLO) S.rel[0][idx >> 6] &= ~bit;
-                if (old == CP_DIPLO) S.rel[1][idx >> 6] &= ~bit;
-                if (snew == CP_HAPLO) S.rel[0][idx >> 6] |= bit;
-                if (snew == CP_DIPLO) S.rel[1][idx >> 6] |= bit;
+                if (old == CP_HAPLO) S.rel[g][0][idx >> 6] &= ~bit;
+                if (old == CP_DIPLO) S.rel[g][1][idx >> 6] &= ~bit;
+                if (snew == CP_HAPLO) S.rel[g][0][idx >> 6] |= bit;
+                if (snew == CP_DIPLO) S.rel[g][1][idx >> 6] |= bit;
               }
-            S.asgn[idx] = (int8_t)snew;
+            S.asgn[g][idx] = (int8_t)snew;
           }
         wave_sync();
       }
-  for (int k = lane; k < N; k += WAVE)
-    intvl[k].asgn = S.asgn[k];
+  for (int k = ql; k < N; k += L)
+    intvl[k].asgn = S.asgn[g][k];
 }
 
 // ---------------------------------------------------------------------------------------------
