@@ -96,7 +96,7 @@ struct dbuf { void *p; size_t cap; };
 
 struct cp_workspace
   { dbuf bitmap, ncand, nintvl, nrel, ioff, eoff, wall, perror, eintvl, ointvl, intvl, rintvl,
-         relmap, parent, eff, rpos, asgn, ord, err;
+         relmap, parent, eff, rpos, asgn, ord, err, memo_val, memo_key;
     int64_t *h_totals;        // pinned: [totalI, totalE]
     int32_t *h_err;           // pinned
     // shape of the last run
@@ -139,7 +139,7 @@ extern "C" void cp_workspace_destroy(cp_workspace *ws)
 { if (!ws) return;
   dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->wall,&ws->perror,
                   &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
-                  &ws->asgn,&ws->ord,&ws->err };
+                  &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key };
   for (dbuf *b : all) if (b->p) (void)hipFree(b->p);
   if (ws->h_totals) (void)hipHostFree(ws->h_totals);
   if (ws->h_err) (void)hipHostFree(ws->h_err);
@@ -150,7 +150,7 @@ extern "C" size_t cp_workspace_bytes(const cp_workspace *ws)
 { if (!ws) return 0;
   const dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->wall,&ws->perror,
                         &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
-                        &ws->asgn,&ws->ord,&ws->err };
+                        &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key };
   size_t s = 0;
   for (const dbuf *b : all) s += b->cap;
   return s;
@@ -270,11 +270,11 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->parent.p,(int32_t *)ws->eff.p,
                      (uint8_t *)ws->rpos.p,(int8_t *)ws->asgn.p,totalI);
-  // size classes: M <= 256 two reads per wave, 256 < M <= 1024 one read per wave, larger: sequential kernel above
-  hipLaunchKernelGGL((k_classify_rel_grp<0,256,2>),dim3((nreads+1)/2),dim3(WAVE),0,st,
+  // size classes: M <= 128 two reads per wave, 128 < M <= 1024 one read per wave, larger: sequential kernel above
+  hipLaunchKernelGGL((k_classify_rel_grp<0,128,2>),dim3((nreads+1)/2),dim3(WAVE),0,st,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI);
-  hipLaunchKernelGGL((k_classify_rel_grp<256,1024,1>),dim3(nreads),dim3(WAVE),0,st,
+  hipLaunchKernelGGL((k_classify_rel_grp<128,1024,1>),dim3(nreads),dim3(WAVE),0,st,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI);
   HIPCHK(hipGetLastError());
@@ -287,10 +287,14 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
                      (int32_t *)ws->ord.p);
   // size classes: N <= 256 eight reads per wave, 256 < N <= 1024 two reads per wave, larger: sequential kernel above
+  ENSURE(ws->memo_val,(size_t)totalI*8*8);
+  ENSURE(ws->memo_key,(size_t)totalI*8*4);
   hipLaunchKernelGGL((k_classify_unrel_grp<0,256,8>),dim3((nreads+7)/8),dim3(WAVE),0,st,
-                     p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p);
+                     p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
+                     (double *)ws->memo_val.p,(int32_t *)ws->memo_key.p);
   hipLaunchKernelGGL((k_classify_unrel_grp<256,1024,2>),dim3((nreads+1)/2),dim3(WAVE),0,st,
-                     p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p);
+                     p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
+                     (double *)ws->memo_val.p,(int32_t *)ws->memo_key.p);
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_CLASS_ALL)
     return CP_OK;

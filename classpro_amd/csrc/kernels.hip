@@ -494,7 +494,7 @@ k_classify_unrel(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__re
 template <int MAXM, int G>
 struct rel_grp_lds
   { uint16_t b[G][MAXM], e[G][MAXM], ccb[G][MAXM], cce[G][MAXM];
-    int8_t   parent[G][2][MAXM*4];
+    uint8_t  parent[G][2][MAXM];         // back-pointers of the 4 cells of an interval, 2 bits each
     int16_t  eff[G][2][MAXM];
     uint8_t  rpos[G][2][MAXM];
     int8_t   asgn[G][2][MAXM];
@@ -546,9 +546,9 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
       cp_rel_init_cell(P,l16,I,i,plen,F,COV,&c);
       S.cell[g][d][0][l16] = c;
       S.tr[g][d][l16] = exp(c.dp);
-      S.parent[g][d][i*4+l16] = (int8_t)l16;
       if (l16 == 0)
-        { S.rpos[g][d][i] = 0;
+        { S.parent[g][d][i] = 0xe4;                        // each state its own parent: 3,2,1,0
+          S.rpos[g][d][i] = 0;
           S.eff[g][d][i] = (int16_t)i;
         }
     }
@@ -631,10 +631,10 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
                 only_r = false;
             }
           cp_cell c;
+          int pv = l16;
           if (only_r)
             { c = S.cell[g][d][cur][l16];
               cp_rel_only_r_cell(l16,i,&c);
-              S.parent[g][d][i*4+l16] = (int8_t)l16;
               if (l16 == 0)
                 { S.rpos[g][d][i] = 1;
                   S.eff[g][d][i] = S.eff[g][d][i_pred];
@@ -657,7 +657,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
                       max_s = x;
                     }
                 }
-              S.parent[g][d][i*4+l16] = (int8_t)(max_s == CP_N_STATE ? l16 : max_s);
+              pv = (max_s == CP_N_STATE) ? l16 : max_s;
               if (l16 == 0)
                 { S.rpos[g][d][i] = 0;
                   S.eff[g][d][i] = (int16_t)i;
@@ -665,6 +665,10 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
               cp_rel_target_cell(P,l16,i,I,F,COV,max_s,max_logp,&S.cell[g][d][cur][0],view,&c);
             }
           S.cell[g][d][cur^1][l16] = c;
+          const int l0 = lane-l16;                         // pack the four back-pointers into one byte
+          const int pk = pv | (__shfl(pv,l0+1) << 2) | (__shfl(pv,l0+2) << 4) | (__shfl(pv,l0+3) << 6);
+          if (l16 == 0)
+            S.parent[g][d][i] = (uint8_t)pk;
         }
       wave_sync();
       cur ^= 1;
@@ -682,12 +686,12 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
       if (F)
         for (int k = M-1; k >= 0; k--)
           { S.asgn[g][d][k] = S.rpos[g][d][k] ? (int8_t)CP_REPEAT : (int8_t)st;
-            st = S.parent[g][d][k*4+st];
+            st = (S.parent[g][d][k] >> (2*st)) & 3;
           }
       else
         for (int k = 0; k < M; k++)
           { S.asgn[g][d][k] = S.rpos[g][d][k] ? (int8_t)CP_REPEAT : (int8_t)st;
-            st = S.parent[g][d][k*4+st];
+            st = (S.parent[g][d][k] >> (2*st)) & 3;
           }
     }
   wave_sync();
@@ -819,7 +823,8 @@ __device__ __forceinline__ int bits_right(const uint64_t *bits, int idx, int nwo
 template <int MINN, int MAXN, int G>
 __global__ void __launch_bounds__(WAVE)
 k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__restrict__ intvl_all,
-                     const int64_t *__restrict__ ioff, const int32_t *__restrict__ nintvl)
+                     const int64_t *__restrict__ ioff, const int32_t *__restrict__ nintvl,
+                     double *__restrict__ memo_val, int32_t *__restrict__ memo_key)
 { __shared__ unrel_grp_lds<MAXN,G> S;
   constexpr int L = WAVE/G;
   static_assert(L >= 8 && (L % 8) == 0, "8 role lanes per read");
@@ -829,7 +834,11 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
   int N = (r < nreads) ? nintvl[r] : 0;
   if (N <= MINN || N > MAXN) N = 0;                        // other size classes / sequential kernel
   if (__ballot(N > 0) == 0) return;
-  cp_intvl *intvl = intvl_all+ioff[(r < nreads) ? r : 0];
+  const int64_t io = ioff[(r < nreads) ? r : 0];
+  cp_intvl *intvl = intvl_all+io;
+  // memo of the expensive terms between the two sweeps: 8 (key,value) pairs per interval
+  double  *mval = memo_val+io*8;
+  int32_t *mkey = memo_key+io*8;
   const int nwords = (N+63) >> 6;
   const int REP = P->cov[CP_REPEAT];
   int maxN = N;
@@ -869,19 +878,28 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
       S.ord[g][rank] = (int16_t)(k | (fixed << 14));
     }
   wave_sync();
+  int nnf = 0;                                             // keep only the non-fixed intervals, order preserved
+  if (ql == 0)
+    for (int i = 0; i < N; i++)
+      { const int16_t oi = S.ord[g][i];
+        if (!(oi & (1 << 14)))
+          S.ord[g][nnf++] = oi;
+      }
+  nnf = __shfl(nnf,gbase);
+  int maxNF = nnf;
+  for (int o = 32; o > 0; o >>= 1)
+    { int x = __shfl_xor(maxNF,o); maxNF = x > maxNF ? x : maxNF; }
+  wave_sync();
 
   // role of this lane inside its read's group: class (H,D) x side (L,R) x kind (0: max(er,sf), 1: sf_er)
   const int s2 = (ql >> 2) & 1, side = (ql >> 1) & 1, kind = ql & 1;
   const int s = s2 ? CP_DIPLO : CP_HAPLO;
   for (int pass = 0; pass < 2; pass++)                     // class_unrel.c:260-274
-    for (int it = 0; it < maxN; it++)
-      { bool on = it < N;
+    for (int it = 0; it < maxNF; it++)
+      { bool on = it < nnf;
         int idx = 0;
         if (on)
-          { const int oi = S.ord[g][pass == 0 ? N-1-it : it];
-            on = !(oi & (1 << 14));
-            idx = oi & 0x3fff;
-          }
+          idx = S.ord[g][pass == 0 ? nnf-1-it : it];
         int snew = -1;
         bool do_sf = false, do_bin = false;
         int tb = 0, te = 0, tcb = 0, tce = 0, tcov = 0, est = 0, c = 0;
@@ -934,12 +952,26 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
                   }
               }
           }
-        // one convergent call per kind for every read of the wave
+        // The Skellam term depends only on which neighbour was found, the binomial term only on the
+        // estimated count: the second sweep reuses the first sweep's value when that key is unchanged.
         double val = -INFINITY;
+        const int key = do_sf ? ((side == 0) ? tb : te) : (do_bin ? est : -1);   // tb/te identify the neighbour
+        if (pass == 1 && (do_sf || do_bin))
+          { if (mkey[idx*8+ql] == key)
+              { val = mval[idx*8+ql];
+                do_sf = do_bin = false;
+              }
+          }
+        const bool fresh = do_sf || do_bin;
+        // one convergent call per kind for every read of the wave
         if (do_sf)
           val = cp_logp_trans(P,tb,te,tcb,tce,tcov);
         if (do_bin)
           val = log(cp_p_errorin(P,CP_OTHERS,0.1,P->u_lpe,P->u_l1mpe,est,c));
+        if (pass == 0 && on && ql < 8)
+          { mkey[idx*8+ql] = fresh ? key : -1;
+            mval[idx*8+ql] = val;
+          }
         if (on)
           { if (ql < 8 && kind == 0)
               val = (er > val) ? er : val;
