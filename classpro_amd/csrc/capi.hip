@@ -95,13 +95,13 @@ extern "C" int cp_decode_profile(const uint8_t *code, int64_t len, uint16_t *pro
 struct dbuf { void *p; size_t cap; };
 
 struct cp_workspace
-  { dbuf bitmap, ncand, nintvl, nrel, ioff, eoff, wall, perror, eintvl, ointvl, intvl, rintvl,
+  { dbuf bitmap, ncand, nintvl, nrel, ioff, eoff, hoff, wall, hkeys, hvals, eintvl, ointvl, intvl, rintvl,
          relmap, parent, eff, rpos, asgn, ord, err, memo_val, memo_key;
-    int64_t *h_totals;        // pinned: [totalI, totalE]
+    int64_t *h_totals;        // pinned: [totalI, totalE, totalH]
     int32_t *h_err;           // pinned
     // shape of the last run
     int      nreads;
-    int64_t  total_kmers, total_bases, totalI, totalE, nwords;
+    int64_t  total_kmers, total_bases, totalI, totalE, totalH, nwords;
     int      last_stage;
     hipStream_t stream;
   };
@@ -125,7 +125,7 @@ extern "C" int cp_workspace_create(cp_workspace **out)
 { if (!out) return set_err(CP_EINVAL,"cp_workspace_create: null out");
   cp_workspace *ws = (cp_workspace *)calloc(1,sizeof(cp_workspace));
   if (!ws) return set_err(CP_ENOMEM,"cp_workspace_create: out of memory");
-  hipError_t e = hipHostMalloc((void **)&ws->h_totals,2*sizeof(int64_t),hipHostMallocDefault);
+  hipError_t e = hipHostMalloc((void **)&ws->h_totals,4*sizeof(int64_t),hipHostMallocDefault);
   if (e == hipSuccess) e = hipHostMalloc((void **)&ws->h_err,sizeof(int32_t),hipHostMallocDefault);
   if (e != hipSuccess)
     { free(ws);
@@ -137,7 +137,7 @@ extern "C" int cp_workspace_create(cp_workspace **out)
 
 extern "C" void cp_workspace_destroy(cp_workspace *ws)
 { if (!ws) return;
-  dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->wall,&ws->perror,
+  dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->hkeys,&ws->hvals,
                   &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
                   &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key };
   for (dbuf *b : all) if (b->p) (void)hipFree(b->p);
@@ -148,7 +148,7 @@ extern "C" void cp_workspace_destroy(cp_workspace *ws)
 
 extern "C" size_t cp_workspace_bytes(const cp_workspace *ws)
 { if (!ws) return 0;
-  const dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->wall,&ws->perror,
+  const dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->hkeys,&ws->hvals,
                         &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
                         &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key };
   size_t s = 0;
@@ -211,6 +211,7 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   ENSURE(ws->nrel,(size_t)nreads*4);
   ENSURE(ws->ioff,((size_t)nreads+1)*8);
   ENSURE(ws->eoff,((size_t)nreads+1)*8);
+  ENSURE(ws->hoff,((size_t)nreads+1)*8);
   ENSURE(ws->err,16);
   HIPCHK(hipMemsetAsync(ws->err.p,0,16,st));
   HIPCHK(hipMemsetAsync(ws->nintvl.p,0,(size_t)nreads*4,st));
@@ -219,8 +220,9 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   if (rc != CP_OK) return rc;
   hipLaunchKernelGGL(k_count_caps,dim3(nreads),dim3(WAVE),0,st,
                      (const uint64_t *)ws->bitmap.p,d_prof_off,nreads,
-                     (int32_t *)ws->ncand.p,(int64_t *)ws->ioff.p,(int64_t *)ws->eoff.p);
-  hipLaunchKernelGGL(k_prefix_caps,dim3(1),dim3(1024),0,st,(int64_t *)ws->ioff.p,(int64_t *)ws->eoff.p,nreads);
+                     (int32_t *)ws->ncand.p,(int64_t *)ws->ioff.p,(int64_t *)ws->eoff.p,(int64_t *)ws->hoff.p);
+  hipLaunchKernelGGL(k_prefix_caps,dim3(1),dim3(1024),0,st,(int64_t *)ws->ioff.p,(int64_t *)ws->eoff.p,
+                     (int64_t *)ws->hoff.p,nreads);
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_SCAN)
     return CP_OK;
@@ -228,22 +230,25 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   // the only host round trip of the pipeline: scratch sizes depend on the data
   HIPCHK(hipMemcpyAsync(&ws->h_totals[0],(int64_t *)ws->ioff.p+nreads,8,hipMemcpyDeviceToHost,st));
   HIPCHK(hipMemcpyAsync(&ws->h_totals[1],(int64_t *)ws->eoff.p+nreads,8,hipMemcpyDeviceToHost,st));
+  HIPCHK(hipMemcpyAsync(&ws->h_totals[2],(int64_t *)ws->hoff.p+nreads,8,hipMemcpyDeviceToHost,st));
   HIPCHK(hipStreamSynchronize(st));
-  const int64_t totalI = ws->h_totals[0], totalE = ws->h_totals[1];
-  ws->totalI = totalI; ws->totalE = totalE;
+  const int64_t totalI = ws->h_totals[0], totalE = ws->h_totals[1], totalH = ws->h_totals[2];
+  ws->totalI = totalI; ws->totalE = totalE; ws->totalH = totalH;
 
   // ---- stage 2: find_wall ----------------------------------------------------------------------
   const int64_t ncell = total_kmers+nreads;
   ENSURE(ws->wall,ncell);
-  ENSURE(ws->perror,(size_t)ncell*4*8);
+  ENSURE(ws->hkeys,(size_t)totalH*4);
+  ENSURE(ws->hvals,(size_t)totalH*4*8);
   ENSURE(ws->eintvl,(size_t)totalE*sizeof(cp_eintvl));
   ENSURE(ws->ointvl,(size_t)totalE*sizeof(cp_eintvl));
   ENSURE(ws->intvl,(size_t)totalI*sizeof(cp_intvl));
   HIPCHK(hipMemsetAsync(ws->wall.p,0,(size_t)ncell,st));
-  hipLaunchKernelGGL(k_fill_f64,dim3(256*8),dim3(256),0,st,(double *)ws->perror.p,ncell*4,-INFINITY);
+  HIPCHK(hipMemsetAsync(ws->hkeys.p,0xff,(size_t)totalH*4,st));       // every slot empty (key -1)
   hipLaunchKernelGGL(k_find_wall,dim3(nreads),dim3(WAVE),0,st,
                      p->dev,d_seq,d_seq_off,d_prof,d_prof_off,nreads,(const uint64_t *)ws->bitmap.p,
-                     (uint8_t *)ws->wall.p,(double *)ws->perror.p,(cp_eintvl *)ws->eintvl.p,(cp_eintvl *)ws->ointvl.p,
+                     (uint8_t *)ws->wall.p,(int32_t *)ws->hkeys.p,(double *)ws->hvals.p,(const int64_t *)ws->hoff.p,
+                     (cp_eintvl *)ws->eintvl.p,(cp_eintvl *)ws->ointvl.p,
                      (const int64_t *)ws->eoff.p,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,
                      (int32_t *)ws->nintvl.p,(int32_t *)ws->err.p);
   HIPCHK(hipGetLastError());

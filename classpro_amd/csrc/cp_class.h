@@ -16,10 +16,12 @@
 
 #define CP_NONE (-1)
 
+#ifndef CP_HDM
 #ifdef __HIPCC__
 #define CP_HDM __host__ __device__ __forceinline__
 #else
 #define CP_HDM inline
+#endif
 #endif
 
 struct cp_cell                       // one DP cell = (interval i, state s); ClassPro.h:210-219 per cell

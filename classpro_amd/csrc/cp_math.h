@@ -53,17 +53,32 @@ CP_HD double cp_bessi1(double x)
 }
 
 // ---- bessel.c:478-521: downward recurrence, 2*(n+(int)sqrt(40 n)) steps, 1e10 rescale ------
+// The rescale happens a handful of times per call; on the device it is kept out of the hot loop by a
+// wave-level vote (otherwise the compiler if-converts it into three extra multiplies and six selects
+// per step).  `dj` mirrors the integer counter exactly, so dj*tox*bi == j*tox*bi bit for bit.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CP_ANY_LANE(c) __any(c)
+#define CP_NO_IFCVT() asm volatile("" ::: "memory")     /* keeps the rare block a real branch */
+#else
+#define CP_ANY_LANE(c) (c)
+#define CP_NO_IFCVT() ((void)0)
+#endif
 CP_HD double cp_bessi(int n, double x)
 { if (n == 0) return cp_bessi0(x);
   if (n == 1) return cp_bessi1(x);
   if (x == 0.0) return 0.0;
   double tox = 2.0/fabs(x), bip = 0.0, ans = 0.0, bi = 1.0, bim;
-  for (int j = 2*(n+(int)sqrt(40.0*n)); j > 0; j--)
-    { bim = bip+j*tox*bi;
+  int j = 2*(n+(int)sqrt(40.0*n));
+  double dj = (double)j;
+  for (; j > 0; j--, dj -= 1.0)
+    { bim = bip+dj*tox*bi;
       bip = bi;
       bi  = bim;
-      if (fabs(bi) > 1.0e10)
-        { ans *= 1.0e-10; bi *= 1.0e-10; bip *= 1.0e-10; }
+      if (CP_ANY_LANE(fabs(bi) > 1.0e10))
+        { CP_NO_IFCVT();
+          if (fabs(bi) > 1.0e10)
+            { ans *= 1.0e-10; bi *= 1.0e-10; bip *= 1.0e-10; }
+        }
       if (j == n) ans = bip;
     }
   ans *= cp_bessi0(x)/bi;

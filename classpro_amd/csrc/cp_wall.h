@@ -5,37 +5,92 @@
 //
 // Per-read state lives in HBM scratch owned by the wave that processes the read:
 //   wall[plen+1]        flag byte per profile position (bit layout of wall.c:264-269)
-//   perror[plen+1][4]   memoised P(error) per position, [etype*2+wtype], -inf = unset (wall.c:310-315)
+//   perror              memoised P(error) per (position, etype, wtype), -inf = unset (wall.c:310-315).
+//                       The reference keeps a dense [plen+1][2][2] array; only ~3 positions per wall
+//                       candidate are ever touched, so the device keeps a small open-addressing table
+//                       per read (cp_perr_hash) that stays cache-resident.  Functions below are generic
+//                       over that store (`PE`): get(pos,e,w) -> value or -inf, set(pos,e,w,v).
 //   eintvl/ointvl       E-/O-interval lists (ClassPro.h:153-157)
 // Index plen is reset like every other index (the reference leaves it stale, SURVEY.md hazard 1).
 #pragma once
 #include "cp_math.h"
 #include "cp_ctx.h"
 
-struct cp_read
+#ifndef CP_HDM
+#ifdef __HIPCC__
+#define CP_HDM __host__ __device__ __forceinline__
+#else
+#define CP_HDM inline
+#endif
+#endif
+
+// dense store: the reference's layout (used by tests/host_harness.cpp)
+struct cp_perr_dense
+  { double *a;
+    CP_HDM double get(int pos, int e, int w) const { return a[(size_t)pos*4+e*2+w]; }
+    CP_HDM void   set(int pos, int e, int w, double v) { a[(size_t)pos*4+e*2+w] = v; }
+  };
+
+// sparse store: open addressing, linear probing, insert-only; keys[] start at -1, a slot's four
+// values are set to -inf when the slot is claimed.  Capacity (mask+1) is a power of two >= 4*ncand+16
+// while at most 3*ncand+2 positions can ever be touched, so the table never fills.
+struct cp_perr_hash
+  { int32_t *keys;
+    double  *vals;
+    uint32_t mask;
+    CP_HDM uint32_t slot0(int pos) const { return ((uint32_t)pos*0x9E3779B1u >> 7) & mask; }
+    CP_HDM double get(int pos, int e, int w) const
+    { uint32_t h = slot0(pos);
+      while (true)
+        { int32_t k = keys[h];
+          if (k == pos) return vals[(size_t)h*4+e*2+w];
+          if (k < 0) return -INFINITY;
+          h = (h+1) & mask;
+        }
+    }
+    CP_HDM void set(int pos, int e, int w, double v)
+    { uint32_t h = slot0(pos);
+      while (true)
+        { int32_t k = keys[h];
+          if (k == pos) break;
+          if (k < 0)
+            { keys[h] = pos;
+              for (int x = 0; x < 4; x++) vals[(size_t)h*4+x] = -INFINITY;
+              break;
+            }
+          h = (h+1) & mask;
+        }
+      vals[(size_t)h*4+e*2+w] = v;
+    }
+  };
+
+template <class PE>
+struct cp_read_t
   { const cp_dev_params *P;
     const uint16_t      *prof;
     const char          *seq;
     int                  plen, rlen;
     uint8_t             *wall;
-    double              *perror;
+    PE                   perror;
     cp_eintvl           *eintvl, *ointvl;
     int                  ecap;
     int                  eidx, oidx;
     int                  overflow;
   };
 
-#define CP_PERR(R,i,e,w) ((R)->perror[(size_t)(i)*4+(e)*2+(w)])
+#define CP_PERR(R,i,e,w) ((R)->perror.get(i,e,w))
 #define CP_NEG_INF (-INFINITY)
 
 // wall.c:310-315
-CP_HD void cp_update_perror(cp_read *R, int i, int e, int w, int cout, int cin, double erate, double lpe, double l1mpe)
+template <class RD>
+CP_HD void cp_update_perror(RD *R, int i, int e, int w, int cout, int cin, double erate, double lpe, double l1mpe)
 { if (CP_PERR(R,i,e,w) == CP_NEG_INF)
-    CP_PERR(R,i,e,w) = cp_p_errorin(R->P,e,erate,lpe,l1mpe,cout,cin);
+    R->perror.set(i,e,w,cp_p_errorin(R->P,e,erate,lpe,l1mpe,cout,cin));
 }
 
 // wall.c:317-322
-CP_HD double cp_logp_diff_pair(const cp_read *R, int i, int j)
+template <class RD>
+CP_HD double cp_logp_diff_pair(const RD *R, int i, int j)
 { const uint16_t *pr = R->prof;
   int n_drop = (int)pr[i-1]-pr[i];
   int n_gain = (int)pr[j]-pr[j-1];
@@ -49,7 +104,8 @@ CP_HD bool cp_cthres_ng(int e, int cin, int ct)
 
 // wall.c:331-507: find_gain (w == DROP: partner GAIN to the right of i) and find_drop (w == GAIN:
 // partner DROP to the left), folded into one routine by mirroring the index arithmetic.
-CP_HD bool cp_find_pair(cp_read *R, int i, int cout, int cin, int e, int w, int t, int l,
+template <class RD>
+CP_HD bool cp_find_pair(RD *R, int i, int cout, int cin, int e, int w, int t, int l,
                         double erate, double lpe, double l1mpe, cp_eintvl *out)
 { const cp_dev_params *P = R->P;
   const uint16_t *pr = R->prof;
@@ -132,7 +188,8 @@ CP_HD bool cp_find_pair(cp_read *R, int i, int cout, int cin, int e, int w, int 
 
 // One iteration of the candidate walk, wall.c:590-707, for a position i that passed the scan
 // (min(c[i-1],c[i]) < R and |c[i-1]-c[i]| >= 3).
-CP_HD void cp_wall_candidate(cp_read *R, int i)
+template <class RD>
+CP_HD void cp_wall_candidate(RD *R, int i)
 { const cp_dev_params *P = R->P;
   const int CMAX = P->cmax;
   const int cim1 = R->prof[i-1], ci = R->prof[i];
@@ -243,7 +300,8 @@ CP_HD int cp_dedupe_sorted(cp_eintvl *v, int N)
 // wall.c:763-860 for one O-only wall i: look up to 200 positions right (DROP) / left (GAIN) for
 // partner walls that would make [i,j) an error interval by multiple errors; boundary intervals at
 // plen / 0.  `NS` = number of sorted unique E-intervals, `*midx` = append cursor.
-CP_HD void cp_wall_mult(cp_read *R, int i, int NS, int *midx)
+template <class RD>
+CP_HD void cp_wall_mult(RD *R, int i, int NS, int *midx)
 { uint8_t *wall = R->wall;
   const int plen = R->plen;
   cp_eintvl *ev = R->eintvl;
@@ -309,7 +367,8 @@ CP_HD void cp_wall_mult(cp_read *R, int i, int NS, int *midx)
 }
 
 // wall.c:878-909: append the union of every chain of overlapping E-intervals (list sorted by (b,e)).
-CP_HD int cp_merge_eintvl(cp_read *R, int NS)
+template <class RD>
+CP_HD int cp_merge_eintvl(RD *R, int NS)
 { cp_eintvl *ev = R->eintvl;
   const int n0 = NS;
   int i = 0, j;
@@ -337,7 +396,8 @@ CP_HD int cp_merge_eintvl(cp_read *R, int NS)
 }
 
 // wall.c:928-946: the record of interval [b,e) given the final sorted E-interval list.
-CP_HD void cp_make_interval(const cp_read *R, int NS, int b, int e, cp_intvl *out)
+template <class RD>
+CP_HD void cp_make_interval(const RD *R, int NS, int b, int e, cp_intvl *out)
 { int idx = cp_bs_eintvl(R->eintvl,0,NS-1,b,e);
   out->b = b;
   out->e = e;

@@ -5,7 +5,7 @@
 // addressed with the same offsets:
 //   bitmap   1 bit per profile position over the WHOLE concatenated profile (bit g = candidate at g)
 //   wall     1 byte per position, read r at wall + prof_off[r] + r        (plen+1 cells per read)
-//   perror   4 doubles per position, same indexing
+//   hkeys/hvals  per-read open-addressing table position -> 4 memoised probabilities (perror), read r at hoff[r]
 //   eintvl / ointvl   E-/O-interval lists, read r at eoff[r], capacity eoff[r+1]-eoff[r]
 //   intvl / rintvl / relmap / DP scratch   read r at ioff[r], capacity ioff[r+1]-ioff[r]
 //
@@ -13,7 +13,6 @@
 //   k_scan_candidates   streaming pass over the profile (the HBM-roofline kernel): wall.c:590-607
 //   k_count_caps        per-read candidate count -> scratch capacities
 //   k_prefix_caps       exclusive prefix sums of the capacities (single block)
-//   k_fill_f64          perror := -inf
 //   k_find_wall         one wave per read: wall.c:570-958
 //   k_find_rel          one wave per read, one lane per interval: wall.c:960-1051
 //   k_classify_rel_grp   2 reads per wave (1 for M > 256), lane per transition: class_rel.c:871-963
@@ -105,6 +104,7 @@ k_scan_candidates(const uint16_t *__restrict__ prof, int64_t total, int rep, uin
 //  Candidate count per read and scratch capacities.
 //    N (intervals)  <= 2*ncand+3   (boundaries are O-walls = candidates, or E-interval endpoints)
 //    E-list entries <= 16*ncand+64 (checked at run time; overflow is reported, never silent)
+//    perror slots   <= 3*ncand+2   (a candidate's own position + one low-complexity partner per error type)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t bitmap_word(const uint64_t *bm, int64_t w, int64_t lo, int64_t hi)
 { // bits of word w restricted to global positions [lo,hi)
@@ -117,7 +117,8 @@ __device__ __forceinline__ uint64_t bitmap_word(const uint64_t *bm, int64_t w, i
 
 __global__ void __launch_bounds__(WAVE)
 k_count_caps(const uint64_t *__restrict__ bm, const int64_t *__restrict__ prof_off, int nreads,
-             int32_t *__restrict__ ncand, int64_t *__restrict__ icap, int64_t *__restrict__ ecap)
+             int32_t *__restrict__ ncand, int64_t *__restrict__ icap, int64_t *__restrict__ ecap,
+             int64_t *__restrict__ hcap)
 { const int r = blockIdx.x;
   if (r >= nreads) return;
   const int lane = lane_id();
@@ -132,48 +133,39 @@ k_count_caps(const uint64_t *__restrict__ bm, const int64_t *__restrict__ prof_o
     { ncand[r] = cnt;
       icap[r]  = 2*(int64_t)cnt+4;
       ecap[r]  = 16*(int64_t)cnt+64;
+      int64_t h = 32;                                   // perror table: power of two >= 4*ncand+16
+      while (h < 4*(int64_t)cnt+16) h <<= 1;
+      hcap[r] = h;
     }
 }
 
-// exclusive prefix sums of two int64 arrays, in place, totals appended at [n]; single block.
+// exclusive prefix sums of three int64 arrays, in place, totals appended at [n]; single block.
 __global__ void __launch_bounds__(1024)
-k_prefix_caps(int64_t *__restrict__ a, int64_t *__restrict__ b, int n)
-{ __shared__ int64_t sa[1024], sb[1024];
+k_prefix_caps(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__restrict__ c, int n)
+{ __shared__ int64_t sa[1024], sb[1024], sc[1024];
   const int t = threadIdx.x, T = blockDim.x;
   const int per = (n+T-1)/T;
   const int lo = t*per, hi = (lo+per < n) ? lo+per : n;
-  int64_t xa = 0, xb = 0;
-  for (int i = lo; i < hi; i++) { xa += a[i]; xb += b[i]; }
-  sa[t] = xa; sb[t] = xb;
+  int64_t xa = 0, xb = 0, xc = 0;
+  for (int i = lo; i < hi; i++) { xa += a[i]; xb += b[i]; xc += c[i]; }
+  sa[t] = xa; sb[t] = xb; sc[t] = xc;
   __syncthreads();
   if (t == 0)
-    { int64_t ra = 0, rb = 0;
+    { int64_t ra = 0, rb = 0, rc = 0;
       for (int i = 0; i < T; i++)
-        { int64_t ya = sa[i], yb = sb[i];
-          sa[i] = ra; sb[i] = rb;
-          ra += ya; rb += yb;
+        { int64_t ya = sa[i], yb = sb[i], yc = sc[i];
+          sa[i] = ra; sb[i] = rb; sc[i] = rc;
+          ra += ya; rb += yb; rc += yc;
         }
-      a[n] = ra; b[n] = rb;
+      a[n] = ra; b[n] = rb; c[n] = rc;
     }
   __syncthreads();
-  xa = sa[t]; xb = sb[t];
+  xa = sa[t]; xb = sb[t]; xc = sc[t];
   for (int i = lo; i < hi; i++)
-    { int64_t ya = a[i], yb = b[i];
-      a[i] = xa; b[i] = xb;
-      xa += ya; xb += yb;
+    { int64_t ya = a[i], yb = b[i], yc = c[i];
+      a[i] = xa; b[i] = xb; c[i] = xc;
+      xa += ya; xb += yb; xc += yc;
     }
-}
-
-__global__ void __launch_bounds__(256)
-k_fill_f64(double *__restrict__ p, int64_t n, double v)
-{ const int64_t stride = (int64_t)gridDim.x*blockDim.x;
-  int64_t n2 = n >> 1;
-  double2 *p2 = reinterpret_cast<double2 *>(p);
-  const double2 vv = make_double2(v,v);
-  for (int64_t i = (int64_t)blockIdx.x*blockDim.x+threadIdx.x; i < n2; i += stride)
-    p2[i] = vv;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1))
-    p[n-1] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -207,7 +199,8 @@ __device__ __forceinline__ void wave_wall_or(uint8_t *wall, int b, int e, uint8_
 __global__ void __launch_bounds__(WAVE)
 k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, const int64_t *__restrict__ seq_off,
             const uint16_t *__restrict__ prof, const int64_t *__restrict__ prof_off, int nreads,
-            const uint64_t *__restrict__ bm, uint8_t *__restrict__ wall_all, double *__restrict__ perror_all,
+            const uint64_t *__restrict__ bm, uint8_t *__restrict__ wall_all,
+            int32_t *__restrict__ hkeys, double *__restrict__ hvals, const int64_t *__restrict__ hoff,
             cp_eintvl *__restrict__ eintvl_all, cp_eintvl *__restrict__ ointvl_all, const int64_t *__restrict__ eoff,
             cp_intvl *__restrict__ intvl_all, const int64_t *__restrict__ ioff,
             int32_t *__restrict__ nintvl, int32_t *__restrict__ err)
@@ -218,10 +211,12 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   const int plen = (int)(prof_off[r+1]-po);
   const int rlen = (int)(seq_off[r+1]-seq_off[r]);
 
-  cp_read R;
+  cp_read_t<cp_perr_hash> R;
   R.P = P; R.prof = prof+po; R.seq = seq+seq_off[r]; R.plen = plen; R.rlen = rlen;
   R.wall = wall_all+po+r;
-  R.perror = perror_all+(po+r)*4;
+  R.perror.keys = hkeys+hoff[r];
+  R.perror.vals = hvals+hoff[r]*4;
+  R.perror.mask = (uint32_t)(hoff[r+1]-hoff[r])-1;
   R.eintvl = eintvl_all+eoff[r];
   R.ointvl = ointvl_all+eoff[r];
   R.ecap = (int)(eoff[r+1]-eoff[r]);
