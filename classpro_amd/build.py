@@ -9,6 +9,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OUT = os.path.join(_HERE, "libclasspro_amd.so")
+CLI = os.path.join(_HERE, "ClassPro")          # drop-in command line (csrc/host/classpro_main.cpp)
 # -ffp-contract=off: the decision path compares doubles against thresholds and truncates them to
 # ints (class_rel.c:449,483); fused multiply-adds would change those values.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
@@ -24,10 +25,16 @@ def _newest_src():
 
 
 def build(force=False, verbose=False):
-    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= _newest_src():
+    if (not force and os.path.exists(OUT) and os.path.exists(CLI)
+            and min(os.path.getmtime(OUT), os.path.getmtime(CLI)) >= _newest_src()):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc] + FLAGS + [os.path.join(CSRC, "capi.hip"), "-o", OUT]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    cmd = [hipcc, "-O2", "-std=c++17", os.path.join(CSRC, "host", "classpro_main.cpp"), "-o", CLI,
+           "-L" + _HERE, "-lclasspro_amd", "-lz", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

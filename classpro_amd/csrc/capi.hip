@@ -104,6 +104,8 @@ struct cp_workspace
     int64_t  total_kmers, total_bases, totalI, totalE, totalH, nwords;
     int      last_stage;
     hipStream_t stream;
+    hipStream_t aux;          // size classes of one stage run side by side: the rare long reads are latency-bound
+    hipEvent_t  ev_fork, ev_join;
   };
 
 static int ensure(dbuf &b, size_t need)
@@ -127,6 +129,9 @@ extern "C" int cp_workspace_create(cp_workspace **out)
   if (!ws) return set_err(CP_ENOMEM,"cp_workspace_create: out of memory");
   hipError_t e = hipHostMalloc((void **)&ws->h_totals,4*sizeof(int64_t),hipHostMallocDefault);
   if (e == hipSuccess) e = hipHostMalloc((void **)&ws->h_err,sizeof(int32_t),hipHostMallocDefault);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ws->aux,hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ws->ev_fork,hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ws->ev_join,hipEventDisableTiming);
   if (e != hipSuccess)
     { free(ws);
       return set_err(CP_EHIP,std::string("cp_workspace_create: ")+hipGetErrorString(e));
@@ -141,6 +146,9 @@ extern "C" void cp_workspace_destroy(cp_workspace *ws)
                   &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
                   &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key };
   for (dbuf *b : all) if (b->p) (void)hipFree(b->p);
+  if (ws->aux) (void)hipStreamDestroy(ws->aux);
+  if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
+  if (ws->ev_join) (void)hipEventDestroy(ws->ev_join);
   if (ws->h_totals) (void)hipHostFree(ws->h_totals);
   if (ws->h_err) (void)hipHostFree(ws->h_err);
   free(ws);
@@ -276,12 +284,18 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->parent.p,(int32_t *)ws->eff.p,
                      (uint8_t *)ws->rpos.p,(int8_t *)ws->asgn.p,totalI);
   // size classes: M <= 128 two reads per wave, 128 < M <= 1024 one read per wave, larger: sequential kernel above
+  // (the classes touch disjoint reads; the long-read class is a handful of latency-bound waves, so it
+  //  runs beside the main class on the auxiliary stream)
+  HIPCHK(hipEventRecord(ws->ev_fork,st));
+  HIPCHK(hipStreamWaitEvent(ws->aux,ws->ev_fork,0));
+  hipLaunchKernelGGL((k_classify_rel_grp<128,1024,1>),dim3(nreads),dim3(WAVE),0,ws->aux,
+                     p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
+                     (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI);
+  HIPCHK(hipEventRecord(ws->ev_join,ws->aux));
   hipLaunchKernelGGL((k_classify_rel_grp<0,128,2>),dim3((nreads+1)/2),dim3(WAVE),0,st,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI);
-  hipLaunchKernelGGL((k_classify_rel_grp<128,1024,1>),dim3(nreads),dim3(WAVE),0,st,
-                     p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
-                     (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI);
+  HIPCHK(hipStreamWaitEvent(st,ws->ev_join,0));
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_CLASS_REL)
     return CP_OK;
@@ -294,12 +308,16 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   // size classes: N <= 256 eight reads per wave, 256 < N <= 1024 two reads per wave, larger: sequential kernel above
   ENSURE(ws->memo_val,(size_t)totalI*8*8);
   ENSURE(ws->memo_key,(size_t)totalI*8*4);
+  HIPCHK(hipEventRecord(ws->ev_fork,st));
+  HIPCHK(hipStreamWaitEvent(ws->aux,ws->ev_fork,0));
+  hipLaunchKernelGGL((k_classify_unrel_grp<256,1024,2>),dim3((nreads+1)/2),dim3(WAVE),0,ws->aux,
+                     p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
+                     (double *)ws->memo_val.p,(int32_t *)ws->memo_key.p);
+  HIPCHK(hipEventRecord(ws->ev_join,ws->aux));
   hipLaunchKernelGGL((k_classify_unrel_grp<0,256,8>),dim3((nreads+7)/8),dim3(WAVE),0,st,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
                      (double *)ws->memo_val.p,(int32_t *)ws->memo_key.p);
-  hipLaunchKernelGGL((k_classify_unrel_grp<256,1024,2>),dim3((nreads+1)/2),dim3(WAVE),0,st,
-                     p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
-                     (double *)ws->memo_val.p,(int32_t *)ws->memo_key.p);
+  HIPCHK(hipStreamWaitEvent(st,ws->ev_join,0));
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_CLASS_ALL)
     return CP_OK;

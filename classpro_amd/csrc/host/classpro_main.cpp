@@ -1,0 +1,437 @@
+// classpro_main.cpp -- `ClassPro`-compatible command line on top of the C ABI (libclasspro_amd.so).
+//
+// Same process contract as the reference binary (src/const.c:14-17, src/ClassPro.c:348-631):
+//   ClassPro [-vs] [-T<int(4)>] [-c<int>] [-r<int(20000)>] [-P<tmp_dir(./)>] [-N<fastk_root>]
+//            [-M<model_path>] <source>[.db|.dam|.f[ast][aq][.gz]]
+// inputs  <fk_root>.hist, <fk_root>.prof, <dir>/.<root>.pidx.N, <dir>/.<root>.prof.N   (FASTK)
+// output  <dir>/<root>.class : "@name comment\nseq\n+\nlabels\n" per read              (ClassPro.c:289)
+//
+// The reference's pthread-per-read-range loop is replaced by read batches: the host parses FASTX
+// (kseq semantics) and decodes FASTK profiles (cp_decode_profile) into pinned staging buffers, copies
+// them with hipMemcpyAsync, calls cp_classify_batch, and writes the records in input order.  While
+// the GPU works on one batch the host stages the next one.
+//
+// Not supported yet (rows "next" of SURVEY.md section 8f; the reference's behaviour is exit(1) with a
+// message, so is ours): .db/.dam inputs, -s (needs .db), -M (HIsim model + polynomial fit).
+// -T is accepted for compatibility; the device does the work, -T only sizes nothing here.
+#include <hip/hip_runtime.h>
+#include <zlib.h>
+#include <dirent.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <strings.h>
+#include <cstdio>
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include <chrono>
+#include "../../../include/classpro_amd.h"
+
+static const char *PROG = "ClassPro";
+static const char *USAGE = "[-vs] [-T<int(4)>] [-c<int>] [-r<int(20000)>] "
+                           "[-P<tmp_dir(./)>] [-N<fastk_root>] [-M<model_path>] "
+                           "<source>[.db|.dam|.f[ast][aq][.gz]";                      // const.c:14-17
+static const char *EXT[10] = { ".db", ".dam", ".fastq", ".fasta", ".fq", ".fa",
+                               ".fastq.gz", ".fasta.gz", ".fq.gz", ".fa.gz" };          // ClassPro.h:326-330
+
+[[noreturn]] static void die(const char *fmt, ...)
+{ va_list ap;
+  va_start(ap,fmt);
+  vfprintf(stderr,fmt,ap);
+  va_end(ap);
+  exit(1);
+}
+#define HIPOK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) die("%s: %s: %s\n",PROG,#call,hipGetErrorString(e_)); } while (0)
+#define CPOK(call)  do { if ((call) < 0) die("%s\n",cp_last_error()); } while (0)
+
+// gene_core.c:71-81, 83-109
+static std::string path_to(const std::string &name)
+{ size_t p = name.rfind('/');
+  return p == std::string::npos ? std::string(".") : name.substr(0,p);
+}
+static std::string root_of(const std::string &name, const char *suffix)
+{ size_t p = name.rfind('/');
+  std::string f = p == std::string::npos ? name : name.substr(p+1);
+  size_t sl = strlen(suffix);
+  if (f.size() > sl && strcasecmp(f.c_str()+f.size()-sl,suffix) == 0)
+    return f.substr(0,f.size()-sl);
+  return f;
+}
+
+// ---- integer options, gene_core.h:46-77 ----------------------------------------------------------
+static int arg_int(const char *arg, const char *what, bool positive)
+{ char *end;
+  long v = strtol(arg+2,&end,10);
+  if (*end != '\0' || arg[2] == '\0')
+    die("%s: -%c '%s' argument is not an integer\n",PROG,arg[1],arg+2);
+  if (positive ? v <= 0 : v < 0)
+    die("%s: %s must be %s (%ld)\n",PROG,what,positive ? "positive" : "non-negative",v);
+  return (int)v;
+}
+
+// ---- FASTX reader with kseq.h semantics (name up to the first space, comment = rest of the header
+//      line, multi-line sequences, FASTQ qualities skipped) --------------------------------------
+struct FastxReader
+  { gzFile f;
+    std::vector<unsigned char> buf;
+    int beg, end;
+    bool eof;
+    int last;                      // last header char seen ('>' or '@'), 0 = none
+    std::string name, comment, seq;
+    bool have_comment;
+
+    explicit FastxReader(const char *path) : f(gzopen(path,"r")), buf(1 << 16), beg(0), end(0), eof(false), last(0), have_comment(false) {}
+    ~FastxReader() { if (f) gzclose(f); }
+    int getc()
+    { if (beg >= end)
+        { if (eof) return -1;
+          beg = 0;
+          end = gzread(f,buf.data(),(unsigned)buf.size());
+          if (end <= 0) { eof = true; end = 0; return -1; }
+        }
+      return buf[beg++];
+    }
+    // returns sequence length, or -1 at end of file
+    int next()
+    { int c;
+      if (last == 0)
+        { while ((c = getc()) != -1 && c != '>' && c != '@') ;
+          if (c == -1) return -1;
+          last = c;
+        }
+      name.clear(); seq.clear();
+      bool got_comment = false;
+      std::string cm;
+      while ((c = getc()) != -1 && c != ' ' && c != '\t' && c != '\n' && c != '\r') name.push_back((char)c);
+      if (c == ' ' || c == '\t')
+        { got_comment = true;
+          while ((c = getc()) != -1 && c != '\n') cm.push_back((char)c);
+          if (!cm.empty() && cm.back() == '\r') cm.pop_back();
+        }
+      else if (c == '\r')
+        while ((c = getc()) != -1 && c != '\n') ;
+      if (got_comment) { comment = cm; have_comment = true; }    // kseq leaves the old comment buffer otherwise
+      while ((c = getc()) != -1 && c != '>' && c != '+' && c != '@')
+        { if (c == '\n') continue;
+          if (c > 32) seq.push_back((char)c);
+          while ((c = getc()) != -1 && c != '\n')
+            if (c > 32) seq.push_back((char)c);
+        }
+      if (c == '>' || c == '@') last = c;
+      else last = 0;
+      if (c == '+')                                             // FASTQ: skip the rest of '+' line and the qualities
+        { while ((c = getc()) != -1 && c != '\n') ;
+          size_t q = 0;
+          while (q < seq.size() && (c = getc()) != -1)
+            if (c > 32) q++;
+          last = 0;
+        }
+      return (int)seq.size();
+    }
+  };
+
+// ---- FASTK profile index (libfastk.c:1267-1370) ----------------------------------------------------
+struct Profiles
+  { int kmer = 0, nparts = 0;
+    int64_t nreads = 0;
+    std::vector<int64_t> index;      // end offset of read i inside its part
+    std::vector<int64_t> nbase;      // reads before the end of part p
+    std::string prefix;              // <dir>/.<root>.
+    int cpart = -1;
+    std::vector<uint8_t> data;       // current part, whole file
+
+    bool open(const std::string &fk_root)
+    { std::string dir = path_to(fk_root), root = root_of(fk_root,".prof");
+      std::string stub = dir+"/"+root+".prof";
+      FILE *f = fopen(stub.c_str(),"rb");
+      if (!f) return false;
+      int smer, nthreads;
+      if (fread(&smer,4,1,f) != 1 || fread(&nthreads,4,1,f) != 1) { fclose(f); return false; }
+      fclose(f);
+      prefix = dir+"/."+root+".";
+      index.clear(); nbase.clear(); nreads = 0;
+      for (int p = 0; p < nthreads; p++)
+        { std::string nm = prefix+"pidx."+std::to_string(p+1);
+          FILE *g = fopen(nm.c_str(),"rb");
+          if (!g) die("Profile part %s is misssing ?\n",nm.c_str());
+          int k; int64_t first, n;
+          if (fread(&k,4,1,g) != 1 || fread(&first,8,1,g) != 1 || fread(&n,8,1,g) != 1) die("Profile part %s is truncated\n",nm.c_str());
+          if (k != smer) die("Profile part %s does not have k-mer length matching stub ?\n",nm.c_str());
+          size_t o = index.size();
+          index.resize(o+(size_t)n);
+          if (n > 0 && fread(index.data()+o,8,(size_t)n,g) != (size_t)n) die("Profile part %s is truncated\n",nm.c_str());
+          fclose(g);
+          nreads += n;
+          nbase.push_back(nreads);
+        }
+      kmer = smer; nparts = nthreads;
+      return true;
+    }
+    // code string of read `id`
+    void fetch(int64_t id, const uint8_t **code, int64_t *len)
+    { int w = 0;
+      while (w < nparts && id >= nbase[w]) w++;
+      if (w >= nparts) die("Id %lld is out of range [1,%lld]\n",(long long)id,(long long)nbase[nparts-1]);
+      if (w != cpart)
+        { std::string nm = prefix+"prof."+std::to_string(w+1);
+          FILE *f = fopen(nm.c_str(),"rb");
+          if (!f) die("Profile part %s is misssing ?\n",nm.c_str());
+          fseek(f,0,SEEK_END); long sz = ftell(f); fseek(f,0,SEEK_SET);
+          data.resize((size_t)sz);
+          if (sz > 0 && fread(data.data(),1,(size_t)sz,f) != (size_t)sz) die("Cannot read %s\n",nm.c_str());
+          fclose(f);
+          cpart = w;
+        }
+      int64_t first = (w == 0) ? 0 : nbase[w-1];
+      int64_t off = (id == first) ? 0 : index[(size_t)id-1];
+      *code = data.data()+off;
+      *len = index[(size_t)id]-off;
+    }
+  };
+
+static bool load_hist(const std::string &fk_root, int *low, int *high, int64_t *ilow, int64_t *ihigh, std::vector<int64_t> &h)
+{ std::string full = path_to(fk_root)+"/"+root_of(fk_root,".hist")+".hist";
+  FILE *f = fopen(full.c_str(),"rb");
+  if (!f) return false;
+  int kmer;
+  bool ok = fread(&kmer,4,1,f) == 1 && fread(low,4,1,f) == 1 && fread(high,4,1,f) == 1
+            && fread(ilow,8,1,f) == 1 && fread(ihigh,8,1,f) == 1;
+  if (ok)
+    { h.resize((size_t)(*high-*low)+1);
+      ok = fread(h.data(),8,h.size(),f) == h.size();
+    }
+  fclose(f);
+  return ok;
+}
+
+// ---- one batch in flight ----------------------------------------------------------------------------
+struct Batch
+  { char *h_seq = nullptr, *h_lab = nullptr; uint16_t *h_prof = nullptr; int64_t *h_soff = nullptr, *h_poff = nullptr;
+    char *d_seq = nullptr, *d_lab = nullptr; uint16_t *d_prof = nullptr; int64_t *d_soff = nullptr, *d_poff = nullptr;
+    size_t cap_bases = 0, cap_reads = 0;
+    int n = 0; int64_t bases = 0, kmers = 0;
+    std::vector<std::string> headers;            // every record of the batch, in order (short reads included)
+    std::vector<int> slot;                       // record -> index among classified reads, or -1 (short read)
+    std::vector<std::string> short_seq;
+    hipStream_t st = nullptr;
+    cp_workspace *ws = nullptr;
+    void alloc(size_t bases_cap, size_t reads_cap)
+    { cap_bases = bases_cap; cap_reads = reads_cap;
+      HIPOK(hipHostMalloc((void **)&h_seq,bases_cap)); HIPOK(hipHostMalloc((void **)&h_lab,bases_cap));
+      HIPOK(hipHostMalloc((void **)&h_prof,bases_cap*2));
+      HIPOK(hipHostMalloc((void **)&h_soff,(reads_cap+1)*8)); HIPOK(hipHostMalloc((void **)&h_poff,(reads_cap+1)*8));
+      HIPOK(hipMalloc((void **)&d_seq,bases_cap)); HIPOK(hipMalloc((void **)&d_lab,bases_cap));
+      HIPOK(hipMalloc((void **)&d_prof,bases_cap*2));
+      HIPOK(hipMalloc((void **)&d_soff,(reads_cap+1)*8)); HIPOK(hipMalloc((void **)&d_poff,(reads_cap+1)*8));
+      HIPOK(hipStreamCreate(&st));
+      CPOK(cp_workspace_create(&ws));
+    }
+    void reset() { n = 0; bases = kmers = 0; headers.clear(); slot.clear(); short_seq.clear(); }
+  };
+
+int main(int argc, char **argv)
+{ auto t_start = std::chrono::steady_clock::now();
+  bool verbose = false, seeds = false;
+  int nthreads = 4, cov = 0, rlen_opt = 20000;
+  std::string tmp_path = "./", fk_root, model_path, source;
+  std::vector<std::string> pos;
+  for (int i = 1; i < argc; i++)
+    { const char *a = argv[i];
+      if (a[0] == '-')
+        switch (a[1])
+        { default:
+            for (int k = 1; a[k]; k++)
+              { if (a[k] == 'v') verbose = true;
+                else if (a[k] == 's') seeds = true;
+                else die("%s: -%c is an illegal option\n",PROG,a[k]);
+              }
+            break;
+          case 'T': nthreads = arg_int(a,"Number of threads",true); break;
+          case 'c': cov = arg_int(a,"Estimated k-mer coverage",false); break;
+          case 'r': rlen_opt = arg_int(a,"Average read length",true); break;
+          case 'N': fk_root = a+2; break;
+          case 'P': tmp_path = a+2; break;
+          case 'M': model_path = a+2; break;
+        }
+      else
+        pos.push_back(a);
+    }
+  (void)nthreads;
+  if (pos.empty())
+    die("Usage: %s %s\n",PROG,USAGE);
+  if (verbose) fprintf(stderr,"Info about inputs:\n");
+
+  std::string path = path_to(pos[0]), root;
+  int idx;
+  for (idx = 0; idx < 10; idx++)
+    { root = root_of(pos[0],EXT[idx]);
+      int fd = open((path+"/"+root+EXT[idx]).c_str(),O_RDONLY);
+      if (fd >= 0) { close(fd); break; }
+    }
+  if (idx == 10)
+    die("Cannot open %s as a .db|.dam or .f{ast}[aq][.gz] file\n",pos[0].c_str());
+  if (pos.size() != 1)
+    die(idx <= 1 ? "Only single file is accepted for .db and .dam\n" : "Currently only single file is accepted for FASTX input\n");
+  if (idx <= 1)
+    die("%s: .db/.dam inputs are not supported by this build (FASTX only)\n",PROG);
+  if (seeds)
+    die("%s: -s requires a .db/.dam input, which this build does not support\n",PROG);
+  if (!model_path.empty())
+    die("%s: -M error-model files are not supported by this build\n",PROG);
+  if (fk_root.empty()) fk_root = path+"/"+root;
+  source = path+"/"+root+EXT[idx];
+  const std::string out_path = path+"/"+root+".class";
+  if (verbose)
+    { fprintf(stderr,"    # of sequence files   = %d\n",1);
+      fprintf(stderr,"    First (path,root,ext) = (%s, %s, %s)\n",path.c_str(),root.c_str(),EXT[idx]);
+      fprintf(stderr,"    FASTK outputs' root   = %s\n",fk_root.c_str());
+      fprintf(stderr,"    Output .class file    = %s/%s.class\n",path.c_str(),root.c_str());
+    }
+  { std::string tp = tmp_path;                                            // ClassPro.c:466-498
+    if (tp[0] != '/')
+      { char *cwd = getcwd(NULL,0);
+        if (tp[0] == '.')
+          { if (tp.size() > 1 && tp[1] == '/') tp = std::string(cwd)+tp.substr(1);
+            else if (tp.size() == 1) tp = cwd;
+            else die("\n%s: -P option: . not followed by /\n",PROG);
+          }
+        else tp = std::string(cwd)+"/"+tp;
+        free(cwd);
+      }
+    DIR *d = opendir(tp.c_str());
+    if (!d) die("\n%s: -P option: cannot open directory %s\n",PROG,tp.c_str());
+    closedir(d);
+    if (verbose) fprintf(stderr,"    Temp dir path         = %s\n",tp.c_str());
+  }
+
+  Profiles P;
+  if (!P.open(fk_root))
+    die("%s: Cannot open %s.prof\n",PROG,fk_root.c_str());
+  const int K = P.kmer, Km1 = K-1;
+  if (verbose)
+    fprintf(stderr,"    Total # of reads      = %lld\n",(long long)P.nreads);
+
+  int hcov, dcov;                                                          // ClassPro.c:536-554
+  { int low = 0, high = 0; int64_t il = 0, ih = 0;
+    std::vector<int64_t> h;
+    if (!load_hist(fk_root,&low,&high,&il,&ih,h))
+      die("%s: Cannot open %s.hist\n",PROG,fk_root.c_str());
+    if (verbose) fprintf(stderr,"Global histogram inspection:\n");
+    CPOK(cp_hist_covs(h.data(),low,high,il,ih,cov,&hcov,&dcov));
+    if (verbose)
+      fprintf(stderr,cov > 0 ? "    Specified (H,D) cov   = (%d,%d)\n" : "    Estimated (H,D) cov   = (%d,%d)\n",hcov,dcov);
+  }
+  cp_params *params;
+  CPOK(cp_params_create(K,rlen_opt,hcov,dcov,&params));
+  { int c4[4];
+    cp_params_export(params,c4,NULL,NULL,NULL,NULL,NULL,NULL);
+    if (verbose)
+      { fprintf(stderr,"    Estimated R-threshold = %d\n",c4[CP_REPEAT]);
+        fprintf(stderr,"Error model not specified. Using the default error model.\n");
+        fprintf(stderr,"Classifying %d-mers...\n",K);
+      }
+  }
+
+  FastxReader fx(source.c_str());
+  if (!fx.f) die("%s: Cannot open %s\n",PROG,source.c_str());
+  FILE *out = fopen(out_path.c_str(),"w");
+  if (!out) die("Cannot open %s\n",out_path.c_str());
+  std::vector<char> obuf(1 << 22);
+  setvbuf(out,obuf.data(),_IOFBF,obuf.size());
+
+  const size_t BATCH_BASES = (size_t)256 << 20, BATCH_READS = 1 << 17;
+  Batch B[2];
+  B[0].alloc(BATCH_BASES+CP_MAX_READ_LEN,BATCH_READS);
+  B[1].alloc(BATCH_BASES+CP_MAX_READ_LEN,BATCH_READS);
+  std::vector<uint16_t> tmp_prof(CP_MAX_READ_LEN);
+
+  int64_t id = 0, total_bases = 0;
+  bool more = true;
+  auto stage = [&](Batch &b)                       // fill one batch from the input; false when nothing was read
+    { b.reset();
+      b.h_soff[0] = b.h_poff[0] = 0;
+      while (more && (size_t)b.bases < BATCH_BASES && (size_t)b.n < BATCH_READS)
+        { if (id >= P.nreads) { more = false; break; }
+          int rlen = fx.next();
+          if (rlen < 0)
+            die("Cannot load %lld-th read\n",(long long)id+1);
+          if (rlen > CP_MAX_READ_LEN)
+            die("rlen (%d) > MAX_READ_LEN for FASTX inputs (%d)\n",rlen,CP_MAX_READ_LEN);
+          // header "@name comment": kseq keeps the previous comment when a record has none (ClassPro.c:188)
+          b.headers.push_back("@"+fx.name+" "+(fx.have_comment ? fx.comment : std::string("(null)")));
+          const uint8_t *code; int64_t clen;
+          P.fetch(id,&code,&clen);
+          if (rlen <= Km1)                            // ClassPro.c:209-226: printed by the host, not classified
+            { b.slot.push_back(-1);
+              b.short_seq.push_back(fx.seq);
+              id++;
+              continue;
+            }
+          int plen = cp_decode_profile(code,clen,b.h_prof+b.kmers,CP_MAX_READ_LEN);
+          if (plen < 0) die("%s\n",cp_last_error());
+          if (rlen != plen+Km1)
+            die("Read %lld: rlen (%d) != plen+Km1 (%d)\n",(long long)id+1,rlen,plen+Km1);
+          memcpy(b.h_seq+b.bases,fx.seq.data(),(size_t)rlen);
+          b.slot.push_back(b.n);
+          b.bases += rlen; b.kmers += plen; b.n++;
+          b.h_soff[b.n] = b.bases; b.h_poff[b.n] = b.kmers;
+          id++;
+        }
+      if (id >= P.nreads) more = false;
+      return !b.headers.empty();
+    };
+  auto submit = [&](Batch &b)
+    { if (b.n == 0) return;
+      HIPOK(hipMemcpyAsync(b.d_seq,b.h_seq,(size_t)b.bases,hipMemcpyHostToDevice,b.st));
+      HIPOK(hipMemcpyAsync(b.d_prof,b.h_prof,(size_t)b.kmers*2,hipMemcpyHostToDevice,b.st));
+      HIPOK(hipMemcpyAsync(b.d_soff,b.h_soff,(size_t)(b.n+1)*8,hipMemcpyHostToDevice,b.st));
+      HIPOK(hipMemcpyAsync(b.d_poff,b.h_poff,(size_t)(b.n+1)*8,hipMemcpyHostToDevice,b.st));
+      CPOK(cp_classify_batch(params,b.ws,b.d_seq,b.d_soff,b.d_prof,b.d_poff,b.n,b.bases,b.kmers,b.d_lab,b.st));
+      HIPOK(hipMemcpyAsync(b.h_lab,b.d_lab,(size_t)b.bases,hipMemcpyDeviceToHost,b.st));
+    };
+  auto finish = [&](Batch &b)
+    { if (b.n > 0)
+        { HIPOK(hipStreamSynchronize(b.st));
+          CPOK(cp_workspace_check(b.ws));
+        }
+      size_t si = 0;
+      for (size_t r = 0; r < b.headers.size(); r++)              // ClassPro.c:215,289
+        { fputs(b.headers[r].c_str(),out); fputc('\n',out);
+          if (b.slot[r] < 0)
+            { const std::string &s = b.short_seq[si++];
+              fwrite(s.data(),1,s.size(),out); fputs("\n+\n",out);
+              for (size_t k = 0; k < s.size(); k++) fputc('N',out);
+              fputc('\n',out);
+            }
+          else
+            { int i = b.slot[r];
+              size_t o = (size_t)b.h_soff[i], l = (size_t)(b.h_soff[i+1]-b.h_soff[i]);
+              fwrite(b.h_seq+o,1,l,out); fputs("\n+\n",out);
+              fwrite(b.h_lab+o,1,l,out); fputc('\n',out);
+            }
+        }
+      total_bases += b.bases;
+    };
+
+  int cur = 0;
+  bool have = stage(B[cur]);
+  while (have)
+    { submit(B[cur]);
+      bool have_next = more ? stage(B[cur^1]) : false;       // host stages the next batch while the GPU works
+      finish(B[cur]);
+      cur ^= 1;
+      have = have_next;
+    }
+  fclose(out);
+
+  if (verbose)
+    { double s = std::chrono::duration<double>(std::chrono::steady_clock::now()-t_start).count();
+      fprintf(stderr,"\nResources for phase:  %.3f (s) wall, %.1f Mbases classified (%.1f Mbases/s end to end)\n",
+              s,total_bases/1e6,total_bases/1e6/s);
+    }
+  cp_params_destroy(params);
+  return 0;
+}

@@ -207,3 +207,50 @@ def test_scale_properties(torch_dev):
     bad = int((lab[:so[m]] != want).sum())
     assert bad <= 1e-6 * so[m], "%d mismatching positions of %d" % (bad, so[m])
     clf.close()
+
+
+def test_cli_drop_in(torch_dev, tmp_path):
+    """The ClassPro-compatible binary: FASTA(.gz) + FASTK .hist/.prof in, .class out, byte-identical
+    to the records the reference writes (ClassPro.c:188,289) with labels from the oracle."""
+    import os
+    import subprocess
+    from classpro_amd import synth, fastk, build
+    from classpro_amd.api import hist_covs
+    from oracle.oracle import Oracle
+    ds = synth.make_dataset(genome_len=150000, cov=40, read_len=9000, seed=77)
+    seqs, profs, names = list(ds["seqs"]), list(ds["profiles"]), list(ds["names"])
+    # a read shorter than K (printed by the host, ClassPro.c:209-226) and kseq's stale-comment quirk
+    seqs.insert(5, b"ACGTACGTAC"); profs.insert(5, np.zeros(0, np.uint16)); names.insert(5, "tiny")
+    comments = [None] * len(seqs)
+    comments[3] = "first comment"
+    comments[10] = "second one"
+    d = str(tmp_path)
+    with open(os.path.join(d, "reads.fasta"), "wb") as f:
+        for n, s, c in zip(names, seqs, comments):
+            f.write(b">" + n.encode() + ((b" " + c.encode()) if c else b"") + b"\n")
+            for o in range(0, len(s), 70):                  # multi-line FASTA
+                f.write(s[o:o + 70] + b"\n")
+    subprocess.check_call(["gzip", "-k", os.path.join(d, "reads.fasta")])
+    os.remove(os.path.join(d, "reads.fasta"))
+    fastk.write_fastk(d, "reads", K, profs, ds["hist"], nparts=3)
+    low, high, il, ih, h = ds["hist"]
+    hc, dc = hist_covs(h, low, high, il, ih, 0)
+    cli = os.path.join(os.path.dirname(build.OUT), "ClassPro")
+    r = subprocess.run([cli, "-v", "-T4", "-P" + d, os.path.join(d, "reads.fasta.gz")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Estimated (H,D) cov   = (%d,%d)" % (hc, dc) in r.stderr
+    got = open(os.path.join(d, "reads.class"), "rb").read()
+    O = Oracle(K, 20000, hc, dc)
+    exp = []
+    last = "(null)"
+    for n, s, p, c in zip(names, seqs, profs, comments):
+        if c:
+            last = c
+        lab = O.classify_read(s, p) if len(s) >= K else b"N" * len(s)
+        exp.append(b"@" + n.encode() + b" " + last.encode() + b"\n" + s + b"\n+\n" + lab + b"\n")
+    assert got == b"".join(exp)
+    # -c overrides the histogram; error contract: message + exit code 1
+    r = subprocess.run([cli, "-c40", os.path.join(d, "reads")], capture_output=True, text=True)
+    assert r.returncode == 0
+    r = subprocess.run([cli, os.path.join(d, "missing.fa")], capture_output=True, text=True)
+    assert r.returncode == 1 and "Cannot open" in r.stderr
