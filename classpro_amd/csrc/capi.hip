@@ -95,8 +95,8 @@ extern "C" int cp_decode_profile(const uint8_t *code, int64_t len, uint16_t *pro
 struct dbuf { void *p; size_t cap; };
 
 struct cp_workspace
-  { dbuf bitmap, ncand, nintvl, nrel, ioff, eoff, hoff, wall, hkeys, hvals, eintvl, ointvl, intvl, rintvl,
-         relmap, parent, eff, rpos, asgn, ord, err, memo_val, memo_key;
+  { dbuf bitmap, ncand, nintvl, nrel, ioff, eoff, hoff, wall, wall_s, hkeys, hvals, eintvl, ointvl, intvl, rintvl,
+         relmap, parent, eff, rpos, asgn, ord, err, memo_val, memo_key, perm;
     int64_t *h_totals;        // pinned: [totalI, totalE, totalH]
     int32_t *h_err;           // pinned
     // shape of the last run
@@ -142,9 +142,9 @@ extern "C" int cp_workspace_create(cp_workspace **out)
 
 extern "C" void cp_workspace_destroy(cp_workspace *ws)
 { if (!ws) return;
-  dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->hkeys,&ws->hvals,
+  dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
                   &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
-                  &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key };
+                  &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm };
   for (dbuf *b : all) if (b->p) (void)hipFree(b->p);
   if (ws->aux) (void)hipStreamDestroy(ws->aux);
   if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
@@ -156,9 +156,9 @@ extern "C" void cp_workspace_destroy(cp_workspace *ws)
 
 extern "C" size_t cp_workspace_bytes(const cp_workspace *ws)
 { if (!ws) return 0;
-  const dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->hkeys,&ws->hvals,
+  const dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
                         &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
-                        &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key };
+                        &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm };
   size_t s = 0;
   for (const dbuf *b : all) s += b->cap;
   return s;
@@ -169,7 +169,7 @@ static int scan_grid(int64_t total)
 { int64_t groups = total >> 3;
   int64_t blocks = (groups+256*SCAN_UNROLL-1)/(256*SCAN_UNROLL);
   if (blocks < 1) blocks = 1;
-  if (blocks > 256*8) blocks = 256*8;               // 8 blocks per CU, grid-stride beyond that
+  if (blocks > 256*SCAN_BLOCKS_PER_CU) blocks = 256*SCAN_BLOCKS_PER_CU;   // grid-stride beyond that
   return (int)blocks;
 }
 
@@ -246,19 +246,24 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   // ---- stage 2: find_wall ----------------------------------------------------------------------
   const int64_t ncell = total_kmers+nreads;
   ENSURE(ws->wall,ncell);
+  ENSURE(ws->wall_s,ncell);
   ENSURE(ws->hkeys,(size_t)totalH*4);
   ENSURE(ws->hvals,(size_t)totalH*4*8);
   ENSURE(ws->eintvl,(size_t)totalE*sizeof(cp_eintvl));
   ENSURE(ws->ointvl,(size_t)totalE*sizeof(cp_eintvl));
   ENSURE(ws->intvl,(size_t)totalI*sizeof(cp_intvl));
   HIPCHK(hipMemsetAsync(ws->wall.p,0,(size_t)ncell,st));
+  HIPCHK(hipMemsetAsync(ws->wall_s.p,0,(size_t)ncell,st));
   HIPCHK(hipMemsetAsync(ws->hkeys.p,0xff,(size_t)totalH*4,st));       // every slot empty (key -1)
+  ENSURE(ws->perm,(size_t)nreads*4);
+  // longest reads first: key = wall candidates / 4 (bins of 4 up to 4096 candidates)
+  hipLaunchKernelGGL(k_order_by_work,dim3(1),dim3(1024),0,st,(const int32_t *)ws->ncand.p,nreads,2,(int32_t *)ws->perm.p);
   hipLaunchKernelGGL(k_find_wall,dim3(nreads),dim3(WAVE),0,st,
                      p->dev,d_seq,d_seq_off,d_prof,d_prof_off,nreads,(const uint64_t *)ws->bitmap.p,
-                     (uint8_t *)ws->wall.p,(int32_t *)ws->hkeys.p,(double *)ws->hvals.p,(const int64_t *)ws->hoff.p,
+                     (uint8_t *)ws->wall.p,(uint8_t *)ws->wall_s.p,(int32_t *)ws->hkeys.p,(double *)ws->hvals.p,(const int64_t *)ws->hoff.p,
                      (cp_eintvl *)ws->eintvl.p,(cp_eintvl *)ws->ointvl.p,
                      (const int64_t *)ws->eoff.p,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,
-                     (int32_t *)ws->nintvl.p,(int32_t *)ws->err.p);
+                     (int32_t *)ws->nintvl.p,(int32_t *)ws->err.p,(const int32_t *)ws->perm.p);
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_WALL)
     return CP_OK;
@@ -284,17 +289,18 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->parent.p,(int32_t *)ws->eff.p,
                      (uint8_t *)ws->rpos.p,(int8_t *)ws->asgn.p,totalI);
   // size classes: M <= 128 two reads per wave, 128 < M <= 1024 one read per wave, larger: sequential kernel above
+  hipLaunchKernelGGL(k_order_by_work,dim3(1),dim3(1024),0,st,(const int32_t *)ws->nrel.p,nreads,0,(int32_t *)ws->perm.p);
   // (the classes touch disjoint reads; the long-read class is a handful of latency-bound waves, so it
   //  runs beside the main class on the auxiliary stream)
   HIPCHK(hipEventRecord(ws->ev_fork,st));
   HIPCHK(hipStreamWaitEvent(ws->aux,ws->ev_fork,0));
   hipLaunchKernelGGL((k_classify_rel_grp<128,1024,1>),dim3(nreads),dim3(WAVE),0,ws->aux,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
-                     (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI);
+                     (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI,(const int32_t *)ws->perm.p);
   HIPCHK(hipEventRecord(ws->ev_join,ws->aux));
   hipLaunchKernelGGL((k_classify_rel_grp<0,128,2>),dim3((nreads+1)/2),dim3(WAVE),0,st,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
-                     (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI);
+                     (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI,(const int32_t *)ws->perm.p);
   HIPCHK(hipStreamWaitEvent(st,ws->ev_join,0));
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_CLASS_REL)
@@ -308,15 +314,16 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   // size classes: N <= 256 eight reads per wave, 256 < N <= 1024 two reads per wave, larger: sequential kernel above
   ENSURE(ws->memo_val,(size_t)totalI*8*8);
   ENSURE(ws->memo_key,(size_t)totalI*8*4);
+  hipLaunchKernelGGL(k_order_by_work,dim3(1),dim3(1024),0,st,(const int32_t *)ws->nintvl.p,nreads,0,(int32_t *)ws->perm.p);
   HIPCHK(hipEventRecord(ws->ev_fork,st));
   HIPCHK(hipStreamWaitEvent(ws->aux,ws->ev_fork,0));
   hipLaunchKernelGGL((k_classify_unrel_grp<256,1024,2>),dim3((nreads+1)/2),dim3(WAVE),0,ws->aux,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
-                     (double *)ws->memo_val.p,(int32_t *)ws->memo_key.p);
+                     (double *)ws->memo_val.p,(int32_t *)ws->memo_key.p,(const int32_t *)ws->perm.p);
   HIPCHK(hipEventRecord(ws->ev_join,ws->aux));
   hipLaunchKernelGGL((k_classify_unrel_grp<0,256,8>),dim3((nreads+7)/8),dim3(WAVE),0,st,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
-                     (double *)ws->memo_val.p,(int32_t *)ws->memo_key.p);
+                     (double *)ws->memo_val.p,(int32_t *)ws->memo_key.p,(const int32_t *)ws->perm.p);
   HIPCHK(hipStreamWaitEvent(st,ws->ev_join,0));
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_CLASS_ALL)

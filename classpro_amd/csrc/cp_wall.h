@@ -70,22 +70,23 @@ struct cp_read_t
     const uint16_t      *prof;
     const char          *seq;
     int                  plen, rlen;
-    uint8_t             *wall;
-    PE                   perror;
+    uint8_t             *wall;      // flags written by the OTHERS pass + PAIRED_M/ERROR (and everything, if shared)
+    uint8_t             *wall_s;    // flags written by the SELF pass (may alias `wall`: the bits are disjoint)
+    PE                   perror[2]; // memo per error type (may share storage: entries are keyed by etype too)
     cp_eintvl           *eintvl, *ointvl;
     int                  ecap;
     int                  eidx, oidx;
     int                  overflow;
   };
 
-#define CP_PERR(R,i,e,w) ((R)->perror.get(i,e,w))
+#define CP_PERR(R,i,e,w) ((R)->perror[e].get(i,e,w))
 #define CP_NEG_INF (-INFINITY)
 
 // wall.c:310-315
 template <class RD>
 CP_HD void cp_update_perror(RD *R, int i, int e, int w, int cout, int cin, double erate, double lpe, double l1mpe)
 { if (CP_PERR(R,i,e,w) == CP_NEG_INF)
-    R->perror.set(i,e,w,cp_p_errorin(R->P,e,erate,lpe,l1mpe,cout,cin));
+    R->perror[e].set(i,e,w,cp_p_errorin(R->P,e,erate,lpe,l1mpe,cout,cin));
 }
 
 // wall.c:317-322
@@ -187,9 +188,12 @@ CP_HD bool cp_find_pair(RD *R, int i, int cout, int cin, int e, int w, int t, in
 }
 
 // One iteration of the candidate walk, wall.c:590-707, for a position i that passed the scan
-// (min(c[i-1],c[i]) < R and |c[i-1]-c[i]| >= 3).
+// (min(c[i-1],c[i]) < R and |c[i-1]-c[i]| >= 3) and ONE error type e.  The SELF and OTHERS passes of
+// the reference's inner loop (:638-691) touch disjoint state -- different flag bits, different memo
+// entries, different interval lists -- and each depends only on its own earlier iterations, so the
+// device walks them on two lanes at once (with separate flag arrays and memo tables).
 template <class RD>
-CP_HD void cp_wall_candidate(RD *R, int i)
+CP_HD void cp_wall_candidate_e(RD *R, int i, int e)
 { const cp_dev_params *P = R->P;
   const int CMAX = P->cmax;
   const int cim1 = R->prof[i-1], ci = R->prof[i];
@@ -198,6 +202,9 @@ CP_HD void cp_wall_candidate(RD *R, int i)
   int wtype, cin, cout;
   if (cim1 > ci) { wtype = CP_DROP; cin = ci;   cout = cim1; }
   else           { wtype = CP_GAIN; cin = cim1; cout = ci;   }
+
+  if (e == CP_SELF ? (R->wall_s[i] & CP_W_PAIRED_S) : (R->wall[i] & CP_W_PAIRED_O))      // wall.c:639
+    return;
 
   int maxt = -1, maxl = -1;                              // wall.c:624-634
   double maxpe = CP_NEG_INF;
@@ -211,50 +218,52 @@ CP_HD void cp_wall_candidate(RD *R, int i)
   const double lpe = P->lpe[maxt][maxl], l1mpe = P->l1mpe[maxt][maxl];
 
   int ct_init = 0, ct_final = 0;
-  for (int e = CP_SELF; e <= CP_OTHERS; e++)            // wall.c:638-691
-    { if (R->wall[i] & (e == CP_SELF ? CP_W_PAIRED_S : CP_W_PAIRED_O))
-        continue;
-      if (cout < CMAX)
-        { ct_init  = P->cthres[maxt][maxl][cout][CP_INIT][e];
-          ct_final = P->cthres[maxt][maxl][cout][CP_FINAL][e];
-          if (!(cng > CP_MAX_CNT_CHANGE || cin < (ct_init > 3 ? ct_init : 3)))
-            continue;
-        }
-      if (e == CP_SELF)
-        { if (cout < CMAX && cin >= ct_final)
-            continue;
-          cp_update_perror(R,i,e,wtype,cout,cin,maxpe,lpe,l1mpe);
-          if (CP_PERR(R,i,e,wtype) < CP_PE_THRES_FINAL)
-            continue;
-          cp_eintvl I;
-          if (cp_find_pair(R,i,cout,cin,e,wtype,maxt,maxl,maxpe,lpe,l1mpe,&I) && I.pe >= CP_PE_THRES_FINAL)
-            { R->wall[I.b] |= (CP_W_WALL_S|CP_W_PAIRED_S);
-              R->wall[I.e] |= (CP_W_WALL_S|CP_W_PAIRED_S);
-              if (R->eidx < R->ecap) R->eintvl[R->eidx++] = I;
-              else R->overflow = 1;
-            }
-        }
-      else
-        { if (cng >= P->cov[CP_HAPLO] || (cout < CMAX && cin < ct_final))
-            { R->wall[i] |= CP_W_WALL_O;
-              continue;
-            }
-          cp_update_perror(R,i,e,wtype,cout,cin,maxpe,lpe,l1mpe);
-          if (CP_PERR(R,i,e,wtype) < CP_PE_THRES_FINAL)
-            { R->wall[i] |= CP_W_WALL_O;
-              continue;
-            }
-          cp_eintvl I;
-          if (cp_find_pair(R,i,cout,cin,e,wtype,maxt,maxl,maxpe,lpe,l1mpe,&I) && I.pe >= CP_PE_THRES_FINAL)
-            { R->wall[I.b] |= CP_W_PAIRED_O;
-              R->wall[I.e] |= CP_W_PAIRED_O;
-              if (R->oidx < R->ecap) R->ointvl[R->oidx++] = I;
-              else R->overflow = 1;
-              continue;
-            }
-          R->wall[i] |= CP_W_WALL_O;
+  if (cout < CMAX)                                       // wall.c:643-648
+    { ct_init  = P->cthres[maxt][maxl][cout][CP_INIT][e];
+      ct_final = P->cthres[maxt][maxl][cout][CP_FINAL][e];
+      if (!(cng > CP_MAX_CNT_CHANGE || cin < (ct_init > 3 ? ct_init : 3)))
+        return;
+    }
+  if (e == CP_SELF)                                      // wall.c:651-670
+    { if (cout < CMAX && cin >= ct_final)
+        return;
+      cp_update_perror(R,i,e,wtype,cout,cin,maxpe,lpe,l1mpe);
+      if (CP_PERR(R,i,e,wtype) < CP_PE_THRES_FINAL)
+        return;
+      cp_eintvl I;
+      if (cp_find_pair(R,i,cout,cin,e,wtype,maxt,maxl,maxpe,lpe,l1mpe,&I) && I.pe >= CP_PE_THRES_FINAL)
+        { R->wall_s[I.b] |= (CP_W_WALL_S|CP_W_PAIRED_S);
+          R->wall_s[I.e] |= (CP_W_WALL_S|CP_W_PAIRED_S);
+          if (R->eidx < R->ecap) R->eintvl[R->eidx++] = I;
+          else R->overflow = 1;
         }
     }
+  else                                                   // wall.c:671-690
+    { if (cng >= P->cov[CP_HAPLO] || (cout < CMAX && cin < ct_final))
+        { R->wall[i] |= CP_W_WALL_O;
+          return;
+        }
+      cp_update_perror(R,i,e,wtype,cout,cin,maxpe,lpe,l1mpe);
+      if (CP_PERR(R,i,e,wtype) < CP_PE_THRES_FINAL)
+        { R->wall[i] |= CP_W_WALL_O;
+          return;
+        }
+      cp_eintvl I;
+      if (cp_find_pair(R,i,cout,cin,e,wtype,maxt,maxl,maxpe,lpe,l1mpe,&I) && I.pe >= CP_PE_THRES_FINAL)
+        { R->wall[I.b] |= CP_W_PAIRED_O;
+          R->wall[I.e] |= CP_W_PAIRED_O;
+          if (R->oidx < R->ecap) R->ointvl[R->oidx++] = I;
+          else R->overflow = 1;
+          return;
+        }
+      R->wall[i] |= CP_W_WALL_O;
+    }
+}
+
+template <class RD>
+CP_HD void cp_wall_candidate(RD *R, int i)
+{ cp_wall_candidate_e(R,i,CP_SELF);
+  cp_wall_candidate_e(R,i,CP_OTHERS);
 }
 
 // wall.c:519-528: order by (b,e); the pe term truncates to 0, and glibc's qsort is a stable merge
@@ -303,6 +312,7 @@ CP_HD int cp_dedupe_sorted(cp_eintvl *v, int N)
 template <class RD>
 CP_HD void cp_wall_mult(RD *R, int i, int NS, int *midx)
 { uint8_t *wall = R->wall;
+  const uint8_t *wall_s = R->wall_s;
   const int plen = R->plen;
   cp_eintvl *ev = R->eintvl;
   double pe, pe_i, pe_j;
@@ -320,7 +330,7 @@ CP_HD void cp_wall_mult(RD *R, int i, int NS, int *midx)
                   wall[i] |= CP_W_PAIRED_M;
                   (*midx)++;
                 }
-              if (!(wall[j] & (CP_W_WALL_S|CP_W_WALL_O)))
+              if (!((wall[j] & CP_W_WALL_O) | (wall_s[j] & CP_W_WALL_S)))
                 continue;
               if (cp_bs_eintvl(ev,0,NS-1,i,j) == -1)
                 { pe_j = CP_PERR(R,j,CP_SELF,CP_GAIN);
@@ -347,7 +357,7 @@ CP_HD void cp_wall_mult(RD *R, int i, int NS, int *midx)
                   wall[i] |= CP_W_PAIRED_M;
                   (*midx)++;
                 }
-              if (!(wall[j] & (CP_W_WALL_S|CP_W_WALL_O)))
+              if (!((wall[j] & CP_W_WALL_O) | (wall_s[j] & CP_W_WALL_S)))
                 continue;
               if (cp_bs_eintvl(ev,0,NS-1,j,i) == -1)
                 { pe_j = CP_PERR(R,j,CP_SELF,CP_DROP);

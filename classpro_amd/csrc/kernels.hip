@@ -43,7 +43,17 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE-1); }
 //  first position of a read compare across a read boundary; consumers skip position 0.
 //  Algorithmic traffic: 2 B read + 1/8 B written per position.
 // ---------------------------------------------------------------------------------------------
+#ifdef SCAN_NT
+#define SCAN_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define SCAN_LOAD(p) (*(p))
+#endif
+#ifndef SCAN_UNROLL
 #define SCAN_UNROLL 4
+#endif
+#ifndef SCAN_BLOCKS_PER_CU
+#define SCAN_BLOCKS_PER_CU 8
+#endif
 
 __global__ void __launch_bounds__(256)
 k_scan_candidates(const uint16_t *__restrict__ prof, int64_t total, int rep, uint8_t *__restrict__ bitmap)
@@ -59,7 +69,7 @@ k_scan_candidates(const uint16_t *__restrict__ prof, int64_t total, int rep, uin
       for (int u = 0; u < SCAN_UNROLL; u++)
         { g[u] = base+(int64_t)u*blockDim.x+threadIdx.x;
           if (g[u] < ngroups)
-            v[u] = vp[g[u]];
+            v[u] = SCAN_LOAD(&vp[g[u]]);
           else
             v[u] = make_uint4(0,0,0,0);
         }
@@ -133,9 +143,9 @@ k_count_caps(const uint64_t *__restrict__ bm, const int64_t *__restrict__ prof_o
     { ncand[r] = cnt;
       icap[r]  = 2*(int64_t)cnt+4;
       ecap[r]  = 16*(int64_t)cnt+64;
-      int64_t h = 32;                                   // perror table: power of two >= 4*ncand+16
+      int64_t h = 32;                                   // perror tables (one per error type): power of two >= 4*ncand+16
       while (h < 4*(int64_t)cnt+16) h <<= 1;
-      hcap[r] = h;
+      hcap[r] = 2*h;
     }
 }
 
@@ -165,6 +175,40 @@ k_prefix_caps(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__restr
     { int64_t ya = a[i], yb = b[i], yc = c[i];
       a[i] = xa; b[i] = xb; c[i] = xc;
       xa += ya; xb += yb; xc += yc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+//  k_order_by_work: perm[] = read ids sorted by a work key (candidates / intervals / reliable
+//  intervals), largest first.  The per-read kernels are latency-bound chains whose length grows with
+//  the key: launching long reads first removes the tail, and reads that share a wave (rel: 2,
+//  unrel: 8) get similar trip counts.  Counting sort in one block: LDS histogram, suffix sums, scatter
+//  (order inside a bin is arbitrary; reads are independent, so results do not depend on it).
+// ---------------------------------------------------------------------------------------------
+#define ORDER_BINS 1024
+__global__ void __launch_bounds__(1024)
+k_order_by_work(const int32_t *__restrict__ key, int n, int shift, int32_t *__restrict__ perm)
+{ __shared__ int hist[ORDER_BINS];
+  __shared__ int start[ORDER_BINS];
+  const int t = threadIdx.x;
+  hist[t] = 0;
+  __syncthreads();
+  for (int i = t; i < n; i += 1024)
+    { int b = key[i] >> shift;
+      atomicAdd(&hist[b < ORDER_BINS ? b : ORDER_BINS-1],1);
+    }
+  __syncthreads();
+  if (t == 0)
+    { int acc = 0;
+      for (int b = ORDER_BINS-1; b >= 0; b--)              // descending keys
+        { start[b] = acc;
+          acc += hist[b];
+        }
+    }
+  __syncthreads();
+  for (int i = t; i < n; i += 1024)
+    { int b = key[i] >> shift;
+      perm[atomicAdd(&start[b < ORDER_BINS ? b : ORDER_BINS-1],1)] = i;
     }
 }
 
@@ -199,13 +243,13 @@ __device__ __forceinline__ void wave_wall_or(uint8_t *wall, int b, int e, uint8_
 __global__ void __launch_bounds__(WAVE)
 k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, const int64_t *__restrict__ seq_off,
             const uint16_t *__restrict__ prof, const int64_t *__restrict__ prof_off, int nreads,
-            const uint64_t *__restrict__ bm, uint8_t *__restrict__ wall_all,
+            const uint64_t *__restrict__ bm, uint8_t *__restrict__ wall_all, uint8_t *__restrict__ walls_all,
             int32_t *__restrict__ hkeys, double *__restrict__ hvals, const int64_t *__restrict__ hoff,
             cp_eintvl *__restrict__ eintvl_all, cp_eintvl *__restrict__ ointvl_all, const int64_t *__restrict__ eoff,
             cp_intvl *__restrict__ intvl_all, const int64_t *__restrict__ ioff,
-            int32_t *__restrict__ nintvl, int32_t *__restrict__ err)
-{ const int r = blockIdx.x;
-  if (r >= nreads) return;
+            int32_t *__restrict__ nintvl, int32_t *__restrict__ err, const int32_t *__restrict__ perm)
+{ if ((int)blockIdx.x >= nreads) return;
+  const int r = perm[blockIdx.x];
   const int lane = lane_id();
   const int64_t po = prof_off[r];
   const int plen = (int)(prof_off[r+1]-po);
@@ -214,9 +258,14 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   cp_read_t<cp_perr_hash> R;
   R.P = P; R.prof = prof+po; R.seq = seq+seq_off[r]; R.plen = plen; R.rlen = rlen;
   R.wall = wall_all+po+r;
-  R.perror.keys = hkeys+hoff[r];
-  R.perror.vals = hvals+hoff[r]*4;
-  R.perror.mask = (uint32_t)(hoff[r+1]-hoff[r])-1;
+  R.wall_s = walls_all+po+r;
+  { const int64_t ho = hoff[r], hc = (hoff[r+1]-ho) >> 1;     // two tables, one per error type
+    for (int e = 0; e < 2; e++)
+      { R.perror[e].keys = hkeys+ho+e*hc;
+        R.perror[e].vals = hvals+(ho+e*hc)*4;
+        R.perror[e].mask = (uint32_t)hc-1;
+      }
+  }
   R.eintvl = eintvl_all+eoff[r];
   R.ointvl = ointvl_all+eoff[r];
   R.ecap = (int)(eoff[r+1]-eoff[r]);
@@ -224,22 +273,31 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   cp_intvl *intvl = intvl_all+ioff[r];
   const int icap = (int)(ioff[r+1]-ioff[r]);
   uint8_t *wall = R.wall;
+  const uint8_t *wall_s = R.wall_s;
 
-  // ---- candidate walk (wall.c:590-707): order-dependent, one lane -------------------------
-  if (lane == 0 && plen > 1)
+  // ---- candidate walk (wall.c:590-707): order-dependent; the SELF pass on lane 0 and the OTHERS
+  //      pass on lane 1 (disjoint state: own flag array, own memo table, own interval list) -------
+  if (lane < 2 && plen > 1)
     { const int64_t lo = po+1, hi = po+plen;
       for (int64_t w = lo >> 6; w <= ((hi-1) >> 6); w++)
         { uint64_t bits = bitmap_word(bm,w,lo,hi);
           while (bits)
             { int k = __ffsll((long long)bits)-1;
               bits &= bits-1;
-              cp_wall_candidate(&R,(int)((w << 6)+k-po));
+              cp_wall_candidate_e(&R,(int)((w << 6)+k-po),lane);
             }
         }
     }
-  int NS = __shfl(R.eidx,0), NO = __shfl(R.oidx,0);
-  int overflow = __shfl(R.overflow,0);
+#if defined(CP_K2_STOP) && CP_K2_STOP == 0
+  if (plen >= 0) return;
+#endif
+  int NS = __shfl(R.eidx,0), NO = __shfl(R.oidx,1);
+  int overflow = __shfl(R.overflow,0) | __shfl(R.overflow,1);
+  R.eidx = NS; R.oidx = NO;
   wave_sync();
+#if defined(CP_K2_STOP) && CP_K2_STOP == 1
+  if (plen >= 0) { if (lane == 0) nintvl[r] = 0; return; }
+#endif
 
   // ---- un-wall positions explained by O-pairs / inside E-intervals (wall.c:722-731) --------
   if (lane == 0)
@@ -265,8 +323,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
     { int i = base+lane;
       bool cand = false;
       if (i < plen)
-        { uint8_t wv = wall[i];
-          cand = (wv & CP_W_WALL_O) && !(wv & CP_W_WALL_S);
+        { cand = (wall[i] & CP_W_WALL_O) && !(wall_s[i] & CP_W_WALL_S);
         }
       uint64_t mask = __ballot(cand);
       if (mask && lane == 0)
@@ -301,6 +358,9 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
     wave_wall_or(wall,R.eintvl[k].b,R.eintvl[k].e,CP_W_ERROR);
   wave_sync();
 
+#if defined(CP_K2_STOP) && CP_K2_STOP == 2
+  if (plen >= 0) { if (lane == 0) nintvl[r] = 0; return; }
+#endif
   // ---- emit intervals at error transitions and O-walls (wall.c:922-948) ----------------------
   int N = 0, prev_b = 0;
   for (int base = 1; base <= plen; base += WAVE)
@@ -697,12 +757,13 @@ __global__ void __launch_bounds__(WAVE)
 k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ prof_off, int nreads,
                    cp_intvl *__restrict__ intvl_all, cp_intvl *__restrict__ rintvl_all, const int32_t *__restrict__ relmap_all,
                    const int64_t *__restrict__ ioff, const int32_t *__restrict__ nrel,
-                   int8_t *__restrict__ asgn_all, int64_t totalI)
+                   int8_t *__restrict__ asgn_all, int64_t totalI, const int32_t *__restrict__ perm)
 { __shared__ rel_grp_lds<MAXM,G> S;
   constexpr int L = WAVE/G;
   const int lane = lane_id();
   const int g = lane/L, ql = lane%L;
-  const int r = blockIdx.x*G+g;
+  const int slot = blockIdx.x*G+g;
+  const int r = (slot < nreads) ? perm[slot] : nreads;
   int M = (r < nreads) ? nrel[r] : 0;
   if (M <= MINM || M > MAXM) M = 0;                        // other size classes / sequential kernel
   if (__ballot(M > 0) == 0) return;
@@ -819,13 +880,14 @@ template <int MINN, int MAXN, int G>
 __global__ void __launch_bounds__(WAVE)
 k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__restrict__ intvl_all,
                      const int64_t *__restrict__ ioff, const int32_t *__restrict__ nintvl,
-                     double *__restrict__ memo_val, int32_t *__restrict__ memo_key)
+                     double *__restrict__ memo_val, int32_t *__restrict__ memo_key, const int32_t *__restrict__ perm)
 { __shared__ unrel_grp_lds<MAXN,G> S;
   constexpr int L = WAVE/G;
   static_assert(L >= 8 && (L % 8) == 0, "8 role lanes per read");
   const int lane = lane_id();
   const int g = lane/L, ql = lane%L, gbase = g*L;
-  const int r = blockIdx.x*G+g;
+  const int slot = blockIdx.x*G+g;
+  const int r = (slot < nreads) ? perm[slot] : nreads;
   int N = (r < nreads) ? nintvl[r] : 0;
   if (N <= MINN || N > MAXN) N = 0;                        // other size classes / sequential kernel
   if (__ballot(N > 0) == 0) return;
