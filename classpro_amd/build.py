@@ -29,7 +29,7 @@ def build(force=False, verbose=False):
             and min(os.path.getmtime(OUT), os.path.getmtime(CLI)) >= _newest_src()):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + os.environ.get("CP_EXTRA_FLAGS", "").split() + [os.path.join(CSRC, "capi.hip"), "-o", OUT]
+    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, "capi.hip"), "-o", OUT]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -96,7 +96,7 @@ struct dbuf { void *p; size_t cap; };
 
 struct cp_workspace
   { dbuf bitmap, ncand, nintvl, nrel, ioff, eoff, hoff, wall, wall_s, hkeys, hvals, eintvl, ointvl, intvl, rintvl,
-         relmap, parent, eff, rpos, asgn, ord, err, memo_val, memo_key, perm;
+         relmap, parent, eff, rpos, asgn, ord, err, memo_val, memo_key, perm, wlist;
     int64_t *h_totals;        // pinned: [totalI, totalE, totalH]
     int32_t *h_err;           // pinned
     // shape of the last run
@@ -144,7 +144,7 @@ extern "C" void cp_workspace_destroy(cp_workspace *ws)
 { if (!ws) return;
   dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
                   &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
-                  &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm };
+                  &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist };
   for (dbuf *b : all) if (b->p) (void)hipFree(b->p);
   if (ws->aux) (void)hipStreamDestroy(ws->aux);
   if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
@@ -158,7 +158,7 @@ extern "C" size_t cp_workspace_bytes(const cp_workspace *ws)
 { if (!ws) return 0;
   const dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
                         &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
-                        &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm };
+                        &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist };
   size_t s = 0;
   for (const dbuf *b : all) s += b->cap;
   return s;
@@ -256,6 +256,7 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   HIPCHK(hipMemsetAsync(ws->wall_s.p,0,(size_t)ncell,st));
   HIPCHK(hipMemsetAsync(ws->hkeys.p,0xff,(size_t)totalH*4,st));       // every slot empty (key -1)
   ENSURE(ws->perm,(size_t)nreads*4);
+  ENSURE(ws->wlist,(size_t)totalI*4*4);
   // longest reads first: key = wall candidates / 4 (bins of 4 up to 4096 candidates)
   hipLaunchKernelGGL(k_order_by_work,dim3(1),dim3(1024),0,st,(const int32_t *)ws->ncand.p,nreads,2,(int32_t *)ws->perm.p);
   hipLaunchKernelGGL(k_find_wall,dim3(nreads),dim3(WAVE),0,st,
@@ -263,7 +264,7 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
                      (uint8_t *)ws->wall.p,(uint8_t *)ws->wall_s.p,(int32_t *)ws->hkeys.p,(double *)ws->hvals.p,(const int64_t *)ws->hoff.p,
                      (cp_eintvl *)ws->eintvl.p,(cp_eintvl *)ws->ointvl.p,
                      (const int64_t *)ws->eoff.p,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,
-                     (int32_t *)ws->nintvl.p,(int32_t *)ws->err.p,(const int32_t *)ws->perm.p);
+                     (int32_t *)ws->nintvl.p,(int32_t *)ws->err.p,(const int32_t *)ws->perm.p,(int32_t *)ws->wlist.p);
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_WALL)
     return CP_OK;

@@ -247,7 +247,8 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
             int32_t *__restrict__ hkeys, double *__restrict__ hvals, const int64_t *__restrict__ hoff,
             cp_eintvl *__restrict__ eintvl_all, cp_eintvl *__restrict__ ointvl_all, const int64_t *__restrict__ eoff,
             cp_intvl *__restrict__ intvl_all, const int64_t *__restrict__ ioff,
-            int32_t *__restrict__ nintvl, int32_t *__restrict__ err, const int32_t *__restrict__ perm)
+            int32_t *__restrict__ nintvl, int32_t *__restrict__ err, const int32_t *__restrict__ perm,
+            int32_t *__restrict__ wlist)
 { if ((int)blockIdx.x >= nreads) return;
   const int r = perm[blockIdx.x];
   const int lane = lane_id();
@@ -272,6 +273,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   R.eidx = R.oidx = 0; R.overflow = 0;
   cp_intvl *intvl = intvl_all+ioff[r];
   const int icap = (int)(ioff[r+1]-ioff[r]);
+  int32_t *wl = wlist+ioff[r]*4;                        // four int32 lists of capacity icap
   uint8_t *wall = R.wall;
   const uint8_t *wall_s = R.wall_s;
 
@@ -288,16 +290,10 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
             }
         }
     }
-#if defined(CP_K2_STOP) && CP_K2_STOP == 0
-  if (plen >= 0) return;
-#endif
   int NS = __shfl(R.eidx,0), NO = __shfl(R.oidx,1);
   int overflow = __shfl(R.overflow,0) | __shfl(R.overflow,1);
   R.eidx = NS; R.oidx = NO;
   wave_sync();
-#if defined(CP_K2_STOP) && CP_K2_STOP == 1
-  if (plen >= 0) { if (lane == 0) nintvl[r] = 0; return; }
-#endif
 
   // ---- un-wall positions explained by O-pairs / inside E-intervals (wall.c:722-731) --------
   if (lane == 0)
@@ -318,28 +314,49 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   wave_sync();
 
   // ---- multi-error / boundary E-intervals (wall.c:760-861) -----------------------------------
-  int midx = NS;
-  for (int base = 1; base < plen; base += WAVE)
-    { int i = base+lane;
-      bool cand = false;
-      if (i < plen)
-        { cand = (wall[i] & CP_W_WALL_O) && !(wall_s[i] & CP_W_WALL_S);
-        }
-      uint64_t mask = __ballot(cand);
-      if (mask && lane == 0)
-        { while (mask)
-            { int k = __ffsll((long long)mask)-1;
-              mask &= mask-1;
-              int ii = base+k;
-              if (wall[ii] & CP_W_PAIRED_M)            // may have been set by an earlier i
-                continue;
-              cp_wall_mult(&R,ii,NS,&midx);
+  // The reference scans every position for O-only walls; OTHERS walls are only ever set at wall
+  // candidates, so the lanes walk the candidate bitmap instead (64 words per step) and compact the
+  // qualifying positions, in order, into a short list that one lane then processes sequentially
+  // (processing a wall can mark later ones as paired, wall.c:766-767).
+  int32_t *olist = wl, *compB = wl+icap, *compE = wl+2*(int64_t)icap, *bnd = wl+3*(int64_t)icap;
+  int n_o = 0;
+  if (plen > 1)
+    { const int64_t lo = po+1, hi = po+plen;
+      const int64_t w_lo = lo >> 6, w_hi = (hi-1) >> 6;
+      for (int64_t wb = w_lo; wb <= w_hi; wb += WAVE)
+        { const int64_t w = wb+lane;
+          uint64_t bits = (w <= w_hi) ? bitmap_word(bm,w,lo,hi) : 0ull, keep = 0ull;
+          for (uint64_t t = bits; t; t &= t-1)
+            { const int k = __ffsll((long long)t)-1;
+              const int i = (int)((w << 6)+k-po);
+              if ((wall[i] & CP_W_WALL_O) && !(wall_s[i] & CP_W_WALL_S)) keep |= 1ull << k;
             }
+          int c = __popcll(keep), off = c;
+          for (int o = 1; o < WAVE; o <<= 1)               // inclusive scan over lanes
+            { int x = __shfl_up(off,o); if (lane >= o) off += x; }
+          const int tot = __shfl(off,WAVE-1);
+          off = n_o+off-c;
+          for (uint64_t t = keep; t; t &= t-1)
+            { const int k = __ffsll((long long)t)-1;
+              if (off < icap) olist[off] = (int)((w << 6)+k-po);
+              off++;
+            }
+          n_o += tot;
         }
-      wave_sync();
     }
+  if (n_o > icap) { overflow |= 2; n_o = icap; }
+  wave_sync();
+  int midx = NS;
+  if (lane == 0)
+    for (int q = 0; q < n_o; q++)
+      { const int ii = olist[q];
+        if (wall[ii] & CP_W_PAIRED_M)                  // may have been set by an earlier i
+          continue;
+        cp_wall_mult(&R,ii,NS,&midx);
+      }
   midx = __shfl(midx,0);
   overflow |= __shfl(R.overflow,0);
+  wave_sync();
   for (int k = NS; k < midx; k++)                      // wall.c:868-872
     wave_wall_and(wall,R.eintvl[k].b+1,R.eintvl[k].e,(uint8_t)~CP_W_WALL_O);
   wave_sync();
@@ -354,39 +371,92 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   wave_sync();
   wave_sort_eintvl(R.eintvl,NS,R.ointvl);              // wall.c:910
 
-  for (int k = 0; k < NS; k++)                         // wall.c:917-919
-    wave_wall_or(wall,R.eintvl[k].b,R.eintvl[k].e,CP_W_ERROR);
-  wave_sync();
-
-#if defined(CP_K2_STOP) && CP_K2_STOP == 2
-  if (plen >= 0) { if (lane == 0) nintvl[r] = 0; return; }
-#endif
-  // ---- emit intervals at error transitions and O-walls (wall.c:922-948) ----------------------
-  int N = 0, prev_b = 0;
-  for (int base = 1; base <= plen; base += WAVE)
-    { int i = base+lane;
-      bool bd = false;
-      if (i <= plen)
-        { if (i == plen) bd = true;
-          else
-            { uint8_t w0 = wall[i-1], w1 = wall[i];
-              bd = (((w0 ^ w1) & CP_W_ERROR) != 0) || (!(w1 & CP_W_ERROR) && (w1 & CP_W_WALL_O));
+  // ---- interval boundaries (wall.c:917-948) without per-position passes -----------------------
+  // The reference marks every position of every E-interval as "error" and then scans all positions
+  // for error transitions and OTHERS walls outside error regions.  Equivalent, on lists:
+  //   error regions  = connected components of the union of the sorted E-intervals,
+  //   boundaries     = component starts (>= 1) and ends, OTHERS walls (candidate positions) outside
+  //                    every component, and plen; merged in increasing order.
+  int C = 0;
+  if (lane == 0)
+    { int k = 0;
+      while (k < NS)
+        { int cb = R.eintvl[k].b, ce = R.eintvl[k].e;
+          k++;
+          while (k < NS && R.eintvl[k].b <= ce)
+            { if (R.eintvl[k].e > ce) ce = R.eintvl[k].e;
+              k++;
             }
-        }
-      uint64_t mask = __ballot(bd);
-      if (bd)
-        { uint64_t below = mask & ((1ull << lane)-1);
-          int rank = __popcll(below);
-          int b = below ? base+(63-__clzll((long long)below)) : prev_b;
-          if (N+rank < icap)
-            cp_make_interval(&R,NS,b,i,&intvl[N+rank]);
-        }
-      if (mask)
-        { N += __popcll(mask);
-          prev_b = base+(63-__clzll((long long)mask));
+          if (C < icap) { compB[C] = cb; compE[C] = ce; }
+          C++;
         }
     }
+  C = __shfl(C,0);
+  if (C > icap) { overflow |= 2; C = icap; }
+  wave_sync();
+  int n_w = 0;                                         // OTHERS walls outside error regions, in order
+  if (plen > 1)
+    { const int64_t lo = po+1, hi = po+plen;
+      const int64_t w_lo = lo >> 6, w_hi = (hi-1) >> 6;
+      for (int64_t wb = w_lo; wb <= w_hi; wb += WAVE)
+        { const int64_t w = wb+lane;
+          uint64_t bits = (w <= w_hi) ? bitmap_word(bm,w,lo,hi) : 0ull, keep = 0ull;
+          for (uint64_t t = bits; t; t &= t-1)
+            { const int k = __ffsll((long long)t)-1;
+              const int i = (int)((w << 6)+k-po);
+              if (wall[i] & CP_W_WALL_O)
+                { int a = 0, z = C-1, in = 0;            // inside a component?  compB sorted, disjoint
+                  while (a <= z)
+                    { int m = (a+z) >> 1;
+                      if (i < compB[m]) z = m-1;
+                      else if (i >= compE[m]) a = m+1;
+                      else { in = 1; break; }
+                    }
+                  if (!in) keep |= 1ull << k;
+                }
+            }
+          int c = __popcll(keep), off = c;
+          for (int o = 1; o < WAVE; o <<= 1)
+            { int x = __shfl_up(off,o); if (lane >= o) off += x; }
+          const int tot = __shfl(off,WAVE-1);
+          off = n_w+off-c;
+          for (uint64_t t = keep; t; t &= t-1)
+            { const int k = __ffsll((long long)t)-1;
+              if (off < icap) olist[off] = (int)((w << 6)+k-po);
+              off++;
+            }
+          n_w += tot;
+        }
+    }
+  if (n_w > icap) { overflow |= 2; n_w = icap; }
+  wave_sync();
+  int N = 0;
+  if (lane == 0)                                       // merge: transitions, walls, plen
+    { int ci = 0, phase = 0, wi = 0, last = 0;         // phase 0: next transition is compB[ci], 1: compE[ci]
+      while (true)
+        { int tpos = plen;
+          while (ci < C)
+            { int v = phase ? compE[ci] : compB[ci];
+              if (v >= 1 && v < plen && v > last) { tpos = v; break; }
+              if (phase) { ci++; phase = 0; } else phase = 1;
+            }
+          int wpos = (wi < n_w) ? olist[wi] : plen;
+          int nb = tpos < wpos ? tpos : wpos;
+          if (nb >= plen) break;
+          if (N < icap) bnd[N] = nb;
+          N++;
+          last = nb;
+          if (wpos == nb) wi++;
+          if (tpos == nb) { if (phase) { ci++; phase = 0; } else phase = 1; }
+        }
+      if (N < icap) bnd[N] = plen;
+      N++;
+    }
+  N = __shfl(N,0);
   if (N > icap) overflow |= 2;
+  wave_sync();
+  for (int k = lane; k < N && k < icap; k += WAVE)     // wall.c:928-946, one lane per interval
+    cp_make_interval(&R,NS,k ? bnd[k-1] : 0,bnd[k],&intvl[k]);
   if (lane == 0)
     { nintvl[r] = (N > icap) ? icap : N;
       if (overflow) atomicOr(err,overflow);
@@ -617,28 +687,43 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
   wave_sync();
 
   int cur = 0;
+  double pe_next = 0.;                                     // pe of the next interval (E lanes), one step ahead
+  if (in_grp && t == CP_ERROR && M > 1)
+    pe_next = rintvl[F ? 1 : M-2].pe;
   for (int k = 1; k < maxM; k++)                           // _update, class_rel.c:279-513
     { const bool on = in_grp && k < M;
       const int i_pred = i;
       if (on) i = F ? k : M-1-k;
       cp_riv I; I.b = I.e = I.ccb = I.cce = 0; I.pe = 0.;
       double v = 0.;
-      // ---- :300-319: 16 transitions per (read, direction), one lane each.  The H and D lanes only
-      //      prepare arguments here; the Skellam/Bessel evaluation below is one call for all of them.
-      bool live = false, is_sk = false;
+      // ---- :300-319: 16 transitions per (read, direction), one lane each.  Every lane first works out
+      //      which table cells (log-factorials, log lambda) or which Skellam arguments its transition
+      //      needs; the table loads of all lanes are then issued together and the Skellam/Bessel
+      //      evaluation is one call for all H and D lanes.
+      bool live = false, is_sk = false, r_tab = false;
       int tb = 0, te = 0, tcb = 0, tce = 0, tcov = 0;
+      int f0 = 0, f1 = 0, f2 = 0, li = 1, rk = 0, rn = 0;
       double lp = -INFINITY;
+      const double pe_now = pe_next;                       // fetched one step ahead
       if (on)
         { I = rv(i);
+          if (t == CP_ERROR && k+1 < M)
+            pe_next = rintvl[F ? k+1 : M-2-k].pe;
           const cp_cell &pr = S.cell[g][d][cur][s];
           live = pr.dp != -INFINITY;
           if (live)
-            { if (t == CP_ERROR)
-                { I.pe = rintvl[i].pe;
-                  lp = cp_logp_e(P,I,COV);
+            { if (t == CP_ERROR)                           // logp_e, class_rel.c:158-170
+                { I.pe = pe_now;
+                  f0 = cp_check_cnt(I.ccb); f1 = cp_check_cnt(I.cce); li = COV[CP_ERROR];
                 }
-              else if (t == CP_REPEAT)
-                lp = cp_logp_r(P,I,pr.cnt[CP_REPEAT],F,COV);
+              else if (t == CP_REPEAT)                     // logp_r, class_rel.c:172-211
+                { const int beg_cnt = cp_beg_cnt(I,F), prc = pr.cnt[CP_REPEAT];
+                  if (beg_cnt < prc)
+                    { r_tab = true;
+                      rk = cp_check_cnt(beg_cnt); rn = cp_check_cnt(prc);
+                      f0 = rn; f1 = rk; f2 = rn-rk;
+                    }
+                }
               else
                 { is_sk = true;                            // logp_h / logp_d, class_rel.c:213-270
                   const int beg_pos = cp_beg_pos(I,F), beg_cnt = cp_beg_cnt(I,F);
@@ -652,6 +737,24 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
                 }
             }
         }
+      { const double A = P->logfact[f0], B = P->logfact[f1], C = P->logfact[f2];
+        const double D = (li >= 0 && li <= CP_MAX_KMER_CNT) ? P->logint[li] : log((double)li);
+        if (on && live)
+          { if (t == CP_ERROR)
+              { double po = (f0 * D - li - A)+(f1 * D - li - B)+CP_E_PO_BASE;       // prob.c:33-39 twice
+                lp = (po > I.pe) ? po : I.pe;
+              }
+            else if (t == CP_REPEAT)
+              { const cp_cell &pr = S.cell[g][d][cur][s];
+                double l = r_tab ? (A - B - C + rk * P->r_lp + (rn-rk) * P->r_l1mp) : -INFINITY;   // prob.c:67-73
+                if (!(l > CP_R_LOGP))
+                  { int max_cc = I.ccb > I.cce ? I.ccb : I.cce;
+                    if (max_cc >= COV[CP_REPEAT] || max_cc >= pr.cnt[CP_REPEAT]) l = CP_R_LOGP;
+                  }
+                lp = l;
+              }
+          }
+      }
       if (is_sk)
         lp = cp_logp_trans(P,tb,te,tcb,tce,tcov);
       if (on)
