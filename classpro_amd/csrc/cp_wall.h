@@ -377,16 +377,17 @@ CP_HD void cp_wall_mult(RD *R, int i, int NS, int *midx)
 }
 
 // wall.c:878-909: append the union of every chain of overlapping E-intervals (list sorted by (b,e)).
+// The reference bounds both loops by NS while NS grows with every appended union, so the scan runs on
+// into the entries it has just appended (which are not in sorted position); reproduced literally.
 template <class RD>
 CP_HD int cp_merge_eintvl(RD *R, int NS)
 { cp_eintvl *ev = R->eintvl;
-  const int n0 = NS;
   int i = 0, j;
-  while (i < n0-1)
+  while (i < NS-1)
     { int    max_e  = ev[i].e;
       double max_pe = ev[i].pe;
       j = i;
-      while (j < n0-1)
+      while (j < NS-1)
         { if (ev[j+1].b <= ev[j].e)
             { if (max_e < ev[j+1].e) max_e = ev[j+1].e;
               if (!(max_pe > ev[j+1].pe)) max_pe = ev[j+1].pe;

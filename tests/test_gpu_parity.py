@@ -254,3 +254,15 @@ def test_cli_drop_in(torch_dev, tmp_path):
     assert r.returncode == 0
     r = subprocess.run([cli, os.path.join(d, "missing.fa")], capture_output=True, text=True)
     assert r.returncode == 1 and "Cannot open" in r.stderr
+
+
+def test_regression_merge_tail(torch_dev):
+    """The read that exposed the merge-loop bound (see tests/test_host_logic.py): through the C ABI."""
+    from conftest import load_golden
+    from classpro_amd.api import Classifier, Batch
+    g = load_golden("regress_merge_tail.npz")
+    h, d = (int(x) for x in g["cov"])
+    clf = Classifier(K, 20000, h, d)
+    lab = clf.classify(Batch.from_reads([g["seq"].tobytes()], [np.ascontiguousarray(g["prof"])]))
+    assert np.array_equal(lab, g["labels"])
+    clf.close()

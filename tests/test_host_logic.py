@@ -168,3 +168,29 @@ def test_edge_reads(harness):
         assert set(lab[39:]) <= set(b"EHDR") and lab[:39] == b"N" * min(39, len(s))
     assert n_ok >= len(cases) - 4
     harness.hh_params_free(C.c_void_p(P))
+
+
+def test_regression_merge_scans_appended_entries(harness):
+    """wall.c:878-909 bounds its merge loops by NS while appending unions, so the scan continues into the
+    appended entries; a frozen bound changes which duplicate (b,e) record the later binary search finds.
+    Read taken from the bench workload (seed 1, read 4184); expected labels are the oracle's."""
+    g = load_golden("regress_merge_tail.npz")
+    h, d = (int(x) for x in g["cov"])
+    s, p = g["seq"].tobytes(), np.ascontiguousarray(g["prof"])
+    O = Oracle(40, 20000, h, d)
+    assert O.classify_read(s, p) == g["labels"].tobytes()
+    P = harness.hh_params_new(40, 20000, h, d)
+    N, lab, iv, riv, fw, bw = run_harness_read(harness, P, s, p)
+    assert N == int(g["n_intvl"]) and len(riv) == int(g["n_rel"]) and lab == g["labels"].tobytes()
+    harness.hh_params_free(C.c_void_p(P))
+
+
+def test_device_functions_vs_oracle_long_reads(harness):
+    """20 kb reads (more intervals per read, boundary E-intervals at both ends)."""
+    ds = synth.make_dataset(genome_len=600000, cov=40, read_len=20000, seed=1, het=0.001, n_repeats=8, min_len=3000)
+    O = Oracle(40, 20000, 19, 38)
+    P = harness.hh_params_new(40, 20000, 19, 38)
+    for s, p in zip(ds["seqs"], ds["profiles"]):
+        N, lab, *_ = run_harness_read(harness, P, s, p)
+        assert lab == O.classify_read(s, p)
+    harness.hh_params_free(C.c_void_p(P))
