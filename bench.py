@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--read-len", type=int, default=20000)
     ap.add_argument("--tile", type=int, default=1, help="replicate the read set this many times in the batch")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--cpu-sample-reads", type=int, default=6000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=1 << 30, help="reads of the batch timed on the CPU (default: all)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     return ap.parse_args()
