@@ -266,3 +266,37 @@ def test_regression_merge_tail(torch_dev):
     lab = clf.classify(Batch.from_reads([g["seq"].tobytes()], [np.ascontiguousarray(g["prof"])]))
     assert np.array_equal(lab, g["labels"])
     clf.close()
+
+
+def test_long_and_noisy_reads_all_size_classes(torch_dev):
+    """50 kb reads with elevated het/error rates (N 400-900, M 150-380: the one-read-per-wave rel class
+    and the two-reads-per-wave unrel class) and block-noise profiles that push N and M past 1024 (the
+    sequential fallback kernels).  Labels and final interval classes must equal the oracle's."""
+    from classpro_amd.api import Classifier, Batch, STAGE_CLASS_ALL
+    from classpro_amd import synth
+    from oracle.oracle import Oracle
+    AL = np.frombuffer(b"ACGT", np.uint8)
+    rng = np.random.default_rng(5)
+    ds = synth.make_dataset(genome_len=400000, cov=40, read_len=50000, seed=9, het=0.004, err_sub=0.002,
+                            err_indel=0.002, min_len=30000)
+    seqs, profs = list(ds["seqs"][:60]), list(ds["profiles"][:60])
+    for blk, lo, hi in ((60, 15, 45), (45, 5, 60), (25, 18, 42), (90, 30, 50), (45, 5, 60)):
+        plen = 58000
+        vals = rng.integers(lo, hi, plen // blk + 1)
+        profs.append(np.repeat(vals, blk)[:plen].astype(np.uint16))
+        seqs.append(bytes(AL[rng.integers(0, 4, plen + K - 1)]))
+    O = Oracle(K, 20000, 20, 40)
+    want, Ns, Ms = [], [], []
+    for s, p in zip(seqs, profs):
+        lab, iv, M = O.classify_read(s, p, want_intvl=True)
+        want.append(lab)
+        Ns.append(len(iv))
+        Ms.append(M)
+    assert max(Ns) > 1024 and max(Ms) > 1024 and sum(256 < n <= 1024 for n in Ns) > 10 and sum(128 < m <= 1024 for m in Ms) > 10
+    clf = Classifier(K, 20000, 20, 40)
+    b = Batch.from_reads(seqs, profs)
+    got = clf.classify(b).tobytes()
+    assert got == b"".join(want)
+    nc, ni, nr, off = clf.counts(b)
+    assert list(ni) == Ns and list(nr) == Ms
+    clf.close()
