@@ -63,25 +63,51 @@ CP_HD double cp_bessi1(double x)
 #define CP_ANY_LANE(c) (c)
 #define CP_NO_IFCVT() ((void)0)
 #endif
+// One step of the recurrence for counter value dj: (older,newer) = (a,b) -> b becomes the older value
+// and the returned sum the newer one.  `ans` takes part in the rescale only once it has been captured.
+#define CP_BESSI_STEP(t,a,b,WITH_ANS)                                   \
+  t = a+dj*tox*b;                                                       \
+  dj -= 1.0;                                                            \
+  if (CP_ANY_LANE(fabs(t) > 1.0e10))                                    \
+    { CP_NO_IFCVT();                                                    \
+      if (fabs(t) > 1.0e10)                                             \
+        { if (WITH_ANS) ans *= 1.0e-10;                                 \
+          t *= 1.0e-10; b *= 1.0e-10;                                   \
+        }                                                               \
+    }
+
 CP_HD double cp_bessi(int n, double x)
 { if (n == 0) return cp_bessi0(x);
   if (n == 1) return cp_bessi1(x);
   if (x == 0.0) return 0.0;
-  double tox = 2.0/fabs(x), bip = 0.0, ans = 0.0, bi = 1.0, bim;
-  int j = 2*(n+(int)sqrt(40.0*n));
-  double dj = (double)j;
-  for (; j > 0; j--, dj -= 1.0)
-    { bim = bip+dj*tox*bi;
-      bip = bi;
-      bi  = bim;
-      if (CP_ANY_LANE(fabs(bi) > 1.0e10))
-        { CP_NO_IFCVT();
-          if (fabs(bi) > 1.0e10)
-            { ans *= 1.0e-10; bi *= 1.0e-10; bip *= 1.0e-10; }
-        }
-      if (j == n) ans = bip;
+  const double tox = 2.0/fabs(x);
+  const int jmax = 2*(n+(int)sqrt(40.0*n));
+  double dj = (double)jmax;
+  double a = 0.0, b = 1.0, t1, t2, ans = 0.0;            // a = bip (older), b = bi (newer)
+  // j = jmax .. n: ans is still 0, so the reference's `ans *= BIGNI` is a no-op here (bessel.c:500-509)
+  int c = jmax-n+1;
+  for (; c >= 2; c -= 2)
+    { CP_BESSI_STEP(t1,a,b,false)
+      CP_BESSI_STEP(t2,b,t1,false)
+      a = t1; b = t2;
     }
-  ans *= cp_bessi0(x)/bi;
+  if (c == 1)
+    { CP_BESSI_STEP(t1,a,b,false)
+      a = b; b = t1;
+    }
+  ans = a;                                               // `if (j == n) ans = bip` (bessel.c:510)
+  // j = n-1 .. 1
+  c = n-1;
+  for (; c >= 2; c -= 2)
+    { CP_BESSI_STEP(t1,a,b,true)
+      CP_BESSI_STEP(t2,b,t1,true)
+      a = t1; b = t2;
+    }
+  if (c == 1)
+    { CP_BESSI_STEP(t1,a,b,true)
+      a = b; b = t1;
+    }
+  ans *= cp_bessi0(x)/b;
   return (x < 0.0 && (n & 1)) ? -ans : ans;
 }
 
