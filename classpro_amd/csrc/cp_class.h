@@ -54,7 +54,7 @@ CP_HD double cp_logp_e(const cp_dev_params *P, const cp_riv &I, const int *COV)
 // class_rel.c:172-211
 CP_HD double cp_logp_r(const cp_dev_params *P, const cp_riv &I, int pred_r_cnt, int F, const int *COV)
 { int beg_cnt = cp_beg_cnt(I,F);
-  double logp = (beg_cnt < pred_r_cnt) ? cp_logp_binom_pre(P,beg_cnt,pred_r_cnt,P->r_lp,P->r_l1mp) : -INFINITY;
+  double logp = (beg_cnt < pred_r_cnt) ? cp_logp_binom_pre(P->logfact,beg_cnt,pred_r_cnt,P->r_lp,P->r_l1mp) : -INFINITY;
   if (logp > CP_R_LOGP)
     return logp;
   int max_cc = I.ccb > I.cce ? I.ccb : I.cce;
@@ -549,7 +549,7 @@ CP_HD double cp_logp_r_u(const cp_dev_params *P, int idx, const cp_intvl *intvl,
   int rcov_r = (uint16_t)(P->dr_ratio*dcov_r);
   if (I.cb >= rcov_l || I.ce >= rcov_r)
     return CP_R_LOGP;
-  return cp_logp_binom_pre(P,I.cb,rcov_l,P->r_lp,P->r_l1mp)+cp_logp_binom_pre(P,I.ce,rcov_r,P->r_lp,P->r_l1mp);
+  return cp_logp_binom_pre(P->logfact,I.cb,rcov_l,P->r_lp,P->r_l1mp)+cp_logp_binom_pre(P->logfact,I.ce,rcov_r,P->r_lp,P->r_l1mp);
 }
 
 // class_unrel.c:115-175
@@ -565,7 +565,7 @@ CP_HD double cp_logp_hd_u(const cp_dev_params *P, int s, int idx, const cp_intvl
       sf = cp_logp_trans(P,intvl[l_rel].e-1,I.b,intvl[l_rel].cce,I.cb,intvl[l_rel].cce);
     int est = cp_est_cov(P,I.b,idx,intvl,N,s,l_rel,r_rel);
     if (est >= I.cb)
-      sf_er = log(cp_p_errorin(P,CP_OTHERS,0.1,P->u_lpe,P->u_l1mpe,est,I.cb));
+      sf_er = log(cp_p_errorin(P->logfact,CP_OTHERS,0.1,P->u_lpe,P->u_l1mpe,est,I.cb));
     double m = (er > sf) ? er : sf;
     logp_l = (m > sf_er) ? m : sf_er;
   }
@@ -576,7 +576,7 @@ CP_HD double cp_logp_hd_u(const cp_dev_params *P, int s, int idx, const cp_intvl
       sf = cp_logp_trans(P,I.e-1,intvl[r_rel].b,I.ce,intvl[r_rel].ccb,intvl[r_rel].ccb);
     int est = cp_est_cov(P,I.e-1,idx,intvl,N,s,l_rel,r_rel);
     if (est >= I.ce)
-      sf_er = log(cp_p_errorin(P,CP_OTHERS,0.1,P->u_lpe,P->u_l1mpe,est,I.ce));
+      sf_er = log(cp_p_errorin(P->logfact,CP_OTHERS,0.1,P->u_lpe,P->u_l1mpe,est,I.ce));
     double m = (er > sf) ? er : sf;
     logp_r = (m > sf_er) ? m : sf_er;
   }

@@ -24,7 +24,8 @@
 #endif
 
 // _lctx[i][t] of ClassPro.c:136-141 (index = read position)
-CP_HD int cp_lctx(const char *seq, int rlen, int i, int t)
+template <class SEQ>
+CP_HD int cp_lctx(const SEQ &seq, int rlen, int i, int t)
 { (void)rlen;
   if (t == CP_HP)
     { int n = 1;
@@ -47,7 +48,8 @@ CP_HD int cp_lctx(const char *seq, int rlen, int i, int t)
 }
 
 // rctx[j][t] of ClassPro.c:137,142
-CP_HD int cp_rctx(const char *seq, int rlen, int j, int t)
+template <class SEQ>
+CP_HD int cp_rctx(const SEQ &seq, int rlen, int j, int t)
 { if (t == CP_HP)
     { int fwd = 0;                                   // equal bases after j
       while (j+fwd+1 < rlen && seq[j+fwd+1] == seq[j] && fwd < 127) fwd++;
@@ -74,5 +76,6 @@ CP_HD int cp_rctx(const char *seq, int rlen, int j, int t)
 }
 
 // Profile-indexed views of ClassPro.c:138-142: ctx[DROP][i] = _lctx[i+K-2], ctx[GAIN][i] = rctx[i].
-CP_HD int cp_ctx(const char *seq, int rlen, int K, int w, int i, int t)
+template <class SEQ>
+CP_HD int cp_ctx(const SEQ &seq, int rlen, int K, int w, int i, int t)
 { return (w == CP_DROP) ? cp_lctx(seq,rlen,i+K-2,t) : cp_rctx(seq,rlen,i,t); }

@@ -129,15 +129,17 @@ CP_HD double cp_logp_skellam(int k, double lambda)
 { return -2. * lambda + log(cp_bessi(k < 0 ? -k : k,2.*lambda)); }
 
 // ---- prob.c:59-73 with log(p), log(1-p) supplied ----------------------------------------------
-CP_HD double cp_logp_binom_pre(const cp_dev_params *P, int k, int n, double lpe, double l1mpe)
+// `lf` is anything indexable like the log-factorial table: P->logfact, or an LDS-backed accessor.
+template <class LF>
+CP_HD double cp_logp_binom_pre(const LF &lf, int k, int n, double lpe, double l1mpe)
 { k = cp_check_cnt(k);
   n = cp_check_cnt(n);
-  const double *lf = P->logfact;
   return lf[n] - lf[k] - lf[n-k] + k * lpe + (n-k) * l1mpe;
 }
 
 // ---- prob.c:76-112, exact == false ------------------------------------------------------------
-CP_HD double cp_binom_test_g(const cp_dev_params *P, int k, int n, double pe, double lpe, double l1mpe)
+template <class LF>
+CP_HD double cp_binom_test_g(const LF &P, int k, int n, double pe, double lpe, double l1mpe)
 { k = cp_check_cnt(k);
   n = cp_check_cnt(n);
   const double mean = n * pe;
@@ -163,8 +165,9 @@ CP_HD double cp_binom_test_g(const cp_dev_params *P, int k, int n, double pe, do
 }
 
 // ---- util.c:46-55 -----------------------------------------------------------------------------
-CP_HD double cp_p_errorin(const cp_dev_params *P, int e, double erate, double lpe, double l1mpe, int cout, int cin)
-{ return cp_binom_test_g(P,(e == CP_SELF) ? cin : cout-cin,cout,erate,lpe,l1mpe); }
+template <class LF>
+CP_HD double cp_p_errorin(const LF &lf, int e, double erate, double lpe, double l1mpe, int cout, int cin)
+{ return cp_binom_test_g(lf,(e == CP_SELF) ? cin : cout-cin,cout,erate,lpe,l1mpe); }
 
 // ---- util.c:35-44 -----------------------------------------------------------------------------
 CP_HD double cp_logp_trans(const cp_dev_params *P, int b, int e, int cb, int ce, int cov)

@@ -64,11 +64,14 @@ struct cp_perr_hash
     }
   };
 
-template <class PE>
+// SEQ / PROF / LF: anything indexable like the read's bases, its counts and the log-factorial table
+// (plain pointers, or the LDS-window accessors of kernels.hip).
+template <class PE, class SEQ = const char *, class PROF = const uint16_t *, class LF = const double *>
 struct cp_read_t
   { const cp_dev_params *P;
-    const uint16_t      *prof;
-    const char          *seq;
+    PROF                 prof;
+    SEQ                  seq;
+    LF                   lf;
     int                  plen, rlen;
     uint8_t             *wall;      // flags written by the OTHERS pass + PAIRED_M/ERROR (and everything, if shared)
     uint8_t             *wall_s;    // flags written by the SELF pass (may alias `wall`: the bits are disjoint)
@@ -86,13 +89,13 @@ struct cp_read_t
 template <class RD>
 CP_HD void cp_update_perror(RD *R, int i, int e, int w, int cout, int cin, double erate, double lpe, double l1mpe)
 { if (CP_PERR(R,i,e,w) == CP_NEG_INF)
-    R->perror[e].set(i,e,w,cp_p_errorin(R->P,e,erate,lpe,l1mpe,cout,cin));
+    R->perror[e].set(i,e,w,cp_p_errorin(R->lf,e,erate,lpe,l1mpe,cout,cin));
 }
 
 // wall.c:317-322
 template <class RD>
 CP_HD double cp_logp_diff_pair(const RD *R, int i, int j)
-{ const uint16_t *pr = R->prof;
+{ const auto &pr = R->prof;
   int n_drop = (int)pr[i-1]-pr[i];
   int n_gain = (int)pr[j]-pr[j-1];
   int cov    = pr[i-1] > pr[j] ? pr[i-1] : pr[j];
@@ -109,7 +112,7 @@ template <class RD>
 CP_HD bool cp_find_pair(RD *R, int i, int cout, int cin, int e, int w, int t, int l,
                         double erate, double lpe, double l1mpe, cp_eintvl *out)
 { const cp_dev_params *P = R->P;
-  const uint16_t *pr = R->prof;
+  const auto &pr = R->prof;
   const int plen = R->plen, K = P->K, CMAX = P->cmax;
   const int ulen = t+1;
   const bool right = (w == CP_DROP);
@@ -168,10 +171,10 @@ CP_HD bool cp_find_pair(RD *R, int i, int cout, int cin, int e, int w, int t, in
       if (e == CP_OTHERS && (right ? cp_logp_diff_pair(R,i,j) : cp_logp_diff_pair(R,j,i)) < CP_THRES_DIFF_EO)
         continue;
       if (!have_pe_i)                                   // same arguments every time (wall.c:398)
-        { pe_i = cp_p_errorin(P,e,P->hc_erate,P->hc_lpe,P->hc_l1mpe,cout,cin);
+        { pe_i = cp_p_errorin(R->lf,e,P->hc_erate,P->hc_lpe,P->hc_l1mpe,cout,cin);
           have_pe_i = true;
         }
-      double pe_j = cp_p_errorin(P,e,P->hc_erate,P->hc_lpe,P->hc_l1mpe,cout_j,cin_j);
+      double pe_j = cp_p_errorin(R->lf,e,P->hc_erate,P->hc_lpe,P->hc_l1mpe,cout_j,cin_j);
       pe = pe_i * pe_j;
       if (max_pe < pe)
         { max_j  = j;

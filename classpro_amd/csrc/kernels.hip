@@ -257,7 +257,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   const int rlen = (int)(seq_off[r+1]-seq_off[r]);
 
   cp_read_t<cp_perr_hash> R;
-  R.P = P; R.prof = prof+po; R.seq = seq+seq_off[r]; R.plen = plen; R.rlen = rlen;
+  R.P = P; R.prof = prof+po; R.seq = seq+seq_off[r]; R.lf = P->logfact; R.plen = plen; R.rlen = rlen;
   R.wall = wall_all+po+r;
   R.wall_s = walls_all+po+r;
   { const int64_t ho = hoff[r], hc = (hoff[r+1]-ho) >> 1;     // two tables, one per error type
@@ -1127,7 +1127,7 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
         if (do_sf)
           val = cp_logp_trans(P,tb,te,tcb,tce,tcov);
         if (do_bin)
-          val = log(cp_p_errorin(P,CP_OTHERS,0.1,P->u_lpe,P->u_l1mpe,est,c));
+          val = log(cp_p_errorin(P->logfact,CP_OTHERS,0.1,P->u_lpe,P->u_l1mpe,est,c));
         if (pass == 0 && on && ql < 8)
           { mkey[idx*8+ql] = fresh ? key : -1;
             mval[idx*8+ql] = val;
@@ -1162,7 +1162,7 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
               if (Icb >= rcov_l || Ice >= rcov_r)
                 vR = CP_R_LOGP;
               else
-                vR = cp_logp_binom_pre(P,Icb,rcov_l,P->r_lp,P->r_l1mp)+cp_logp_binom_pre(P,Ice,rcov_r,P->r_lp,P->r_l1mp);
+                vR = cp_logp_binom_pre(P->logfact,Icb,rcov_l,P->r_lp,P->r_l1mp)+cp_logp_binom_pre(P->logfact,Ice,rcov_r,P->r_lp,P->r_l1mp);
             }
             double logpmax = -INFINITY;                        // class_unrel.c:208-218: E,R,H,D with strict <
             if (logpmax < vE) { logpmax = vE; snew = CP_ERROR; }
