@@ -37,6 +37,20 @@ def decode_profile(code, cap=60000):
     return n, out[:min(n, cap)]
 
 
+def encode_profiles(profiles):
+    """FASTK code strings for a list of count arrays: (uint8 codes, int64 code_off[n+1])."""
+    L = lib()
+    chunks, off = [], [0]
+    for p in profiles:
+        p = np.ascontiguousarray(p, np.uint16)
+        buf = np.empty(2 * len(p) + 2, np.uint8)
+        n = check(L.cp_encode_profile(p.ctypes.data, len(p), buf.ctypes.data, len(buf)))
+        chunks.append(buf[:n].copy())
+        off.append(off[-1] + n)
+    codes = np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
+    return codes, np.array(off, np.int64)
+
+
 class Batch:
     """A batch of reads resident in HBM in the flat layout of include/classpro_amd.h."""
 
@@ -123,6 +137,18 @@ class Classifier:
 
     def check(self):
         check(self.L.cp_workspace_check(self.ws))
+
+    def decode_profiles(self, codes, code_off, prof_off):
+        """Fetch_Profile on the device: returns a device tensor of counts (int16 view of uint16)."""
+        dev = self.device
+        c = torch.from_numpy(np.ascontiguousarray(codes, np.uint8)).to(dev)
+        co = torch.from_numpy(np.ascontiguousarray(code_off, np.int64)).to(dev)
+        po = torch.from_numpy(np.ascontiguousarray(prof_off, np.int64)).to(dev)
+        out = torch.zeros(max(int(prof_off[-1]), 8), dtype=torch.int16, device=dev)
+        check(self.L.cp_decode_profiles(self.ws, c.data_ptr(), co.data_ptr(), po.data_ptr(), len(code_off) - 1,
+                                        out.data_ptr(), self._stream()))
+        check(self.L.cp_workspace_check(self.ws))
+        return out
 
     def workspace_bytes(self):
         return int(self.L.cp_workspace_bytes(self.ws))

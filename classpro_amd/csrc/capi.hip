@@ -96,13 +96,14 @@ struct dbuf { void *p; size_t cap; };
 
 struct cp_workspace
   { dbuf bitmap, ncand, nintvl, nrel, ioff, eoff, hoff, wall, wall_s, hkeys, hvals, eintvl, ointvl, intvl, rintvl,
-         relmap, parent, eff, rpos, asgn, ord, err, memo_val, memo_key, perm, wlist;
+         relmap, parent, eff, rpos, asgn, ord, err, memo_val, memo_key, perm, wlist, err2;
     int64_t *h_totals;        // pinned: [totalI, totalE, totalH]
     int32_t *h_err;           // pinned
     // shape of the last run
     int      nreads;
     int64_t  total_kmers, total_bases, totalI, totalE, totalH, nwords;
     int      last_stage;
+    int      decode_pending;  // a cp_decode_profiles result has not been checked yet
     hipStream_t stream;
     hipStream_t aux;          // size classes of one stage run side by side: the rare long reads are latency-bound
     hipEvent_t  ev_fork, ev_join;
@@ -144,7 +145,7 @@ extern "C" void cp_workspace_destroy(cp_workspace *ws)
 { if (!ws) return;
   dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
                   &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
-                  &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist };
+                  &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist,&ws->err2 };
   for (dbuf *b : all) if (b->p) (void)hipFree(b->p);
   if (ws->aux) (void)hipStreamDestroy(ws->aux);
   if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
@@ -158,7 +159,7 @@ extern "C" size_t cp_workspace_bytes(const cp_workspace *ws)
 { if (!ws) return 0;
   const dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
                         &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
-                        &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist };
+                        &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist,&ws->err2 };
   size_t s = 0;
   for (const dbuf *b : all) s += b->cap;
   return s;
@@ -351,6 +352,13 @@ extern "C" int cp_classify_batch(const cp_params *p, cp_workspace *ws,
 // The reference aborts in the same situation ("# E-intvls >= plen", wall.c:783-788).
 extern "C" int cp_workspace_check(cp_workspace *ws)
 { if (!ws) return set_err(CP_EINVAL,"cp_workspace_check: null workspace");
+  if (ws->decode_pending)
+    { ws->decode_pending = 0;
+      HIPCHK(hipMemcpyAsync(ws->h_err,ws->err2.p,4,hipMemcpyDeviceToHost,ws->stream));
+      HIPCHK(hipStreamSynchronize(ws->stream));
+      if (*ws->h_err)
+        return set_err(CP_EINVAL,"cp_decode_profiles: a code string does not expand to its read's profile length (rlen != plen+K-1)");
+    }
   if (ws->nreads == 0) return CP_OK;
   HIPCHK(hipMemcpyAsync(ws->h_err,ws->err.p,4,hipMemcpyDeviceToHost,ws->stream));
   HIPCHK(hipStreamSynchronize(ws->stream));
@@ -405,6 +413,28 @@ extern "C" int cp_get_bitmap(cp_workspace *ws, uint64_t *words, int64_t nwords)
   if (nwords > ws->nwords) nwords = ws->nwords;
   HIPCHK(hipStreamSynchronize(ws->stream));
   if (nwords > 0) HIPCHK(hipMemcpy(words,ws->bitmap.p,(size_t)nwords*8,hipMemcpyDeviceToHost));
+  return CP_OK;
+}
+
+extern "C" int64_t cp_encode_profile(const uint16_t *profile, int n, uint8_t *code, int64_t cap)
+{ if (n < 0 || (n > 0 && (!profile || !code)) || cap < 2*(int64_t)n+2)
+    return set_err(CP_EINVAL,"cp_encode_profile: bad argument (code buffer needs 2*n+2 bytes)");
+  return cp_host_encode_profile(profile,n,code);
+}
+
+extern "C" int cp_decode_profiles(cp_workspace *ws, const uint8_t *d_codes, const int64_t *d_code_off,
+                                  const int64_t *d_prof_off, int nreads, uint16_t *d_prof, void *stream)
+{ if (!ws || nreads < 0 || (nreads > 0 && (!d_codes || !d_code_off || !d_prof_off || !d_prof)))
+    return set_err(CP_EINVAL,"cp_decode_profiles: bad argument");
+  if (nreads == 0) return CP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  ENSURE(ws->err2,16);
+  HIPCHK(hipMemsetAsync(ws->err2.p,0,16,st));
+  hipLaunchKernelGGL(k_decode_profiles,dim3(nreads),dim3(WAVE),0,st,
+                     d_codes,d_code_off,d_prof_off,nreads,d_prof,(int32_t *)ws->err2.p);
+  HIPCHK(hipGetLastError());
+  ws->decode_pending = 1;
+  ws->stream = st;
   return CP_OK;
 }
 

@@ -181,3 +181,37 @@ static inline int cp_host_decode_profile(const uint8_t *code, int64_t len, uint1
     }
   return n;
 }
+
+// Inverse of the decoder above (what FastK writes per read; tooling for tests, benchmarks and the
+// synthetic-data path -- ClassPro itself only ever decodes).  Returns the number of code bytes;
+// `code` must hold at least 2*n+2 bytes.
+static inline int64_t cp_host_encode_profile(const uint16_t *cnt, int n, uint8_t *code)
+{ if (n <= 0) return 0;
+  uint8_t *o = code;
+  int d = cnt[0] & 0x7fff;
+  if (d < 128) *o++ = (uint8_t)d;
+  else { *o++ = (uint8_t)(0x80 | (d >> 8)); *o++ = (uint8_t)(d & 0xff); }
+  int i = 1;
+  while (i < n)
+    { int c = cnt[i] & 0x7fff;
+      if (c == d)
+        { int run = 1;
+          while (i+run < n && (cnt[i+run] & 0x7fff) == d && run < 63) run++;
+          *o++ = (uint8_t)run;
+          i += run;
+        }
+      else
+        { int dl = c-d;
+          if (dl >= 1 && dl <= 31)        *o++ = (uint8_t)(0x40 | dl);
+          else if (dl >= -32 && dl <= -1) *o++ = (uint8_t)(0x60 | (dl+32));
+          else
+            { int x = dl & 0x7fff;
+              *o++ = (uint8_t)(0x80 | (x >> 8));
+              *o++ = (uint8_t)(x & 0xff);
+            }
+          d = c;
+          i++;
+        }
+    }
+  return (int64_t)(o-code);
+}

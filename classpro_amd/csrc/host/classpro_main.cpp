@@ -7,7 +7,8 @@
 // output  <dir>/<root>.class : "@name comment\nseq\n+\nlabels\n" per read              (ClassPro.c:289)
 //
 // The reference's pthread-per-read-range loop is replaced by read batches: the host parses FASTX
-// (kseq semantics) and decodes FASTK profiles (cp_decode_profile) into pinned staging buffers, copies
+// (kseq semantics) and FASTK profile code strings into pinned staging buffers (decoded on the device by
+// cp_decode_profiles), copies
 // them with hipMemcpyAsync, calls cp_classify_batch, and writes the records in input order.  While
 // the GPU works on one batch the host stages the next one.
 //
@@ -209,10 +210,13 @@ static bool load_hist(const std::string &fk_root, int *low, int *high, int64_t *
 
 // ---- one batch in flight ----------------------------------------------------------------------------
 struct Batch
-  { char *h_seq = nullptr, *h_lab = nullptr; uint16_t *h_prof = nullptr; int64_t *h_soff = nullptr, *h_poff = nullptr;
-    char *d_seq = nullptr, *d_lab = nullptr; uint16_t *d_prof = nullptr; int64_t *d_soff = nullptr, *d_poff = nullptr;
-    size_t cap_bases = 0, cap_reads = 0;
-    int n = 0; int64_t bases = 0, kmers = 0;
+  { char *h_seq = nullptr, *h_lab = nullptr; uint8_t *h_code = nullptr;
+    int64_t *h_soff = nullptr, *h_poff = nullptr, *h_coff = nullptr;
+    char *d_seq = nullptr, *d_lab = nullptr; uint8_t *d_code = nullptr; uint16_t *d_prof = nullptr;
+    int64_t *d_soff = nullptr, *d_poff = nullptr, *d_coff = nullptr;
+    size_t cap_bases = 0, cap_reads = 0, cap_code = 0;
+    int n = 0; int64_t bases = 0, kmers = 0, codes = 0;
+    std::vector<int64_t> read_id;                // classified read -> 0-based input index (for messages)
     std::vector<std::string> headers;            // every record of the batch, in order (short reads included)
     std::vector<int> slot;                       // record -> index among classified reads, or -1 (short read)
     std::vector<std::string> short_seq;
@@ -221,15 +225,18 @@ struct Batch
     void alloc(size_t bases_cap, size_t reads_cap)
     { cap_bases = bases_cap; cap_reads = reads_cap;
       HIPOK(hipHostMalloc((void **)&h_seq,bases_cap)); HIPOK(hipHostMalloc((void **)&h_lab,bases_cap));
-      HIPOK(hipHostMalloc((void **)&h_prof,bases_cap*2));
+      cap_code = bases_cap;                      // FASTK codes run ~0.1-0.3 B/base on HiFi data; a batch closes early if they fill up
+      HIPOK(hipHostMalloc((void **)&h_code,cap_code));
       HIPOK(hipHostMalloc((void **)&h_soff,(reads_cap+1)*8)); HIPOK(hipHostMalloc((void **)&h_poff,(reads_cap+1)*8));
+      HIPOK(hipHostMalloc((void **)&h_coff,(reads_cap+1)*8));
       HIPOK(hipMalloc((void **)&d_seq,bases_cap)); HIPOK(hipMalloc((void **)&d_lab,bases_cap));
-      HIPOK(hipMalloc((void **)&d_prof,bases_cap*2));
+      HIPOK(hipMalloc((void **)&d_code,cap_code)); HIPOK(hipMalloc((void **)&d_prof,bases_cap*2));
       HIPOK(hipMalloc((void **)&d_soff,(reads_cap+1)*8)); HIPOK(hipMalloc((void **)&d_poff,(reads_cap+1)*8));
+      HIPOK(hipMalloc((void **)&d_coff,(reads_cap+1)*8));
       HIPOK(hipStreamCreate(&st));
       CPOK(cp_workspace_create(&ws));
     }
-    void reset() { n = 0; bases = kmers = 0; headers.clear(); slot.clear(); short_seq.clear(); }
+    void reset() { n = 0; bases = kmers = codes = 0; headers.clear(); slot.clear(); short_seq.clear(); read_id.clear(); }
   };
 
 int main(int argc, char **argv)
@@ -346,15 +353,15 @@ int main(int argc, char **argv)
   Batch B[2];
   B[0].alloc(BATCH_BASES+CP_MAX_READ_LEN,BATCH_READS);
   B[1].alloc(BATCH_BASES+CP_MAX_READ_LEN,BATCH_READS);
-  std::vector<uint16_t> tmp_prof(CP_MAX_READ_LEN);
 
   int64_t id = 0, total_bases = 0;
   bool more = true;
   auto stage = [&](Batch &b)                       // fill one batch from the input; false when nothing was read
     { b.reset();
-      b.h_soff[0] = b.h_poff[0] = 0;
+      b.h_soff[0] = b.h_poff[0] = b.h_coff[0] = 0;
       while (more && (size_t)b.bases < BATCH_BASES && (size_t)b.n < BATCH_READS)
         { if (id >= P.nreads) { more = false; break; }
+          if ((size_t)b.codes+2*(size_t)CP_MAX_READ_LEN+2 > b.cap_code) break;
           int rlen = fx.next();
           if (rlen < 0)
             die("Cannot load %lld-th read\n",(long long)id+1);
@@ -370,14 +377,18 @@ int main(int argc, char **argv)
               id++;
               continue;
             }
-          int plen = cp_decode_profile(code,clen,b.h_prof+b.kmers,CP_MAX_READ_LEN);
-          if (plen < 0) die("%s\n",cp_last_error());
-          if (rlen != plen+Km1)
-            die("Read %lld: rlen (%d) != plen+Km1 (%d)\n",(long long)id+1,rlen,plen+Km1);
+          if (clen > 2*(int64_t)CP_MAX_READ_LEN+2)
+            die("Read %lld: profile code of %lld bytes is longer than any read of MAX_READ_LEN\n",(long long)id+1,(long long)clen);
+          // Fetch_Profile runs on the device (cp_decode_profiles): only the code string crosses PCIe.
+          // plen is taken from rlen; the reference's rlen != plen+Km1 check (ClassPro.c:234) is made by
+          // the decode kernel and reported in finish().
+          int plen = rlen-Km1;
+          memcpy(b.h_code+b.codes,code,(size_t)clen);
           memcpy(b.h_seq+b.bases,fx.seq.data(),(size_t)rlen);
           b.slot.push_back(b.n);
-          b.bases += rlen; b.kmers += plen; b.n++;
-          b.h_soff[b.n] = b.bases; b.h_poff[b.n] = b.kmers;
+          b.read_id.push_back(id);
+          b.bases += rlen; b.kmers += plen; b.codes += clen; b.n++;
+          b.h_soff[b.n] = b.bases; b.h_poff[b.n] = b.kmers; b.h_coff[b.n] = b.codes;
           id++;
         }
       if (id >= P.nreads) more = false;
@@ -386,16 +397,28 @@ int main(int argc, char **argv)
   auto submit = [&](Batch &b)
     { if (b.n == 0) return;
       HIPOK(hipMemcpyAsync(b.d_seq,b.h_seq,(size_t)b.bases,hipMemcpyHostToDevice,b.st));
-      HIPOK(hipMemcpyAsync(b.d_prof,b.h_prof,(size_t)b.kmers*2,hipMemcpyHostToDevice,b.st));
+      HIPOK(hipMemcpyAsync(b.d_code,b.h_code,(size_t)b.codes,hipMemcpyHostToDevice,b.st));
       HIPOK(hipMemcpyAsync(b.d_soff,b.h_soff,(size_t)(b.n+1)*8,hipMemcpyHostToDevice,b.st));
       HIPOK(hipMemcpyAsync(b.d_poff,b.h_poff,(size_t)(b.n+1)*8,hipMemcpyHostToDevice,b.st));
+      HIPOK(hipMemcpyAsync(b.d_coff,b.h_coff,(size_t)(b.n+1)*8,hipMemcpyHostToDevice,b.st));
+      CPOK(cp_decode_profiles(b.ws,b.d_code,b.d_coff,b.d_poff,b.n,b.d_prof,b.st));
       CPOK(cp_classify_batch(params,b.ws,b.d_seq,b.d_soff,b.d_prof,b.d_poff,b.n,b.bases,b.kmers,b.d_lab,b.st));
       HIPOK(hipMemcpyAsync(b.h_lab,b.d_lab,(size_t)b.bases,hipMemcpyDeviceToHost,b.st));
     };
   auto finish = [&](Batch &b)
     { if (b.n > 0)
         { HIPOK(hipStreamSynchronize(b.st));
-          CPOK(cp_workspace_check(b.ws));
+          if (cp_workspace_check(b.ws) != CP_OK)
+            { // a failed decode: find the read on the host so the message is the reference's (ClassPro.c:234-237)
+              std::vector<uint16_t> tmp(CP_MAX_READ_LEN);
+              for (int i = 0; i < b.n; i++)
+                { int rlen = (int)(b.h_soff[i+1]-b.h_soff[i]);
+                  int plen = cp_decode_profile(b.h_code+b.h_coff[i],b.h_coff[i+1]-b.h_coff[i],tmp.data(),CP_MAX_READ_LEN);
+                  if (plen >= 0 && rlen != plen+Km1)
+                    die("Read %lld: rlen (%d) != plen+Km1 (%d)\n",(long long)b.read_id[i]+1,rlen,plen+Km1);
+                }
+              die("%s\n",cp_last_error());
+            }
         }
       size_t si = 0;
       for (size_t r = 0; r < b.headers.size(); r++)              // ClassPro.c:215,289

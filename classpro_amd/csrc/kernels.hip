@@ -20,6 +20,7 @@
 //   k_classify_rel / k_classify_unrel   sequential fallbacks for reads with > 1024 intervals
 //   k_paint_labels      one wave per read: ClassPro.c:116-119,265-271
 //   k_seq_context       dense context arrays (stage API / parity tests only): context.c:8-108
+//   k_decode_profiles   FASTK code strings -> counts on the device: libfastk.c:1467-1534
 //
 // No MFMA anywhere: the path has no dense contraction.  Built with -ffp-contract=off.
 #include <hip/hip_runtime.h>
@@ -1212,6 +1213,105 @@ k_paint_labels(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ 
       for (int j = b+lane; j < e; j += WAVE)
         pasgn[j] = c;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+//  k_decode_profiles: Fetch_Profile's decoder (libfastk.c:1467-1534) on the device, one wave per read
+//  (ship the ~0.27 B/base FASTK code strings over PCIe instead of
+//  2 B/base of counts).  The reference walks the code byte by byte; here a wave takes 64 code bytes at
+//  a time:
+//    1. token starts.  A byte with bit 7 set is the head of a 2-byte token *if* it is a token start,
+//       so start(i) = !(start(i-1) && bit7(i-1)): inside a run of bit-7 bytes starts alternate, and a
+//       byte after a bit-7-clear byte is always a start.  One ballot + a count-leading-zeros gives
+//       every lane the beginning of its bit-7 run, hence its parity; (bit7, start) of lane 63 carry
+//       into the next 64 bytes.
+//    2. each start lane decodes its token to (number of counts it emits, signed delta); two wave
+//       scans turn these into (first output index, count value after the token).
+//    3. expansion: output j is owned by the last lane whose first output index is <= j (binary search
+//       in LDS), so runs are written as coalesced 128-byte stores whatever their lengths.
+//  The reference adds 2-byte deltas modulo 2^15 and 6-bit deltas modulo 2^16; as long as no 6-bit
+//  delta takes a count out of [0,32767] (FastK caps counts at 32767) every count is the prefix sum
+//  of the deltas modulo 2^15, which is what the scan computes.  A 6-bit delta that leaves the range,
+//  a code that ends inside a 2-byte token, or one that does not expand to exactly plen counts sets
+//  err bit 4 (cp_workspace_check reports it) instead of producing counts.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WAVE)
+k_decode_profiles(const uint8_t *__restrict__ codes, const int64_t *__restrict__ code_off,
+                  const int64_t *__restrict__ prof_off, int nreads, uint16_t *__restrict__ prof,
+                  int32_t *__restrict__ err)
+{ const int r = blockIdx.x, lane = threadIdx.x;
+  __shared__ int s_o[WAVE], s_v[WAVE];
+  const uint8_t *c = codes+code_off[r];
+  const int clen = (int)(code_off[r+1]-code_off[r]);
+  uint16_t *out = prof+prof_off[r];
+  const int cap = (int)(prof_off[r+1]-prof_off[r]);
+  int npos = 0, dcur = 0, bad = 0;
+  bool prev_h = false, prev_s = false;
+  for (int base = 0; base < clen; base += WAVE)
+    { const int g = base+lane;
+      const bool valid = g < clen;
+      const int x  = valid ? c[g] : 0;
+      const int nx = (g+1 < clen) ? c[g+1] : 0;
+      const bool h = valid && (x & 0x80);
+      const uint64_t hm = __ballot(h);
+      const uint64_t zeros = ~hm & (((uint64_t)1 << lane)-1);      // bit-7-clear bytes below this lane
+      bool st;
+      if (zeros)
+        st = ((lane-(64-__clzll((long long)zeros))) & 1) == 0;     // run of bit-7 bytes starts right after the nearest one
+      else
+        { const bool s0 = (base == 0 || !prev_h) ? true : !prev_s;  // run reaches back into the previous 64 bytes
+          st = s0 ^ ((lane & 1) != 0);
+        }
+      st = st && valid;
+      const uint64_t sm = __ballot(st);
+      prev_h = (hm >> 63) & 1;
+      prev_s = (sm >> 63) & 1;
+
+      int contrib = 0, delta = 0;
+      if (st)
+        { if (g == 0)
+            { delta = h ? (((x & 0x7f) << 8) | nx) : x; contrib = 1; }
+          else if ((x & 0xc0) == 0)
+            contrib = x;                                           // 00rrrrrr: run of the current count
+          else
+            { contrib = 1;
+              if (h)                                               // 1sxxxxxx yyyyyyyy: 15-bit two's complement delta
+                { const int v = ((x & 0x3f) << 8) | nx;
+                  delta = (x & 0x40) ? v-16384 : v;
+                }
+              else if (x & 0x20) delta = (x & 0x1f)-32;            // 011xxxxx
+              else               delta = x & 0x1f;                 // 010xxxxx
+            }
+          if (h && g+1 >= clen) bad = 1;
+        }
+      int o = contrib, v = delta;
+      for (int k = 1; k < WAVE; k <<= 1)
+        { const int a = __shfl_up(o,k), b = __shfl_up(v,k);
+          if (lane >= k) { o += a; v += b; }
+        }
+      const int T = __shfl(o,WAVE-1), D = __shfl(v,WAVE-1);
+      if (st && g > 0 && !h && (x & 0x40))                         // a 6-bit delta must not leave [0,32767]
+        { const int t = ((dcur+v-delta) & 0x7fff)+delta;
+          if (t < 0 || t > 32767) bad = 1;
+        }
+      v = (dcur+v) & 0x7fff;
+      wave_sync();
+      s_o[lane] = npos+o-contrib;
+      s_v[lane] = v;
+      wave_sync();
+      for (int j = lane; j < T; j += WAVE)
+        { const int target = npos+j;
+          int lo = 0;
+          #pragma unroll
+          for (int step = WAVE/2; step > 0; step >>= 1)
+            if (s_o[lo+step] <= target) lo += step;
+          if (target < cap) out[target] = (uint16_t)s_v[lo];
+        }
+      npos += T;
+      dcur = (dcur+D) & 0x7fff;
+    }
+  if (__ballot(bad) != 0 || npos != cap)
+    { if (lane == 0) atomicOr(err,4); }
 }
 
 // ---------------------------------------------------------------------------------------------

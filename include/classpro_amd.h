@@ -83,6 +83,10 @@ int  cp_params_export(const cp_params *p, int *cov4, double *dr_ratio, int *cmax
  * exceed `cap`, in which case only `cap` counts were written), or a negative CP_E* code. */
 int cp_decode_profile(const uint8_t *code, int64_t len, uint16_t *profile, int cap);
 
+/* Inverse of cp_decode_profile: the FASTK code string of one read's counts (what FastK writes;
+ * tooling for tests / synthetic inputs).  `code` needs 2*n+2 bytes; returns the code length. */
+int64_t cp_encode_profile(const uint16_t *profile, int n, uint8_t *code, int64_t cap);
+
 /* ------------------------------------------------------------------------------------------
  * Batched device path.
  * ------------------------------------------------------------------------------------------ */
@@ -99,6 +103,16 @@ int cp_classify_batch(const cp_params *p, cp_workspace *ws,
                       const uint16_t *d_prof, const int64_t *d_prof_off,
                       int nreads, int64_t total_bases, int64_t total_kmers,
                       char *d_labels, void *stream);
+
+/* Fetch_Profile's decoder on the device: d_codes holds the concatenated code
+ * strings of the batch (read r = d_codes[d_code_off[r] .. d_code_off[r+1])), d_prof receives the
+ * counts at d_prof_off (plen_r = rlen_r-(K-1), known from the read lengths).  Bit-exact with
+ * cp_decode_profile for every code whose counts stay in [0,32767] (FastK caps counts there).  A code
+ * that does not expand to exactly plen_r counts (the reference's "rlen != plen+Km1" abort,
+ * ClassPro.c:234-237), ends inside a 2-byte token or steps out of [0,32767] is reported as CP_EINVAL by the
+ * next cp_workspace_check; d_prof is then unspecified. */
+int cp_decode_profiles(cp_workspace *ws, const uint8_t *d_codes, const int64_t *d_code_off,
+                       const int64_t *d_prof_off, int nreads, uint16_t *d_prof, void *stream);
 
 /* Waits for the last run on `ws` and returns CP_EOVERFLOW if a read needed more E-interval /
  * interval scratch than its capacity (the reference aborts likewise: "# E-intvls >= plen",

@@ -1,5 +1,6 @@
 """The C-ABI library builds for gfx950, loads, and exports every symbol include/classpro_amd.h declares.
 No compute calls here (no GPU in this container)."""
+import numpy as np
 import os
 import re
 
@@ -39,3 +40,24 @@ def test_product_does_not_touch_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(root, f), errors="replace").read()
                 assert "from oracle" not in txt and "import oracle" not in txt and "classpro_oracle" not in txt, f
+
+
+def test_profile_encoder_matches_fastk_writer_and_round_trips(built):
+    """cp_encode_profile (tooling) == classpro_amd.fastk.encode_profile == inverse of cp_decode_profile,
+    including 15-bit deltas, negative small deltas and runs longer than one token."""
+    from classpro_amd import fastk
+    from classpro_amd.api import encode_profiles, decode_profile
+    rng = np.random.default_rng(11)
+    ps = [np.array([5], np.uint16), np.array([200] * 300, np.uint16),
+          np.array([1, 32767, 0, 31, 0, 63, 31, 32, 0, 127, 128], np.uint16)]
+    for _ in range(40):
+        n = int(rng.integers(2, 400))
+        c = rng.integers(0, 60, n)
+        c[rng.integers(0, n, 3)] = rng.integers(0, 32768, 3)
+        ps.append(np.repeat(c, rng.integers(1, 90, n))[:n].astype(np.uint16))
+    codes, off = encode_profiles(ps)
+    for i, p in enumerate(ps):
+        code = codes[off[i]:off[i + 1]].tobytes()
+        assert code == fastk.encode_profile(p)
+        n, out = decode_profile(code)
+        assert n == len(p) and np.array_equal(out, p)

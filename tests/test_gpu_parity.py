@@ -300,3 +300,37 @@ def test_long_and_noisy_reads_all_size_classes(torch_dev):
     nc, ni, nr, off = clf.counts(b)
     assert list(ni) == Ns and list(nr) == Ms
     clf.close()
+
+
+def test_device_profile_decode(torch_dev, ds_a):
+    """cp_decode_profiles (Fetch_Profile on the device, libfastk.c:1467-1534) is bit-exact with the host
+    decoder on every read, feeds cp_classify_batch without a host round trip, and reports a code that
+    does not expand to rlen-(K-1) counts (the reference's abort, ClassPro.c:234-237)."""
+    from classpro_amd.api import Classifier, Batch, encode_profiles
+    from classpro_amd._lib import ClassProError
+    from classpro_amd.synth import pack_batch
+    ds, hc, dc = ds_a
+    rng = np.random.default_rng(2)
+    profs = [p.copy() for p in ds["profiles"]]
+    profs[3][100:140] = rng.integers(300, 32768, 40)          # 15-bit deltas
+    profs[5][:] = 17                                           # one value + runs only
+    profs[7][:] = rng.integers(0, 32768, len(profs[7]))       # back-to-back 2-byte tokens, second bytes with bit 7 set
+    profs[9][:] = np.repeat(rng.integers(0, 32768, len(profs[9]) // 50 + 1), 50)[:len(profs[9])]
+    profs[11][:] = np.where(rng.random(len(profs[11])) < 0.5, 40, 200)   # alternating 1-/2-byte deltas
+    seq, so, prof, po = pack_batch(ds["seqs"], profs)
+    codes, co = encode_profiles(profs)
+    clf = Classifier(K=K, read_len=10000, hcov=hc, dcov=dc)
+    d = clf.decode_profiles(codes, co, po)
+    got = d[:po[-1]].cpu().numpy().view(np.uint16)
+    assert np.array_equal(got, prof)
+    b = Batch(seq, so, prof, po)
+    want = clf.classify(b)
+    b.prof = d
+    assert np.array_equal(clf.classify(b), want)
+    bad = po.copy()
+    bad[1:] += 1                                               # read 0 now claims one more count than its code holds
+    with pytest.raises(ClassProError):
+        clf.decode_profiles(codes, co, bad)
+    empty = clf.decode_profiles(np.zeros(0, np.uint8), np.zeros(1, np.int64), np.zeros(1, np.int64))
+    assert empty is not None
+    clf.close()
