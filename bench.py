@@ -183,6 +183,17 @@ def main():
         torch.cuda.synchronize()
         decode_ms = e0.elapsed_time(e1) / 10
 
+        # ---- accuracy against the generator's ground truth (prof2class.c:210-229 mapping of the genomic
+        #      multiplicity of every k-mer: 0 E, 1 H, 2 D, >=3 R); what class2acc reports as "Accuracy" ----
+        tmap = np.full(32768, ord("R"), np.uint8)
+        tmap[0], tmap[1], tmap[2] = ord("E"), ord("H"), ord("D")
+        rel = np.concatenate(ds["rel_profiles"] * a.tile)
+        kpos = np.ones(b.total_bases, bool)
+        for k in range(39):
+            kpos[seq_off[:-1] + k] = False
+        est = lab[kpos]
+        acc = float((est == tmap[rel]).mean()) if len(rel) == len(est) else None
+
         # ---- CPU baseline: the oracle (a port, pthreads) on a bounded sample of the same workload --
         cpu = None
         if not a.no_cpu:
@@ -213,6 +224,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
             "extras": {"pcie_inclusive_mbases_per_s": round(b.total_bases / t_e2e / 1e6, 2),
                        "pcie_inclusive_pinned_codes_mbases_per_s": round(b.total_bases / min(t_codes) / 1e6, 2),
+                       "accuracy_vs_synthetic_truth": None if acc is None else round(acc, 5),
                        "code_bytes_per_base": round(len(codes) / b.total_bases, 4),
                        "decode_ms": round(decode_ms, 3), "decode_matches": decode_ok,
                        "h2d_seconds": round(t_h2d, 3), "gen_seconds": round(t_gen, 1),

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OUT = os.path.join(_HERE, "libclasspro_amd.so")
 CLI = os.path.join(_HERE, "ClassPro")          # drop-in command line (csrc/host/classpro_main.cpp)
+TOOLS = {"prof2class": "prof2class.cpp", "class2acc": "class2acc.cpp"}   # host-only evaluation tools
 # -ffp-contract=off: the decision path compares doubles against thresholds and truncates them to
 # ints (class_rel.c:449,483); fused multiply-adds would change those values.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
@@ -25,8 +26,9 @@ def _newest_src():
 
 
 def build(force=False, verbose=False):
-    if (not force and os.path.exists(OUT) and os.path.exists(CLI)
-            and min(os.path.getmtime(OUT), os.path.getmtime(CLI)) >= _newest_src()):
+    outs = [OUT, CLI] + [os.path.join(_HERE, t) for t in TOOLS]
+    if (not force and all(os.path.exists(o) for o in outs)
+            and min(os.path.getmtime(o) for o in outs) >= _newest_src()):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc] + FLAGS + [os.path.join(CSRC, "capi.hip"), "-o", OUT]
@@ -38,6 +40,12 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
+    for tool, src in TOOLS.items():
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-ffp-contract=off",
+               os.path.join(CSRC, "host", src), "-o", os.path.join(_HERE, tool), "-lz"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
     return OUT
 
 

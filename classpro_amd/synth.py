@@ -132,7 +132,10 @@ def make_dataset(genome_len=200_000, cov=40, read_len=10_000, K=40, het=0.002, e
         strand = int(rng.integers(0, 2))
         reads.append((codes, cls, strand))
 
-    seqs, profiles, names = [], [], []
+    # genomic multiplicity of every k-mer class over both haplotypes: the "relative profile" the
+    # reference's evaluation derives its ground truth from (prof2class.c: 0->E, 1->H, 2->D, >=3->R)
+    mult = np.bincount(np.concatenate([c.ravel() for c in classes]), minlength=ncls)
+    seqs, profiles, names, rel_profiles = [], [], [], []
     n_err_kmers = 0
     for i, (codes, cls, strand) in enumerate(reads):
         prof = np.ones(len(cls), np.int64)
@@ -140,11 +143,16 @@ def make_dataset(genome_len=200_000, cov=40, read_len=10_000, K=40, het=0.002, e
         prof[ok] = cover[cls[ok]]
         n_err_kmers += int((~ok).sum())
         prof = np.minimum(prof, 32767).astype(np.uint16)
+        rel = np.zeros(len(cls), np.int64)
+        rel[ok] = mult[cls[ok]]
+        rel = np.minimum(rel, 32767).astype(np.uint16)
         if strand:
             codes = _COMP[codes[::-1]]
             prof = prof[::-1].copy()
+            rel = rel[::-1].copy()
         seqs.append(BASES[codes].tobytes())
         profiles.append(prof)
+        rel_profiles.append(rel)
         names.append("read%d" % (i + 1))
 
     low, high = 1, 32767
@@ -152,7 +160,7 @@ def make_dataset(genome_len=200_000, cov=40, read_len=10_000, K=40, het=0.002, e
     cc = np.bincount(np.minimum(cover[cover > 0], high), minlength=high + 1)
     hist[:] = cc[low:high + 1]
     hist[0] += n_err_kmers
-    return dict(seqs=seqs, profiles=profiles, names=names, K=K,
+    return dict(seqs=seqs, profiles=profiles, names=names, K=K, rel_profiles=rel_profiles,
                 hist=(low, high, 0, 0, hist), genome_len=G, read_len=read_len)
 
 

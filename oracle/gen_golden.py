@@ -137,10 +137,39 @@ def fastk_files():
                         codes=np.frombuffer(b"".join(codes), np.uint8), code_off=coff)
 
 
+def eval_tools():
+    """Outputs of the reference's own prof2class / class2acc (built by oracle/Makefile into oracle/_ref/)
+    on the scenario of tests/eval_case.py."""
+    import json, subprocess, tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import eval_case
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    out = dict(cases=[])
+    for tiny in (True, False):
+        with tempfile.TemporaryDirectory() as d:
+            eval_case.build_case(d, eval_case.oracle_labels, tiny)
+            subprocess.check_call([os.path.join(ref, "prof2class"), os.path.join(d, "truth"), os.path.join(d, "reads.fasta")])
+            out["est_sha256_%d" % tiny] = eval_case.sha(os.path.join(d, "est.class"))
+            out["truth_sha256_%d" % tiny] = eval_case.sha(os.path.join(d, "truth.class"))
+            for t, args in eval_case.ACC_CASES:
+                if t != tiny:
+                    continue
+                a = [x.format(dir=d) for x in args]
+                r = subprocess.run([os.path.join(ref, "class2acc")] + a + [os.path.join(d, "est.class"), os.path.join(d, "truth.class")],
+                                   capture_output=True, text=True)
+                out["cases"].append(dict(tiny=tiny, args=args, returncode=r.returncode, stdout=r.stdout,
+                                         stderr=r.stderr.replace(d, "{dir}")))
+            if tiny:                                                   # error contract
+                r = subprocess.run([os.path.join(ref, "class2acc"), os.path.join(d, "est.class")], capture_output=True, text=True)
+                out["usage_stderr"] = r.stderr
+                out["usage_returncode"] = r.returncode
+    json.dump(out, open(os.path.join(OUT, "eval_tools.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     if not ref_available() and not os.path.exists("/root/reference/src/ClassPro.h"):
         sys.exit("oracle/_ref is not built and /root/reference is absent")
     os.makedirs(OUT, exist_ok=True)
-    prims(); context(); classify(); fastk_files()
+    prims(); context(); classify(); fastk_files(); eval_tools()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
