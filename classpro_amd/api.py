@@ -37,6 +37,13 @@ def decode_profile(code, cap=60000):
     return n, out[:min(n, cap)]
 
 
+def load_error_model(path):
+    """-M: pe[t][l] fitted from a HIsim error-model file (wall.c:55-115); double[3][21]."""
+    pe = np.zeros((3, 21), np.float64)
+    check(lib().cp_load_error_model(path.encode(), pe.ctypes.data))
+    return pe
+
+
 def encode_profiles(profiles):
     """FASTK code strings for a list of count arrays: (uint8 codes, int64 code_off[n+1])."""
     L = lib()
@@ -77,7 +84,7 @@ class Batch:
 class Classifier:
     """Global setup (ClassPro.c:536-554) + batched hot path."""
 
-    def __init__(self, K=40, read_len=20000, hcov=20, dcov=40, device="cuda:0"):
+    def __init__(self, K=40, read_len=20000, hcov=20, dcov=40, device="cuda:0", model=None):
         self.L = lib()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -85,7 +92,7 @@ class Classifier:
         torch.cuda.set_device(self.device)
         self.K, self.read_len = K, read_len
         p = C.c_void_p()
-        check(self.L.cp_params_create(K, read_len, hcov, dcov, C.byref(p)))
+        check(self.L.cp_params_create_model(K, read_len, hcov, dcov, model.encode() if model else None, C.byref(p)))
         self.p = p
         w = C.c_void_p()
         check(self.L.cp_workspace_create(C.byref(w)))

@@ -40,10 +40,31 @@ extern "C" int cp_hist_covs(const int64_t *hist, int low, int high, int64_t ilow
 }
 
 extern "C" int cp_params_create(int K, int read_len, int hcov, int dcov, cp_params **out)
+{ return cp_params_create_model(K,read_len,hcov,dcov,NULL,out); }
+
+extern "C" int cp_load_error_model(const char *model_path, double *pe63)
+{ if (!model_path || !pe63) return set_err(CP_EINVAL,"cp_load_error_model: null argument");
+  char msg[512];
+  double pe[3][21];
+  memset(pe,0,sizeof(pe));
+  int rc = cp_host_load_himodel(model_path,pe,msg,sizeof(msg));
+  if (rc != CP_OK) return set_err(rc,msg);
+  memcpy(pe63,pe,sizeof(pe));
+  return CP_OK;
+}
+
+extern "C" int cp_params_create_model(int K, int read_len, int hcov, int dcov, const char *model_path, cp_params **out)
 { if (!out) return set_err(CP_EINVAL,"cp_params_create: null out");
+  double pe[3][21];
+  if (model_path)
+    { char msg[512];
+      memset(pe,0,sizeof(pe));
+      int rc = cp_host_load_himodel(model_path,pe,msg,sizeof(msg));
+      if (rc != CP_OK) return set_err(rc,msg);
+    }
   cp_params *p = (cp_params *)malloc(sizeof(cp_params));
   if (!p) return set_err(CP_ENOMEM,"cp_params_create: out of memory");
-  int rc = cp_host_fill_params(&p->host,K,read_len,hcov,dcov);
+  int rc = cp_host_fill_params(&p->host,K,read_len,hcov,dcov,model_path ? pe : nullptr);
   if (rc != CP_OK)
     { char buf[128];
       if (rc == CP_ERCOV) snprintf(buf,sizeof(buf),"Too high REPEAT coverage (%d) > 255",p->host.cov[CP_REPEAT]);

@@ -4,6 +4,7 @@
 // uploaded to HBM once and read by every kernel.
 #pragma once
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <cstdlib>
 #include <vector>
@@ -65,7 +66,64 @@ static inline int cp_host_hist_covs(const int64_t *disk, int low, int high, int6
   return CP_OK;
 }
 
-static inline int cp_host_fill_params(cp_dev_params *P, int K, int read_len, int hcov, int dcov)
+// -M<model_path>: HIsim error model -> pe[t][l] (load_himodel, wall.c:55-115).  File layout: int kmer;
+// 0x4000 heptamer records of 11 floats (skipped, as in the reference); then for unit length 1,2,3 a table of
+// 4^ulen x (kmer/2-6) micro-satellite records of 7 floats, first float = overall error rate, row i =
+// unit sequence, column c = run length 2*ulen+c.  For j = 2..5 unit copies y[j] is the mean positive
+// rate over unit sequences; y[1] is fixed at 0.002; pe[t][l] = c0 + c1 l + c2 l^2 is the least-squares
+// quadratic through (1..5, y).  The reference calls GSL's gsl_multifit_linear for the fit (wall.c:11-41);
+// x = 1..5 is fixed, so the normal equations have the constant matrix below and are solved exactly in
+// long double arithmetic here -- the same minimiser, no GSL.  (Parity of the fit itself is unpinned: the
+// reference's wall.c cannot be built in this image and its tree holds no model file.)
+static inline int cp_host_load_himodel(const char *path, double pe[3][21], char *msg, size_t msglen)
+{ FILE *f = fopen(path,"rb");
+  if (!f) { snprintf(msg,msglen,"Cannot open error model %s",path); return CP_EINVAL; }
+  int kmer = 0;
+  if (fread(&kmer,4,1,f) != 1) { fclose(f); snprintf(msg,msglen,"Error model %s is truncated",path); return CP_EINVAL; }
+  const int krange = kmer/2-6;
+  if (krange < 1 || krange > 4096 || fseek(f,44L*0x4000,SEEK_CUR) != 0)
+    { fclose(f); snprintf(msg,msglen,"Error model %s: bad k-mer length %d",path,kmer); return CP_EINVAL; }
+  for (int t = 0; t < 3; t++)
+    { const int ulen = t+1, N = 1 << (2*ulen);
+      std::vector<float> tab((size_t)7*N*krange);
+      if (fread(tab.data(),28,(size_t)N*krange,f) != (size_t)N*krange)
+        { fclose(f); snprintf(msg,msglen,"Error model %s is truncated",path); return CP_EINVAL; }
+      double y[6];
+      y[1] = 0.002;
+      for (int j = 2; j <= 5; j++)
+        { if ((j-2)*ulen >= krange)
+            { fclose(f); snprintf(msg,msglen,"Error model %s: k-mer length %d too short for the fit",path,kmer); return CP_EINVAL; }
+          double sum = 0.; int n = 0;
+          for (int i = 0; i < N; i++)
+            { double p = tab[(size_t)7*(krange*i+(j-2)*ulen)];
+              if (p > 0.) { sum += p; n++; }
+            }
+          y[j] = sum/n;
+        }
+      // normal equations  (X^T X) c = X^T y  with X = [1 x x^2], x = 1..5
+      long double M[3][4] = { { 5, 15, 55, 0 }, { 15, 55, 225, 0 }, { 55, 225, 979, 0 } };
+      for (int j = 1; j <= 5; j++)
+        { M[0][3] += (long double)y[j]; M[1][3] += (long double)y[j]*j; M[2][3] += (long double)y[j]*j*j; }
+      for (int k = 0; k < 3; k++)
+        for (int r = 0; r < 3; r++)
+          if (r != k)
+            { long double q = M[r][k]/M[k][k];
+              for (int c = k; c < 4; c++) M[r][c] -= q*M[k][c];
+            }
+      const double c0 = (double)(M[0][3]/M[0][0]), c1 = (double)(M[1][3]/M[1][1]), c2 = (double)(M[2][3]/M[2][2]);
+      pe[t][0] = 0.;
+      for (int l = 1; l <= CP_MAX_N_LC/(t+1); l++)
+        { pe[t][l] = c0+c1*l+c2*l*l;                          // wall.c:102-103
+          if (!(pe[t][l] > 0. && pe[t][l] < 1.))
+            { fclose(f); snprintf(msg,msglen,"Error model %s gives an error rate outside (0,1) (%g for unit %d x %d)",path,pe[t][l],ulen,l); return CP_EINVAL; }
+        }
+    }
+  fclose(f);
+  return CP_OK;
+}
+
+static inline int cp_host_fill_params(cp_dev_params *P, int K, int read_len, int hcov, int dcov,
+                                      const double (*model_pe)[21] = nullptr)
 { memset(P,0,sizeof(*P));
   if (K < 2 || read_len < 1 || hcov < 1 || dcov < 1 || dcov > 65535)
     return CP_EINVAL;
@@ -94,7 +152,7 @@ static inline int cp_host_fill_params(cp_dev_params *P, int K, int read_len, int
       P->lpe[t][0] = log(0.0);
       P->l1mpe[t][0] = log(1.0);
       for (int l = 1; l <= P->lmax[t]; l++)
-        { double pe = 0.002 * l * l + 0.002;
+        { double pe = model_pe ? model_pe[t][l] : 0.002 * l * l + 0.002;
           P->pe[t][l]    = pe;
           P->lpe[t][l]   = log(pe);
           P->l1mpe[t][l] = log(1-pe);

@@ -13,7 +13,7 @@
 // the GPU works on one batch the host stages the next one.
 //
 // Not supported yet (rows "next" of SURVEY.md section 8f; the reference's behaviour is exit(1) with a
-// message, so is ours): .db/.dam inputs, -s (needs .db), -M (HIsim model + polynomial fit).
+// message, so is ours): .db/.dam inputs, -s (needs .db).
 // -T is accepted for compatibility; the device does the work, -T only sizes nothing here.
 #include <hip/hip_runtime.h>
 #include <zlib.h>
@@ -119,8 +119,6 @@ int main(int argc, char **argv)
     die("%s: .db/.dam inputs are not supported by this build (FASTX only)\n",PROG);
   if (seeds)
     die("%s: -s requires a .db/.dam input, which this build does not support\n",PROG);
-  if (!model_path.empty())
-    die("%s: -M error-model files are not supported by this build\n",PROG);
   if (fk_root.empty()) fk_root = path+"/"+root;
   source = path+"/"+root+EXT[idx];
   const std::string out_path = path+"/"+root+".class";
@@ -165,12 +163,13 @@ int main(int argc, char **argv)
       fprintf(stderr,cov > 0 ? "    Specified (H,D) cov   = (%d,%d)\n" : "    Estimated (H,D) cov   = (%d,%d)\n",hcov,dcov);
   }
   cp_params *params;
-  CPOK(cp_params_create(K,rlen_opt,hcov,dcov,&params));
+  CPOK(cp_params_create_model(K,rlen_opt,hcov,dcov,model_path.empty() ? NULL : model_path.c_str(),&params));
   { int c4[4];
     cp_params_export(params,c4,NULL,NULL,NULL,NULL,NULL,NULL);
     if (verbose)
       { fprintf(stderr,"    Estimated R-threshold = %d\n",c4[CP_REPEAT]);
-        fprintf(stderr,"Error model not specified. Using the default error model.\n");
+        if (model_path.empty())
+          fprintf(stderr,"Error model not specified. Using the default error model.\n");
         fprintf(stderr,"Classifying %d-mers...\n",K);
       }
   }

@@ -175,3 +175,34 @@ def pack_batch(seqs, profiles):
     seq = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
     prof = np.concatenate(profiles).astype(np.uint16) if n else np.zeros(0, np.uint16)
     return seq, seq_off, prof, prof_off
+
+
+def write_himodel(path, kmer=40, seed=7, base=(0.004, 0.003, 0.0025), growth=(0.0016, 0.0022, 0.003)):
+    """A synthetic HIsim error-model file in the layout load_himodel reads (wall.c:43-84): int kmer,
+    0x4000 heptamer records (11 floats), then per unit length 1..3 a 4^ulen x (kmer/2-6) table of
+    7-float micro-satellite records whose first float is the error rate of `2*ulen+c` bases of that
+    unit.  Rates grow quadratically with the number of unit copies, with per-unit noise and some
+    empty (0) cells, which the loader must skip.  Returns the per-type mean rates y[2..5] it wrote."""
+    rng = np.random.default_rng(seed)
+    krange = kmer // 2 - 6
+    ys = []
+    with open(path, "wb") as f:
+        f.write(np.int32(kmer).tobytes())
+        f.write(rng.random((0x4000, 11), dtype=np.float32).tobytes())
+        for t in range(3):
+            ulen = t + 1
+            N = 1 << (2 * ulen)
+            tab = np.zeros((N, krange, 7), np.float32)
+            for c in range(krange):
+                copies = (2 * ulen + c) / ulen
+                rate = base[t] + growth[t] * copies * copies
+                tab[:, c, 0] = (rate * (1 + 0.2 * rng.standard_normal(N))).clip(1e-5, 0.9)
+                tab[:, c, 1:] = rng.random((N, 6), dtype=np.float32) * 0.01
+            tab[rng.random((N, krange)) < 0.1, 0] = 0.0            # unobserved cells
+            f.write(tab.tobytes())
+            y = []
+            for j in range(2, 6):
+                col = tab[:, (j - 2) * ulen, 0].astype(np.float64)
+                y.append(col[col > 0].sum() / (col > 0).sum())
+            ys.append(y)
+    return np.array(ys)

@@ -72,6 +72,14 @@ int cp_hist_covs(const int64_t *hist, int low, int high, int64_t ilowcnt, int64_
  * CP_ERCOV when the repeat threshold exceeds 255 (wall.c:174-177). */
 typedef struct cp_params cp_params;
 int  cp_params_create(int K, int read_len, int hcov, int dcov, cp_params **out);
+
+/* -M<model_path> (ClassPro.c:451-453, load_himodel wall.c:55-115): as cp_params_create, with the
+ * low-complexity error rates pe[t][l] fitted from a HIsim error-model file instead of the default
+ * 0.002 l^2 + 0.002.  model_path == NULL is the default model.  The quadratic fit the reference does
+ * with GSL is solved in closed form here (no GSL).  cp_load_error_model returns just the fitted table
+ * (pe63 = double[3][21], rows HP/DS/TS). */
+int  cp_params_create_model(int K, int read_len, int hcov, int dcov, const char *model_path, cp_params **out);
+int  cp_load_error_model(const char *model_path, double *pe63);
 void cp_params_destroy(cp_params *p);
 /* Host copies of the tables, for inspection/tests: cov[4]=GLOBAL_COV[E,R,H,D]; cthres is
  * [3][21][256][2][2] = [ctype][l][cout][INIT|FINAL][SELF|OTHERS]; pe is [3][21]; logfact[32768]. */

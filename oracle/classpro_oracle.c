@@ -196,6 +196,88 @@ double cpo_logp_trans(const cpo_params *p, int b, int e, int cb, int ce, int cov
 /* ------------------------------------------------------------------------------------------
  *  Global setup: ClassPro.c:536-554, prob.c:14-19, wall.c:117-244
  * ------------------------------------------------------------------------------------------ */
+/* load_himodel (wall.c:55-115): HIsim error model -> pe[t][l] by a quadratic fit of the mean error rate of
+ * 2..5 unit copies (plus the fixed point (1, 0.002)).  The reference fits with GSL's gsl_multifit_linear
+ * (wall.c:11-41), which is not in this image: the fit below solves the same least-squares problem with a
+ * Householder QR in double -- PARITY UNPINNED for this function (no GSL, no model file in the reference
+ * tree); the two agree to rounding.  Returns 0, or -1 when the file cannot be read. */
+typedef struct { float all, ins, op[9]; } hi_erates;     /* wall.c:43-47 */
+typedef struct { float all, op[6]; } hi_mrates;          /* wall.c:49-52 */
+
+static void quad_fit5(const double *x, const double *y, double *coef)
+{ double A[5][3], b[5];
+  for (int i = 0; i < 5; i++)
+    { A[i][0] = 1.; A[i][1] = x[i]; A[i][2] = x[i]*x[i]; b[i] = y[i]; }
+  for (int k = 0; k < 3; k++)                            /* Householder reflections, column by column */
+    { double nrm = 0.;
+      for (int i = k; i < 5; i++) nrm += A[i][k]*A[i][k];
+      nrm = sqrt(nrm);
+      double alpha = (A[k][k] > 0) ? -nrm : nrm;
+      double v[5] = {0,0,0,0,0};
+      for (int i = k; i < 5; i++) v[i] = A[i][k];
+      v[k] -= alpha;
+      double vv = 0.;
+      for (int i = k; i < 5; i++) vv += v[i]*v[i];
+      if (vv == 0.) continue;
+      for (int j = k; j < 3; j++)
+        { double d = 0.;
+          for (int i = k; i < 5; i++) d += v[i]*A[i][j];
+          d = 2*d/vv;
+          for (int i = k; i < 5; i++) A[i][j] -= d*v[i];
+        }
+      double d = 0.;
+      for (int i = k; i < 5; i++) d += v[i]*b[i];
+      d = 2*d/vv;
+      for (int i = k; i < 5; i++) b[i] -= d*v[i];
+    }
+  for (int k = 2; k >= 0; k--)
+    { double t = b[k];
+      for (int j = k+1; j < 3; j++) t -= A[k][j]*coef[j];
+      coef[k] = t/A[k][k];
+    }
+}
+
+int cpo_load_himodel(const char *path, double *pe63)
+{ FILE *f = fopen(path,"rb");
+  if (f == NULL) return -1;
+  int kmer;
+  if (fread(&kmer,sizeof(int),1,f) != 1) { fclose(f); return -1; }
+  const int krange = kmer/2-6;
+  if (krange < 1 || krange > 1000 || fseek(f,(long)sizeof(hi_erates)*0x4000,SEEK_CUR) != 0) { fclose(f); return -1; }
+  double x[5] = {1,2,3,4,5}, y[5], coef[3];
+  y[0] = 0.002;
+  for (int t = 0; t < 3; t++)
+    { int ulen = t+1, N = 1 << (2*ulen);
+      hi_mrates *m = malloc(sizeof(hi_mrates)*N*krange);
+      if (fread(m,sizeof(hi_mrates),(size_t)N*krange,f) != (size_t)N*krange) { free(m); fclose(f); return -1; }
+      for (int j = 2; j <= 5; j++)                       /* wall.c:87-99; mics[t] is biased by -2*ulen */
+        { double sum = 0.; int n = 0;
+          for (int i = 0; i < N; i++)
+            { double p = m[krange*i+(j-2)*ulen].all;
+              if (p > 0.) { sum += p; n++; }
+            }
+          y[j-1] = sum/n;
+        }
+      free(m);
+      quad_fit5(x,y,coef);
+      int lmax = MAX_N_LC/(t+1);
+      pe63[t*21] = 0.;
+      for (int l = 1; l <= lmax; l++)
+        pe63[t*21+l] = coef[0]+coef[1]*l+coef[2]*l*l;
+    }
+  fclose(f);
+  return 0;
+}
+
+static const double *g_pe_override = NULL;               /* set only inside cpo_params_new_model */
+
+cpo_params *cpo_params_new_model(int K, int read_len, int hcov, int dcov, const double *pe63)
+{ g_pe_override = pe63;
+  cpo_params *p = cpo_params_new(K,read_len,hcov,dcov);
+  g_pe_override = NULL;
+  return p;
+}
+
 cpo_params *cpo_params_new(int K, int read_len, int hcov, int dcov)
 { cpo_params *p = calloc(1,sizeof(cpo_params));
   p->K = K;
@@ -222,7 +304,7 @@ cpo_params *cpo_params_new(int K, int read_len, int hcov, int dcov)
     { p->lmax[t] = (uint8_t)(MAX_N_LC/(t+1));
       p->pe[t][0] = 0.;
       for (int l = 1; l <= p->lmax[t]; l++)
-        p->pe[t][l] = 0.002 * l * l + 0.002;
+        p->pe[t][l] = g_pe_override ? g_pe_override[t*21+l] : 0.002 * l * l + 0.002;
     }
   p->hc_erate = p->pe[CPO_HP][1];                   /* wall.c:180 */
 

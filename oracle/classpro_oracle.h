@@ -61,6 +61,9 @@ typedef struct
   } cpo_params;
 
 cpo_params *cpo_params_new(int K, int read_len, int hcov, int dcov);
+/* -M<model>: wall.c:55-115 (fit restated without GSL: parity unpinned for the fit itself) */
+int cpo_load_himodel(const char *path, double *pe63);
+cpo_params *cpo_params_new_model(int K, int read_len, int hcov, int dcov, const double *pe63);
 void        cpo_params_free(cpo_params *p);
 const uint8_t *cpo_params_cthres(const cpo_params *p);     /* flat [3][21][256][2][2] */
 const double  *cpo_params_logfact(const cpo_params *p);

@@ -37,7 +37,7 @@ def _p(a, t):
 
 
 class Oracle:
-    def __init__(self, K=40, read_len=20000, hcov=20, dcov=40):
+    def __init__(self, K=40, read_len=20000, hcov=20, dcov=40, model=None):
         build()
         L = C.CDLL(os.path.join(_HERE, "libclasspro_oracle.so"))
         self.L = L
@@ -65,7 +65,17 @@ class Oracle:
         L.cpo_decode_profile.restype = C.c_int
         L.cpo_hist_covs.restype = C.c_int
         self.K, self.read_len = K, read_len
-        self.p = L.cpo_params_new(K, read_len, hcov, dcov)
+        if model is None:
+            self.p = L.cpo_params_new(K, read_len, hcov, dcov)
+        else:
+            pe = np.zeros(63, np.float64)
+            L.cpo_load_himodel.argtypes = [C.c_char_p, C.c_void_p]
+            if L.cpo_load_himodel(model.encode(), pe.ctypes.data) != 0:
+                raise IOError("cannot load error model %s" % model)
+            L.cpo_params_new_model.restype = C.c_void_p
+            L.cpo_params_new_model.argtypes = [C.c_int] * 4 + [C.c_void_p]
+            self.p = L.cpo_params_new_model(K, read_len, hcov, dcov, pe.ctypes.data)
+            self.model_pe = pe.reshape(3, 21)
         if not self.p:
             raise ValueError("REPEAT coverage > 255 (reference exits, wall.c:174)")
 

@@ -334,3 +334,31 @@ def test_device_profile_decode(torch_dev, ds_a):
     empty = clf.decode_profiles(np.zeros(0, np.uint8), np.zeros(1, np.int64), np.zeros(1, np.int64))
     assert empty is not None
     clf.close()
+
+
+def test_error_model_option(torch_dev, tmp_path):
+    """-M<model>: thresholds and labels under a HIsim error model (wall.c:55-115) equal the oracle's under
+    the same model (fits agree to 1e-12, see tests/test_error_model.py), and differ from the default model's."""
+    from classpro_amd import synth
+    from classpro_amd.api import Classifier, Batch
+    from oracle.oracle import Oracle
+    path = str(tmp_path / "hifi.model")
+    synth.write_himodel(path, growth=(0.0004, 0.0005, 0.0006))
+    ds = synth.make_dataset(genome_len=100000, cov=40, read_len=8000, seed=12, err_indel=0.002)
+    clf = Classifier(K=K, read_len=20000, hcov=20, dcov=40, model=path)
+    clf0 = Classifier(K=K, read_len=20000, hcov=20, dcov=40)
+    O = Oracle(K, 20000, 20, 40, model=path)
+    seqs, profs = [], []
+    want = []
+    for s, p in zip(ds["seqs"], ds["profiles"]):
+        try:
+            want.append(O.classify_read(s, p))
+        except OverflowError:
+            continue
+        seqs.append(s); profs.append(p)
+    b = Batch.from_reads(seqs, profs)
+    got = clf.classify(b)
+    assert got.tobytes() == b"".join(want)
+    assert clf0.classify(b).tobytes() != got.tobytes()
+    np.testing.assert_allclose(clf.export()["pe"], O.model_pe, rtol=FLOAT_RTOL)
+    clf.close(); clf0.close()
