@@ -12,8 +12,9 @@
 // them with hipMemcpyAsync, calls cp_classify_batch, and writes the records in input order.  While
 // the GPU works on one batch the host stages the next one.
 //
-// Not supported yet (rows "next" of SURVEY.md section 8f; the reference's behaviour is exit(1) with a
-// message, so is ours): .db/.dam inputs, -s (needs .db).
+// Sources: FASTX (kseq semantics) or a Dazzler .db/.dam (dazz_db.h); for a database the labels are also
+// written as the DAZZ_DB track .<root>.class.anno/.data (and the header-only .<root>.rep.* mask track).
+// Not supported yet: -s (seed selection, seed.c; exits with a message).
 // -T is accepted for compatibility; the device does the work, -T only sizes nothing here.
 #include <hip/hip_runtime.h>
 #include <zlib.h>
@@ -31,6 +32,7 @@
 #include <chrono>
 #include "../../../include/classpro_amd.h"
 #include "host_io.h"
+#include "dazz_db.h"
 
 static const char *USAGE = "[-vs] [-T<int(4)>] [-c<int>] [-r<int(20000)>] "
                            "[-P<tmp_dir(./)>] [-N<fastk_root>] [-M<model_path>] "
@@ -115,10 +117,9 @@ int main(int argc, char **argv)
     die("Cannot open %s as a .db|.dam or .f{ast}[aq][.gz] file\n",pos[0].c_str());
   if (pos.size() != 1)
     die(idx <= 1 ? "Only single file is accepted for .db and .dam\n" : "Currently only single file is accepted for FASTX input\n");
-  if (idx <= 1)
-    die("%s: .db/.dam inputs are not supported by this build (FASTX only)\n",PROG);
+  const bool is_db = idx <= 1, is_dam = idx == 1;
   if (seeds)
-    die("%s: -s requires a .db/.dam input, which this build does not support\n",PROG);
+    die("%s: -s (seed selection, seed.c) is not supported by this build\n",PROG);
   if (fk_root.empty()) fk_root = path+"/"+root;
   source = path+"/"+root+EXT[idx];
   const std::string out_path = path+"/"+root+".class";
@@ -174,8 +175,20 @@ int main(int argc, char **argv)
       }
   }
 
-  FastxReader fx(source.c_str());
+  FastxReader fx(is_db ? "/dev/null" : source.c_str());
   if (!fx.f) die("%s: Cannot open %s\n",PROG,source.c_str());
+  DazzDB db;
+  ClassTrack class_track, rep_track;
+  if (is_db)                                                               // prepare_db, io.c:123-313
+    { db.open(source,is_dam);
+      if (P.nreads != db.nreads)
+        die("Inconsistent # of reads: .prof (%d) != .db (%d)\n",(int)P.nreads,db.nreads);
+      if (db.maxlen > CP_MAX_READ_LEN)
+        die("%s: longest read of the DB (%d) > %d, the longest read this build classifies\n",PROG,db.maxlen,CP_MAX_READ_LEN);
+      class_track.open(path,root,"class",db.nreads,8);
+      rep_track.open(path,root,"rep",db.nreads,0);                         // repeat mask track: written by -s only
+      rep_track.close();
+    }
   FILE *out = fopen(out_path.c_str(),"w");
   if (!out) die("Cannot open %s\n",out_path.c_str());
   std::vector<char> obuf(1 << 22);
@@ -194,13 +207,21 @@ int main(int argc, char **argv)
       while (more && (size_t)b.bases < BATCH_BASES && (size_t)b.n < BATCH_READS)
         { if (id >= P.nreads) { more = false; break; }
           if ((size_t)b.codes+2*(size_t)CP_MAX_READ_LEN+2 > b.cap_code) break;
-          int rlen = fx.next();
-          if (rlen < 0)
-            die("Cannot load %lld-th read\n",(long long)id+1);
-          if (rlen > CP_MAX_READ_LEN)
-            die("rlen (%d) > MAX_READ_LEN for FASTX inputs (%d)\n",rlen,CP_MAX_READ_LEN);
-          // header "@name comment": kseq keeps the previous comment when a record has none (ClassPro.c:188)
-          b.headers.push_back("@"+fx.name+" "+(fx.have_comment ? fx.comment : std::string("(null)")));
+          int rlen;
+          if (is_db)                                                       // ClassPro.c:161-180
+            { db.load((int)id,fx.seq);
+              rlen = (int)fx.seq.size();
+              b.headers.push_back(db.header((int)id));
+            }
+          else
+            { rlen = fx.next();
+              if (rlen < 0)
+                die("Cannot load %lld-th read\n",(long long)id+1);
+              if (rlen > CP_MAX_READ_LEN)
+                die("rlen (%d) > MAX_READ_LEN for FASTX inputs (%d)\n",rlen,CP_MAX_READ_LEN);
+              // header "@name comment": kseq keeps the previous comment when a record has none (ClassPro.c:188)
+              b.headers.push_back("@"+fx.name+" "+(fx.have_comment ? fx.comment : std::string("(null)")));
+            }
           const uint8_t *code; int64_t clen;
           P.fetch(id,&code,&clen);
           if (rlen <= Km1)                            // ClassPro.c:209-226: printed by the host, not classified
@@ -260,12 +281,15 @@ int main(int argc, char **argv)
               fwrite(s.data(),1,s.size(),out); fputs("\n+\n",out);
               for (size_t k = 0; k < s.size(); k++) fputc('N',out);
               fputc('\n',out);
+              if (is_db)
+                { std::string n(s.size(),'N'); class_track.add(n.data(),(int)n.size()); }
             }
           else
             { int i = b.slot[r];
               size_t o = (size_t)b.h_soff[i], l = (size_t)(b.h_soff[i+1]-b.h_soff[i]);
               fwrite(b.h_seq+o,1,l,out); fputs("\n+\n",out);
               fwrite(b.h_lab+o,1,l,out); fputc('\n',out);
+              if (is_db) class_track.add(b.h_lab+o,(int)l);
             }
         }
       total_bases += b.bases;
@@ -281,6 +305,7 @@ int main(int argc, char **argv)
       have = have_next;
     }
   fclose(out);
+  class_track.close();
 
   if (verbose)
     { double s = std::chrono::duration<double>(std::chrono::steady_clock::now()-t_start).count();

@@ -4,10 +4,11 @@
 // Same process contract as the reference tool (src/prof2class.c:19, 62-66, 203-253):
 //   prof2class <relative_profile>[.prof] <source>[.db|.dam|.f[ast][aq][.gz]]
 // writes <dir of profile>/<profile root>.class with one "@name comment\nseq\n+\nlabels\n" record per
-// read, K-1 leading 'N's.  .db/.dam sources are not supported yet.
+// read, K-1 leading 'N's.  Sources: FASTX (kseq semantics) or a Dazzler .db/.dam (dazz_db.h).
 #include <fcntl.h>
 #include <unistd.h>
 #include "host_io.h"
+#include "dazz_db.h"
 #include "../cp_host_setup.h"
 
 static const char *EXT[10] = { ".db", ".dam", ".fastq", ".fasta", ".fq", ".fa",
@@ -37,30 +38,47 @@ int main(int argc, char **argv)
     }
   if (idx == 10)
     die("Cannot open %s as a .db|.dam or .f{ast}[aq][.gz] file\n",pos[1].c_str());
-  if (idx <= 1)
-    die("%s: .db/.dam sources are not supported by this build; give the FASTX file\n",PROG);
+  const bool is_db = idx <= 1, is_dam = idx == 1;
 
   Profiles P;
   if (!P.open(pos[0]))
     die("%s: Cannot open %s as a .prof file\n",PROG,pos[0].c_str());
-  FastxReader fx(source.c_str());
+  FastxReader fx(is_db ? "/dev/null" : source.c_str());
   if (!fx.f) die("%s: Cannot open %s\n",PROG,source.c_str());
+  DazzDB db;
+  if (is_db)
+    { db.open(source,is_dam);
+      if (P.nreads != db.nreads)                                           // prof2class.c:111-114
+        die("Inconsistent # of reads: .prof (%d) != .db (%d)\n",(int)P.nreads,db.nreads);
+    }
   std::vector<char> obuf(1 << 22);
   setvbuf(out,obuf.data(),_IOFBF,obuf.size());
 
-  const int Km1 = P.kmer-1, rlen_max = 60000;                              // prof2class.c:159
-  std::vector<uint16_t> profile(rlen_max+1);
-  std::string asgn;
+  const int Km1 = P.kmer-1, rlen_max = is_db ? db.maxlen : 60000;          // prof2class.c:154-160
+  std::vector<uint16_t> profile(60001);
+  std::string asgn, header;
   for (int64_t id = 0; id < P.nreads; id++)
-    { int rlen = fx.next();
-      if (rlen < 0) { rlen = 0; fx.seq.clear(); }                          // the reference does not check kseq_read here
+    { int rlen;
+      if (is_db)
+        { db.load((int)id,fx.seq);
+          rlen = (int)fx.seq.size();
+          header = db.header((int)id);
+        }
+      else
+        { rlen = fx.next();
+          if (rlen < 0) { rlen = 0; fx.seq.clear(); }                      // the reference does not check kseq_read here
+          header = "@"+fx.name+" "+(fx.have_comment ? fx.comment : std::string("(null)"));
+        }
       if (rlen > rlen_max)
         die("rlen (%d) > rlen_max (%d)\n",rlen,rlen_max);
       const uint8_t *code; int64_t clen;
       P.fetch(id,&code,&clen);
-      int plen = cp_host_decode_profile(code,clen,profile.data(),rlen_max+1);
-      if (plen > rlen_max+1) plen = rlen_max+1;
-      fprintf(out,"@%s %s\n",fx.name.c_str(),fx.have_comment ? fx.comment.c_str() : "(null)");
+      int plen = cp_host_decode_profile(code,clen,profile.data(),(int)profile.size());
+      if (plen > (int)profile.size())                                      // prof2class.c:180-184
+        { profile.resize((size_t)plen);
+          cp_host_decode_profile(code,clen,profile.data(),plen);
+        }
+      fputs(header.c_str(),out); fputc('\n',out);
       fwrite(fx.seq.data(),1,fx.seq.size(),out);
       fputs("\n+\n",out);
       if (rlen <= Km1)                                                     // prof2class.c:203-208

@@ -166,10 +166,25 @@ def eval_tools():
     json.dump(out, open(os.path.join(OUT, "eval_tools.json"), "w"), indent=1)
 
 
+def dazz_db():
+    """sha256 of the reference prof2class output on the .db / .dam scenarios of tests/test_dazz_db.py."""
+    import json, subprocess, tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import eval_case, test_dazz_db as t
+    out = {}
+    for dam in (False, True):
+        with tempfile.TemporaryDirectory() as d:
+            t.make_case(d, dam)
+            src = os.path.join(d, "reads.dam" if dam else "reads.db")
+            subprocess.check_call([os.path.join(ROOT, "oracle", "_ref", "prof2class"), os.path.join(d, "truth"), src])
+            out["prof2class_sha256_dam" if dam else "prof2class_sha256_db"] = eval_case.sha(os.path.join(d, "truth.class"))
+    json.dump(out, open(os.path.join(OUT, "dazz_db.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     if not ref_available() and not os.path.exists("/root/reference/src/ClassPro.h"):
         sys.exit("oracle/_ref is not built and /root/reference is absent")
     os.makedirs(OUT, exist_ok=True)
-    prims(); context(); classify(); fastk_files(); eval_tools()
+    prims(); context(); classify(); fastk_files(); eval_tools(); dazz_db()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

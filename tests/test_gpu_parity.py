@@ -362,3 +362,45 @@ def test_error_model_option(torch_dev, tmp_path):
     assert clf0.classify(b).tobytes() != got.tobytes()
     np.testing.assert_allclose(clf.export()["pe"], O.model_pe, rtol=FLOAT_RTOL)
     clf.close(); clf0.close()
+
+
+@pytest.mark.parametrize("dam", [False, True], ids=["db", "dam"])
+def test_cli_on_dazzler_database(torch_dev, tmp_path, dam):
+    """ClassPro on a .db / .dam (ClassPro.c:161-180, 290-304; io.c:123-313): .class records with the DB
+    headers and oracle labels, plus the .class track (2-bit labels) and the header-only .rep track."""
+    import os
+    import subprocess
+    from classpro_amd import synth, fastk, dazz, build
+    from classpro_amd.api import hist_covs
+    from oracle.oracle import Oracle
+    ds = synth.make_dataset(genome_len=120000, cov=40, read_len=8000, seed=78)
+    seqs, profs = list(ds["seqs"]), list(ds["profiles"])
+    seqs.insert(3, b"ACGTACGTACGG"); profs.insert(3, np.zeros(0, np.uint16))
+    n = len(seqs)
+    files = [(n // 2, "a.fasta", "m1_prolog"), (n - n // 2, "b.fasta", "m2_prolog")]
+    hdr = [">ctg%d part=%d" % (i, i % 3) for i in range(n)] if dam else None
+    d = str(tmp_path)
+    recs = dazz.write_db(d, "reads", seqs, files, dam=dam, hdr_lines=hdr)
+    heads = dazz.db_headers(files, recs, dam=dam, hdr_lines=hdr)
+    fastk.write_fastk(d, "reads", K, profs, ds["hist"], nparts=2)
+    low, high, il, ih, h = ds["hist"]
+    hc, dc = hist_covs(h, low, high, il, ih, 0)
+    cli = os.path.join(os.path.dirname(build.OUT), "ClassPro")
+    r = subprocess.run([cli, "-T2", os.path.join(d, "reads.dam" if dam else "reads.db")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    O = Oracle(K, 20000, hc, dc)
+    labels = [O.classify_read(s, p) if len(s) >= K else b"N" * len(s) for s, p in zip(seqs, profs)]
+    exp = b"".join(hd.encode() + b"\n" + s + b"\n+\n" + lab + b"\n" for hd, s, lab in zip(heads, seqs, labels))
+    assert open(os.path.join(d, "reads.class"), "rb").read() == exp
+    nreads, size, offs, raw = dazz.read_class_track(d, "reads")
+    assert (nreads, size) == (n, 8) and offs[0] == 0 and offs[-1] == len(raw)
+    code = np.zeros(256, np.uint8)
+    code[ord("R")], code[ord("H")], code[ord("D")] = 1, 2, 3
+    for i, lab in enumerate(labels):
+        assert offs[i + 1] - offs[i] == (len(lab) + 3) // 4
+        got = dazz.unpack_2bit(raw[offs[i]:offs[i + 1]], len(lab))
+        assert np.array_equal(got, code[np.frombuffer(lab, np.uint8)])
+    nr, sz, roffs, rraw = dazz.read_class_track(d, "reads", "rep")
+    assert (nr, sz, len(roffs), len(rraw)) == (n, 0, 1, 0)
+    r = subprocess.run([cli, "-s", os.path.join(d, "reads")], capture_output=True, text=True)
+    assert r.returncode == 1 and "-s" in r.stderr
