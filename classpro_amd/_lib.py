@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libclasspro_amd.so")
+LIB_PATH = os.environ.get("CLASSPRO_AMD_LIB") or os.path.join(_HERE, "libclasspro_amd.so")   # env: diagnostic builds only
 
 # every symbol include/classpro_amd.h declares
 SYMBOLS = [

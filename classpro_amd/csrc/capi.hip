@@ -317,11 +317,11 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   //  runs beside the main class on the auxiliary stream)
   HIPCHK(hipEventRecord(ws->ev_fork,st));
   HIPCHK(hipStreamWaitEvent(ws->aux,ws->ev_fork,0));
-  hipLaunchKernelGGL((k_classify_rel_grp<128,1024,1>),dim3(nreads),dim3(WAVE),0,ws->aux,
+  hipLaunchKernelGGL((k_classify_rel_grp<REL_SMALL_MAXM,1024,1>),dim3(nreads),dim3(WAVE),0,ws->aux,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI,(const int32_t *)ws->perm.p);
   HIPCHK(hipEventRecord(ws->ev_join,ws->aux));
-  hipLaunchKernelGGL((k_classify_rel_grp<0,128,2>),dim3((nreads+1)/2),dim3(WAVE),0,st,
+  hipLaunchKernelGGL((k_classify_rel_grp<0,REL_SMALL_MAXM,REL_SMALL_G>),dim3((nreads+REL_SMALL_G-1)/REL_SMALL_G),dim3(WAVE),0,st,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI,(const int32_t *)ws->perm.p);
   HIPCHK(hipStreamWaitEvent(st,ws->ev_join,0));
@@ -340,11 +340,11 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   hipLaunchKernelGGL(k_order_by_work,dim3(1),dim3(1024),0,st,(const int32_t *)ws->nintvl.p,nreads,0,(int32_t *)ws->perm.p);
   HIPCHK(hipEventRecord(ws->ev_fork,st));
   HIPCHK(hipStreamWaitEvent(ws->aux,ws->ev_fork,0));
-  hipLaunchKernelGGL((k_classify_unrel_grp<256,1024,2>),dim3((nreads+1)/2),dim3(WAVE),0,ws->aux,
+  hipLaunchKernelGGL((k_classify_unrel_grp<UNREL_SMALL_MAXN,1024,2>),dim3((nreads+1)/2),dim3(WAVE),0,ws->aux,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
                      (double *)ws->memo_val.p,(int32_t *)ws->memo_key.p,(const int32_t *)ws->perm.p);
   HIPCHK(hipEventRecord(ws->ev_join,ws->aux));
-  hipLaunchKernelGGL((k_classify_unrel_grp<0,256,8>),dim3((nreads+7)/8),dim3(WAVE),0,st,
+  hipLaunchKernelGGL((k_classify_unrel_grp<0,UNREL_SMALL_MAXN,UNREL_SMALL_G>),dim3((nreads+UNREL_SMALL_G-1)/UNREL_SMALL_G),dim3(WAVE),0,st,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
                      (double *)ws->memo_val.p,(int32_t *)ws->memo_key.p,(const int32_t *)ws->perm.p);
   HIPCHK(hipStreamWaitEvent(st,ws->ev_join,0));
@@ -469,3 +469,24 @@ extern "C" int cp_seq_context(const char *d_seq, const int64_t *d_seq_off, int n
   HIPCHK(hipGetLastError());
   return CP_OK;
 }
+
+#ifdef CP_PROF_WALK
+// diagnostic builds only: cycle accumulators of the candidate walk (see cp_wall.h), then reset
+extern "C" int cp_debug_walk_prof(unsigned long long *out16)
+{ HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out16,HIP_SYMBOL(g_walk_prof),16*sizeof(unsigned long long)));
+  unsigned long long z[16] = {0};
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_walk_prof),z,sizeof(z)));
+  return CP_OK;
+}
+extern "C" int cp_debug_phase_prof(unsigned long long *out24)
+{ HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out24,HIP_SYMBOL(g_phase_max),8*sizeof(unsigned long long)));
+  HIPCHK(hipMemcpyFromSymbol(out24+8,HIP_SYMBOL(g_phase_sum),8*sizeof(unsigned long long)));
+  HIPCHK(hipMemcpyFromSymbol(out24+16,HIP_SYMBOL(g_phase_arg),8*sizeof(unsigned long long)));
+  unsigned long long z[8] = {0};
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_max),z,sizeof(z)));
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_sum),z,sizeof(z)));
+  return CP_OK;
+}
+#endif

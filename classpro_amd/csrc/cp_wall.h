@@ -80,7 +80,22 @@ struct cp_read_t
     int                  ecap;
     int                  eidx, oidx;
     int                  overflow;
+#ifdef CP_PROF_WALK
+    long long            tacc[8] = {0,0,0,0,0,0,0,0};
+#endif
   };
+
+// Diagnostic build (-DCP_PROF_WALK): cycle accumulators per region of the walk, summed per pass into
+// g_walk_prof by k_find_wall and read back with cp_debug_walk_prof.  Not part of the product build.
+#if defined(CP_PROF_WALK) && defined(__HIP_DEVICE_COMPILE__)
+#define CP_T0(R,k) ((R)->tacc[k] -= (long long)wall_clock64())
+#define CP_T1(R,k) ((R)->tacc[k] += (long long)wall_clock64())
+#define CP_TC(R,k) ((R)->tacc[k] += 1)
+#else
+#define CP_T0(R,k) ((void)0)
+#define CP_T1(R,k) ((void)0)
+#define CP_TC(R,k) ((void)0)
+#endif
 
 #define CP_PERR(R,i,e,w) ((R)->perror[e].get(i,e,w))
 #define CP_NEG_INF (-INFINITY)
@@ -106,18 +121,109 @@ CP_HD double cp_logp_diff_pair(const RD *R, int i, int j)
 CP_HD bool cp_cthres_ng(int e, int cin, int ct)
 { return (e == CP_SELF) ? (cin >= ct) : (cin < ct); }
 
-// wall.c:331-507: find_gain (w == DROP: partner GAIN to the right of i) and find_drop (w == GAIN:
-// partner DROP to the left), folded into one routine by mirroring the index arithmetic.
+// ---------------------------------------------------------------------------------------------
+//  One iteration of the candidate walk (wall.c:590-707) for a position i that passed the scan
+//  (min(c[i-1],c[i]) < R and |c[i-1]-c[i]| >= 3), split by what it depends on:
+//
+//   cp_wall_candidate_pre    what the two error-type passes share: the count pair and the low-
+//                            complexity context with the largest error rate (wall.c:612-634).
+//   cp_wall_candidate_pure   everything of one pass (error type e) that is a function of the read
+//                            alone: the threshold filters (wall.c:643-653, 672-676), the candidate's
+//                            own P(error) (the value update_perror would store, wall.c:310-315),
+//                            find_gain / find_drop's low-complexity partner j and the value
+//                            update_perror(j) would store (wall.c:345-378 / 432-467), and the best
+//                            high-complexity partner (wall.c:380-404 / 469-493: six scores that use no
+//                            memoised value; "first strict maximum" over them).
+//   cp_wall_candidate_replay the part that depends on earlier candidates: the paired flags
+//                            (wall.c:639), the perror memo -- a position's entry is whatever the FIRST
+//                            request computed, and an earlier candidate may have requested it with its
+//                            own error rate -- and the flag / interval-list updates.
+//
+//  The reference evaluates all of this inline per candidate.  On the device every load of that walk
+//  is a cold miss and the Bessel / binomial-tail evaluations are long serial chains, so k_find_wall
+//  computes pre+pure for 64 candidates at once (one per lane) and then replays the candidates in
+//  order; the SELF and OTHERS replays touch disjoint state (different flag bits, memo entries and
+//  interval lists; each depends only on its own earlier iterations) and run on two lanes.
+// ---------------------------------------------------------------------------------------------
+struct cp_wall_pre
+  { int    cng, wtype, cin, cout, maxt, maxl;
+    double maxpe, lpe, l1mpe;
+  };
+
+#define CP_CF_LIVE     1      // passes the threshold filters: the pass goes on to update_perror(i)
+#define CP_CF_WALLNOW  2      // OTHERS pass: a wall by the count change alone (wall.c:672-676)
+#define CP_LC_NONE     0      // find_gain/find_drop return false at once (partner on the wrong side)
+#define CP_LC_BOUNDARY 1      // partner beyond the read end: pe = perror[i]^2
+#define CP_LC_PAIR     2      // partner j inside the read and admissible
+#define CP_LC_REJECT   3      // partner j inside the read but filtered out: pe = -inf
+
+struct cp_cand_pure
+  { double own_pe;            // p_errorin for (i,e,wtype) with the candidate's own error rate
+    double lc_v;              // p_errorin for the low-complexity partner (lc_j,e,1-wtype), same error rate
+    double hc_pe;             // best high-complexity score, valid if hc_j >= 0
+    int    lc_j, hc_j;
+    int    flags, lc_kind;
+  };
+
 template <class RD>
-CP_HD bool cp_find_pair(RD *R, int i, int cout, int cin, int e, int w, int t, int l,
-                        double erate, double lpe, double l1mpe, cp_eintvl *out)
+CP_HD void cp_wall_candidate_pre(const RD *R, int i, cp_wall_pre *pre)
+{ const cp_dev_params *P = R->P;
+  const int cim1 = R->prof[i-1], ci = R->prof[i];
+  int cng = cim1-ci;
+  if (cng < 0) cng = -cng;
+  pre->cng = cng;
+  if (cim1 > ci) { pre->wtype = CP_DROP; pre->cin = ci;   pre->cout = cim1; }
+  else           { pre->wtype = CP_GAIN; pre->cin = cim1; pre->cout = ci;   }
+  int maxt = -1, maxl = -1;                              // wall.c:624-634
+  double maxpe = CP_NEG_INF;
+  for (int t = 0; t < 3; t++)
+    { int l = cp_ctx(R->seq,R->rlen,P->K,pre->wtype,i,t);
+      if (l > P->lmax[t]) l = P->lmax[t];
+      double pe = P->pe[t][l];
+      if (maxpe < pe)
+        { maxpe = pe; maxt = t; maxl = l; }
+    }
+  pre->maxt = maxt; pre->maxl = maxl; pre->maxpe = maxpe;
+  pre->lpe = P->lpe[maxt][maxl];
+  pre->l1mpe = P->l1mpe[maxt][maxl];
+}
+
+template <class RD>
+CP_HD void cp_wall_candidate_pure(RD *R, int i, int e, const cp_wall_pre &pre, cp_cand_pure *out)
 { const cp_dev_params *P = R->P;
   const auto &pr = R->prof;
   const int plen = R->plen, K = P->K, CMAX = P->cmax;
+  const int cng = pre.cng, w = pre.wtype, cin = pre.cin, cout = pre.cout;
+  const int t = pre.maxt, l = pre.maxl;
+  out->flags = 0; out->lc_kind = CP_LC_NONE; out->lc_j = -1; out->hc_j = -1;
+  out->own_pe = out->lc_v = out->hc_pe = CP_NEG_INF;
+
+  int ct_init = 0, ct_final = 0;
+  if (cout < CMAX)                                       // wall.c:643-648
+    { ct_init  = P->cthres[t][l][cout][CP_INIT][e];
+      ct_final = P->cthres[t][l][cout][CP_FINAL][e];
+      if (!(cng > CP_MAX_CNT_CHANGE || cin < (ct_init > 3 ? ct_init : 3)))
+        return;
+    }
+  if (e == CP_SELF)                                      // wall.c:651-653
+    { if (cout < CMAX && cin >= ct_final)
+        return;
+    }
+  else if (cng >= P->cov[CP_HAPLO] || (cout < CMAX && cin < ct_final))       // wall.c:672-676
+    { out->flags = CP_CF_WALLNOW;
+      return;
+    }
+  out->flags = CP_CF_LIVE;
+  CP_TC(R,5); CP_T0(R,1);
+  out->own_pe = cp_p_errorin(R->lf,e,pre.maxpe,pre.lpe,pre.l1mpe,cout,cin);
+  CP_T1(R,1);
+  CP_T0(R,2);
+
+  // find_gain (w == DROP: partner GAIN to the right of i) / find_drop (w == GAIN: partner DROP to the
+  // left), wall.c:331-507, folded into one routine by mirroring the index arithmetic.
   const int ulen = t+1;
   const bool right = (w == CP_DROP);
-  int n, j, max_j = -1, cout_j, cin_j;
-  double pe, max_pe = CP_NEG_INF;
+  int n, j, cout_j, cin_j;
 
   // low-complexity partner (wall.c:345-378 / 432-467)
   const int m = ulen*l;
@@ -132,31 +238,33 @@ CP_HD bool cp_find_pair(RD *R, int i, int cout, int cin, int e, int w, int t, in
     }
   j = right ? (i+K-1)+n-m : (i-K+1)-n+m;
   if (right ? (j <= i) : (j >= i))
-    return false;
+    { CP_T1(R,2);
+      return;                                            // lc_kind NONE: no pair at all (wall.c:355 / 442)
+    }
   if (right ? (j >= plen) : (j <= 0))
-    { j = right ? plen : 0;
-      pe = CP_PERR(R,i,e,w) * CP_PERR(R,i,e,w);
+    { out->lc_kind = CP_LC_BOUNDARY;
+      out->lc_j = right ? plen : 0;
     }
   else
     { if (right) { cin_j = pr[j-1]; cout_j = pr[j]; }
       else       { cout_j = pr[j-1]; cin_j = pr[j]; }
-      pe = CP_NEG_INF;
+      out->lc_j = j;
       if (cin_j <= cout_j
           && !(cout_j < CMAX && cp_cthres_ng(e,cin_j,P->cthres[t][l][cout_j][CP_FINAL][e]))
           && (e == CP_SELF || (right ? cp_logp_diff_pair(R,i,j) : cp_logp_diff_pair(R,j,i)) >= CP_THRES_DIFF_EO))
-        { cp_update_perror(R,j,e,1-w,cout_j,cin_j,erate,lpe,l1mpe);
-          pe = right ? CP_PERR(R,i,e,CP_DROP)*CP_PERR(R,j,e,CP_GAIN)
-                     : CP_PERR(R,j,e,CP_DROP)*CP_PERR(R,i,e,CP_GAIN);
+        { out->lc_kind = CP_LC_PAIR;
+          out->lc_v = cp_p_errorin(R->lf,e,pre.maxpe,pre.lpe,pre.l1mpe,cout_j,cin_j);
         }
-    }
-  if (max_pe < pe)
-    { max_j  = j;
-      max_pe = pe;
+      else
+        out->lc_kind = CP_LC_REJECT;
     }
 
+  CP_T1(R,2);
+  CP_T0(R,3);
   // high-complexity partners (wall.c:380-404 / 469-493)
   bool   have_pe_i = false;
-  double pe_i = 0.;
+  double pe_i = 0., max_pe = CP_NEG_INF;
+  int    max_j = -1;
   for (n = 0; n <= CP_MAX_N_HC; n++)
     { j = right ? (i+K-1)+n : (i-K+1)-n;
       if (right ? (j >= plen) : (j <= 0))
@@ -175,13 +283,44 @@ CP_HD bool cp_find_pair(RD *R, int i, int cout, int cin, int e, int w, int t, in
           have_pe_i = true;
         }
       double pe_j = cp_p_errorin(R->lf,e,P->hc_erate,P->hc_lpe,P->hc_l1mpe,cout_j,cin_j);
-      pe = pe_i * pe_j;
+      double pe = pe_i * pe_j;
       if (max_pe < pe)
         { max_j  = j;
           max_pe = pe;
         }
     }
+  out->hc_j = max_j;
+  out->hc_pe = max_pe;
+  CP_T1(R,3);
+}
 
+// find_gain / find_drop with the memo state of the moment.  The reference keeps one running maximum
+// over the low-complexity partner and then the six high-complexity ones, replacing it only by a
+// strictly larger score; starting the high-complexity scan from -inf instead (cp_wall_candidate_pure)
+// and comparing its winner with the low-complexity score picks the same partner.
+template <class RD>
+CP_HD bool cp_find_pair_replay(RD *R, int i, int e, int w, const cp_cand_pure &c, cp_eintvl *out)
+{ if (c.lc_kind == CP_LC_NONE)
+    return false;
+  const bool right = (w == CP_DROP);
+  int max_j = -1;
+  double pe = CP_NEG_INF, max_pe = CP_NEG_INF;
+  if (c.lc_kind == CP_LC_BOUNDARY)
+    pe = CP_PERR(R,i,e,w) * CP_PERR(R,i,e,w);
+  else if (c.lc_kind == CP_LC_PAIR)
+    { if (CP_PERR(R,c.lc_j,e,1-w) == CP_NEG_INF)            // update_perror(j), wall.c:310-315
+        R->perror[e].set(c.lc_j,e,1-w,c.lc_v);
+      pe = right ? CP_PERR(R,i,e,CP_DROP)*CP_PERR(R,c.lc_j,e,CP_GAIN)
+                 : CP_PERR(R,c.lc_j,e,CP_DROP)*CP_PERR(R,i,e,CP_GAIN);
+    }
+  if (max_pe < pe)
+    { max_j  = c.lc_j;
+      max_pe = pe;
+    }
+  if (c.hc_j >= 0 && max_pe < c.hc_pe)
+    { max_j  = c.hc_j;
+      max_pe = c.hc_pe;
+    }
   if (max_j == -1)
     return false;
   if (right) { out->b = i;     out->e = max_j; }
@@ -190,51 +329,23 @@ CP_HD bool cp_find_pair(RD *R, int i, int cout, int cin, int e, int w, int t, in
   return true;
 }
 
-// One iteration of the candidate walk, wall.c:590-707, for a position i that passed the scan
-// (min(c[i-1],c[i]) < R and |c[i-1]-c[i]| >= 3) and ONE error type e.  The SELF and OTHERS passes of
-// the reference's inner loop (:638-691) touch disjoint state -- different flag bits, different memo
-// entries, different interval lists -- and each depends only on its own earlier iterations, so the
-// device walks them on two lanes at once (with separate flag arrays and memo tables).
 template <class RD>
-CP_HD void cp_wall_candidate_e(RD *R, int i, int e)
-{ const cp_dev_params *P = R->P;
-  const int CMAX = P->cmax;
-  const int cim1 = R->prof[i-1], ci = R->prof[i];
-  int cng = cim1-ci;
-  if (cng < 0) cng = -cng;
-  int wtype, cin, cout;
-  if (cim1 > ci) { wtype = CP_DROP; cin = ci;   cout = cim1; }
-  else           { wtype = CP_GAIN; cin = cim1; cout = ci;   }
-
-  if (e == CP_SELF ? (R->wall_s[i] & CP_W_PAIRED_S) : (R->wall[i] & CP_W_PAIRED_O))      // wall.c:639
+CP_HD void cp_wall_candidate_replay(RD *R, int i, int e, int wtype, const cp_cand_pure &c)
+{ if (e == CP_SELF ? (R->wall_s[i] & CP_W_PAIRED_S) : (R->wall[i] & CP_W_PAIRED_O))      // wall.c:639
     return;
-
-  int maxt = -1, maxl = -1;                              // wall.c:624-634
-  double maxpe = CP_NEG_INF;
-  for (int t = 0; t < 3; t++)
-    { int l = cp_ctx(R->seq,R->rlen,P->K,wtype,i,t);
-      if (l > P->lmax[t]) l = P->lmax[t];
-      double pe = P->pe[t][l];
-      if (maxpe < pe)
-        { maxpe = pe; maxt = t; maxl = l; }
+  if (c.flags == 0)
+    return;
+  if (c.flags & CP_CF_WALLNOW)
+    { R->wall[i] |= CP_W_WALL_O;
+      return;
     }
-  const double lpe = P->lpe[maxt][maxl], l1mpe = P->l1mpe[maxt][maxl];
-
-  int ct_init = 0, ct_final = 0;
-  if (cout < CMAX)                                       // wall.c:643-648
-    { ct_init  = P->cthres[maxt][maxl][cout][CP_INIT][e];
-      ct_final = P->cthres[maxt][maxl][cout][CP_FINAL][e];
-      if (!(cng > CP_MAX_CNT_CHANGE || cin < (ct_init > 3 ? ct_init : 3)))
-        return;
-    }
+  if (CP_PERR(R,i,e,wtype) == CP_NEG_INF)                  // update_perror(i), wall.c:310-315
+    R->perror[e].set(i,e,wtype,c.own_pe);
+  cp_eintvl I;
   if (e == CP_SELF)                                      // wall.c:651-670
-    { if (cout < CMAX && cin >= ct_final)
+    { if (CP_PERR(R,i,e,wtype) < CP_PE_THRES_FINAL)
         return;
-      cp_update_perror(R,i,e,wtype,cout,cin,maxpe,lpe,l1mpe);
-      if (CP_PERR(R,i,e,wtype) < CP_PE_THRES_FINAL)
-        return;
-      cp_eintvl I;
-      if (cp_find_pair(R,i,cout,cin,e,wtype,maxt,maxl,maxpe,lpe,l1mpe,&I) && I.pe >= CP_PE_THRES_FINAL)
+      if (cp_find_pair_replay(R,i,e,wtype,c,&I) && I.pe >= CP_PE_THRES_FINAL)
         { R->wall_s[I.b] |= (CP_W_WALL_S|CP_W_PAIRED_S);
           R->wall_s[I.e] |= (CP_W_WALL_S|CP_W_PAIRED_S);
           if (R->eidx < R->ecap) R->eintvl[R->eidx++] = I;
@@ -242,17 +353,11 @@ CP_HD void cp_wall_candidate_e(RD *R, int i, int e)
         }
     }
   else                                                   // wall.c:671-690
-    { if (cng >= P->cov[CP_HAPLO] || (cout < CMAX && cin < ct_final))
+    { if (CP_PERR(R,i,e,wtype) < CP_PE_THRES_FINAL)
         { R->wall[i] |= CP_W_WALL_O;
           return;
         }
-      cp_update_perror(R,i,e,wtype,cout,cin,maxpe,lpe,l1mpe);
-      if (CP_PERR(R,i,e,wtype) < CP_PE_THRES_FINAL)
-        { R->wall[i] |= CP_W_WALL_O;
-          return;
-        }
-      cp_eintvl I;
-      if (cp_find_pair(R,i,cout,cin,e,wtype,maxt,maxl,maxpe,lpe,l1mpe,&I) && I.pe >= CP_PE_THRES_FINAL)
+      if (cp_find_pair_replay(R,i,e,wtype,c,&I) && I.pe >= CP_PE_THRES_FINAL)
         { R->wall[I.b] |= CP_W_PAIRED_O;
           R->wall[I.e] |= CP_W_PAIRED_O;
           if (R->oidx < R->ecap) R->ointvl[R->oidx++] = I;
@@ -261,6 +366,15 @@ CP_HD void cp_wall_candidate_e(RD *R, int i, int e)
         }
       R->wall[i] |= CP_W_WALL_O;
     }
+}
+
+template <class RD>
+CP_HD void cp_wall_candidate_e(RD *R, int i, int e)
+{ cp_wall_pre pre;
+  cp_cand_pure c;
+  cp_wall_candidate_pre(R,i,&pre);
+  cp_wall_candidate_pure(R,i,e,pre,&c);
+  cp_wall_candidate_replay(R,i,e,pre.wtype,c);
 }
 
 template <class RD>

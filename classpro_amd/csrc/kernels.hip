@@ -241,7 +241,22 @@ __device__ __forceinline__ void wave_wall_or(uint8_t *wall, int b, int e, uint8_
 // ---------------------------------------------------------------------------------------------
 //  k_find_wall: wall.c:570-958, one wave per read.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WAVE)
+#ifdef CP_PROF_WALK
+__device__ unsigned long long g_walk_prof[16];
+__device__ unsigned long long g_phase_max[8], g_phase_sum[8], g_phase_arg[8];
+#define PH_STAMP(k) do { if (lane == 0) { unsigned long long t_ = wall_clock64(); unsigned long long d_ = t_-ph_t; ph_t = t_; \
+      atomicAdd(&g_phase_sum[k],d_); unsigned long long o_ = atomicMax(&g_phase_max[k],d_); if (d_ > o_) g_phase_arg[k] = ((unsigned long long)r << 32) | (unsigned)n_c; } } while (0)
+#else
+#define PH_STAMP(k) ((void)0)
+#endif
+
+// k_find_wall is a chain of dependent cold loads and FP64 latencies, so it wants waves, not registers:
+// capped at 96 VGPRs (5 waves per SIMD; measured 3: 7.77, 4: 7.63, 5: 7.44, 6: 7.67, 8: 7.89 ms per step
+// against 8.32 ms uncapped at 188 VGPRs / 2 waves).
+#ifndef FW_WAVES_PER_EU
+#define FW_WAVES_PER_EU 5
+#endif
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FW_WAVES_PER_EU)))
 k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, const int64_t *__restrict__ seq_off,
             const uint16_t *__restrict__ prof, const int64_t *__restrict__ prof_off, int nreads,
             const uint64_t *__restrict__ bm, uint8_t *__restrict__ wall_all, uint8_t *__restrict__ walls_all,
@@ -278,19 +293,99 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   uint8_t *wall = R.wall;
   const uint8_t *wall_s = R.wall_s;
 
-  // ---- candidate walk (wall.c:590-707): order-dependent; the SELF pass on lane 0 and the OTHERS
-  //      pass on lane 1 (disjoint state: own flag array, own memo table, own interval list) -------
-  if (lane < 2 && plen > 1)
+  // ---- candidate walk (wall.c:590-707) ----------------------------------------------------------
+  // Every load of the reference's walk is a cold miss here (the profile, bases and flag arrays of a
+  // 200-Mbase batch do not stay in L2), a candidate's loads depend on each other, and its Bessel /
+  // binomial-tail evaluations are long serial chains.  The walk is therefore split (cp_wall.h):
+  //   0. the wave lists the read's candidate positions from the bitmap (64 words per step);
+  //   1. for 64 candidates at a time, lane k evaluates everything about candidate k that is a function
+  //      of the read alone (cp_wall_candidate_pre, cp_wall_candidate_pure for both error types) --
+  //      64 chains in parallel -- and leaves the results in LDS;
+  //   2. the candidates are replayed in order (cp_wall_candidate_replay: paired flags, perror memo,
+  //      flag and interval-list updates), the SELF pass on lane 0 and the OTHERS pass on lane 1
+  //      (disjoint state: own flag array, own memo table, own interval list).
+  __shared__ double s_own[2][WAVE], s_lcv[2][WAVE], s_hcpe[2][WAVE];
+  __shared__ int    s_lcj[2][WAVE], s_hcj[2][WAVE], s_flags[2][WAVE], s_pos[WAVE], s_wtype[WAVE];
+  int32_t *clist = wl+icap;                             // free until the components are built below
+  int n_c = 0;
+#ifdef CP_PROF_WALK
+  unsigned long long ph_t = wall_clock64();
+#endif
+  if (plen > 1)
     { const int64_t lo = po+1, hi = po+plen;
-      for (int64_t w = lo >> 6; w <= ((hi-1) >> 6); w++)
-        { uint64_t bits = bitmap_word(bm,w,lo,hi);
-          while (bits)
-            { int k = __ffsll((long long)bits)-1;
-              bits &= bits-1;
-              cp_wall_candidate_e(&R,(int)((w << 6)+k-po),lane);
+      const int64_t w_lo = lo >> 6, w_hi = (hi-1) >> 6;
+      for (int64_t wb = w_lo; wb <= w_hi; wb += WAVE)
+        { const int64_t w = wb+lane;
+          const uint64_t bits = (w <= w_hi) ? bitmap_word(bm,w,lo,hi) : 0ull;
+          int c = __popcll(bits), off = c;
+          for (int o = 1; o < WAVE; o <<= 1)
+            { int x = __shfl_up(off,o); if (lane >= o) off += x; }
+          const int tot = __shfl(off,WAVE-1);
+          off = n_c+off-c;
+          for (uint64_t t = bits; t; t &= t-1)
+            { const int k = __ffsll((long long)t)-1;
+              if (off < icap) clist[off] = (int)((w << 6)+k-po);
+              off++;
             }
+          n_c += tot;
         }
     }
+  if (n_c > icap) n_c = icap;                           // cannot happen: icap = 2*ncand+4
+  wave_sync();
+  PH_STAMP(0);
+#ifdef CP_PROF_WALK
+  if (lane < 2 && plen > 1) CP_T0(&R,0);
+#endif
+  for (int base = 0; base < n_c; base += WAVE)
+    { const int nb = (n_c-base < WAVE) ? n_c-base : WAVE;
+#ifdef CP_PROF_WALK
+      CP_T0(&R,4);
+#endif
+      if (lane < nb)
+        { const int i = clist[base+lane];
+          cp_wall_pre pre;
+          cp_wall_candidate_pre(&R,i,&pre);
+          s_pos[lane] = i;
+          s_wtype[lane] = pre.wtype;
+          unsigned touch = (unsigned)wall[i] | (unsigned)wall_s[i];
+          asm volatile("" :: "v"(touch));               // keep the two flag loads (they warm the cache)
+#pragma unroll 1
+          for (int e = 0; e < 2; e++)
+            { cp_cand_pure c;
+              cp_wall_candidate_pure(&R,i,e,pre,&c);
+              s_own[e][lane] = c.own_pe; s_lcv[e][lane] = c.lc_v; s_hcpe[e][lane] = c.hc_pe;
+              s_lcj[e][lane] = c.lc_j;   s_hcj[e][lane] = c.hc_j;
+              s_flags[e][lane] = c.flags | (c.lc_kind << 4);
+            }
+        }
+      wave_sync();
+#ifdef CP_PROF_WALK
+      CP_T1(&R,4);
+      CP_T0(&R,6);
+#endif
+      if (lane < 2)
+        for (int k = 0; k < nb; k++)
+          { cp_cand_pure c;
+            const int f = s_flags[lane][k];
+            c.flags = f & 15; c.lc_kind = f >> 4;
+            c.own_pe = s_own[lane][k]; c.lc_v = s_lcv[lane][k]; c.hc_pe = s_hcpe[lane][k];
+            c.lc_j = s_lcj[lane][k];   c.hc_j = s_hcj[lane][k];
+            cp_wall_candidate_replay(&R,s_pos[k],lane,s_wtype[k],c);
+          }
+      wave_sync();
+#ifdef CP_PROF_WALK
+      CP_T1(&R,6);
+#endif
+    }
+#ifdef CP_PROF_WALK
+  if (lane < 2 && plen > 1)
+    { CP_T1(&R,0);
+      for (int k = 0; k < 7; k++)
+        atomicAdd(&g_walk_prof[lane*8+k],(unsigned long long)R.tacc[k]);
+      if (lane == 0) atomicAdd(&g_walk_prof[7],1ull);
+    }
+#endif
+  PH_STAMP(1);
   int NS = __shfl(R.eidx,0), NO = __shfl(R.oidx,1);
   int overflow = __shfl(R.overflow,0) | __shfl(R.overflow,1);
   R.eidx = NS; R.oidx = NO;
@@ -347,6 +442,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
     }
   if (n_o > icap) { overflow |= 2; n_o = icap; }
   wave_sync();
+  PH_STAMP(2);
   int midx = NS;
   if (lane == 0)
     for (int q = 0; q < n_o; q++)
@@ -358,6 +454,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   midx = __shfl(midx,0);
   overflow |= __shfl(R.overflow,0);
   wave_sync();
+  PH_STAMP(3);
   for (int k = NS; k < midx; k++)                      // wall.c:868-872
     wave_wall_and(wall,R.eintvl[k].b+1,R.eintvl[k].e,(uint8_t)~CP_W_WALL_O);
   wave_sync();
@@ -371,6 +468,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   overflow |= __shfl(R.overflow,0);
   wave_sync();
   wave_sort_eintvl(R.eintvl,NS,R.ointvl);              // wall.c:910
+  PH_STAMP(4);
 
   // ---- interval boundaries (wall.c:917-948) without per-position passes -----------------------
   // The reference marks every position of every E-interval as "error" and then scans all positions
@@ -458,6 +556,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   wave_sync();
   for (int k = lane; k < N && k < icap; k += WAVE)     // wall.c:928-946, one lane per interval
     cp_make_interval(&R,NS,k ? bnd[k-1] : 0,bnd[k],&intvl[k]);
+  PH_STAMP(5);
   if (lane == 0)
     { nintvl[r] = (N > icap) ? icap : N;
       if (overflow) atomicOr(err,overflow);
@@ -856,8 +955,25 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
   wave_sync();
 }
 
+// size classes of the grouped classify kernels (reads per wave / largest interval count)
+#ifndef REL_SMALL_G
+#define REL_SMALL_G 2
+#endif
+#ifndef REL_SMALL_MAXM
+#define REL_SMALL_MAXM 128
+#endif
+#ifndef UNREL_SMALL_G
+#define UNREL_SMALL_G 8
+#endif
+#ifndef UNREL_SMALL_MAXN
+#define UNREL_SMALL_MAXN 192             // (8,256): 7.40 ms per step, (4,256): 7.24, (8,192): 7.22, (8,128): 7.55
+#endif
+#ifndef REL_WAVES_PER_EU
+#define REL_WAVES_PER_EU 1
+#endif
+
 template <int MINM, int MAXM, int G>
-__global__ void __launch_bounds__(WAVE)
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(REL_WAVES_PER_EU)))
 k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ prof_off, int nreads,
                    cp_intvl *__restrict__ intvl_all, cp_intvl *__restrict__ rintvl_all, const int32_t *__restrict__ relmap_all,
                    const int64_t *__restrict__ ioff, const int32_t *__restrict__ nrel,
@@ -954,7 +1070,7 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
 // ---------------------------------------------------------------------------------------------
 template <int MAXN, int G>
 struct unrel_grp_lds
-  { uint16_t b[G][MAXN], e[G][MAXN], cb[G][MAXN], ce[G][MAXN], ccb[G][MAXN], cce[G][MAXN];
+  { static_assert(MAXN % 64 == 0,"the reliable-interval bitsets are whole 64-bit words"); uint16_t b[G][MAXN], e[G][MAXN], cb[G][MAXN], ce[G][MAXN], ccb[G][MAXN], cce[G][MAXN];
     int8_t   asgn[G][MAXN];
     uint8_t  isrel[G][MAXN];
     int16_t  ord[G][MAXN];               // sorted index, bit 14 = fixed

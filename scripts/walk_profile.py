@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Diagnostic: where the candidate walk of k_find_wall spends its cycles (needs build/lib_prof.so, built
+with -DCP_PROF_WALK; run with CLASSPRO_AMD_LIB=build/lib_prof.so on the GPU box)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from classpro_amd import synth
+from classpro_amd.api import Classifier, Batch, hist_covs, STAGE_WALL
+from classpro_amd._lib import lib
+
+ds = synth.make_dataset(genome_len=5_000_000, cov=40, read_len=20000, K=40, het=0.001, n_repeats=62, min_len=3000, seed=1)
+low, high, il, ih, h = ds["hist"]
+hc, dc = hist_covs(h, low, high, il, ih, 0)
+clf = Classifier(40, 20000, hc, dc)
+b = Batch.from_reads(ds["seqs"], ds["profiles"])
+out = (C.c_ulonglong * 16)()
+ph = (C.c_ulonglong * 24)()
+clf.run(b, STAGE_WALL)
+lib().cp_debug_walk_prof(out)
+lib().cp_debug_phase_prof(ph)
+clf.run(b, STAGE_WALL)
+lib().cp_debug_walk_prof(out)
+lib().cp_debug_phase_prof(ph)
+pn = ["0 candidate list", "1 walk (pure + replay)", "2 unwall/sort/olist", "3 wall_mult (lane 0)", "4 merge + sorts", "5 boundaries + records"]
+print("phase                          max over reads (ticks)   mean      argmax read / its ncand")
+for k in range(6):
+    print("  %-28s %12d %12.1f      %d / %d" % (pn[k], ph[k], ph[8 + k] / b.nreads, ph[16 + k] >> 32, ph[16 + k] & 0xffffffff))
+v = np.array(list(out), dtype=np.float64)
+names = ["walk total", "pure: own_pe", "pure: LC", "pure: HC", "phase 1 (pre+pure, wave)", "#live (lane view)", "phase 2 (replay, wave)"]
+nreads = v[7]
+for e, nm in ((0, "lane 0 (candidate 0 of each batch; pure timers cover both error types)"), (1, "lane 1")):
+    print(nm)
+    for k in range(7):
+        x = v[e * 8 + k]
+        print("   %-18s %14.0f  per read %10.1f" % (names[k], x, x / nreads))
+print("reads", nreads, "(clock = 100 MHz wall_clock64 ticks)")
