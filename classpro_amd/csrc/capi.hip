@@ -311,7 +311,7 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->parent.p,(int32_t *)ws->eff.p,
                      (uint8_t *)ws->rpos.p,(int8_t *)ws->asgn.p,totalI);
-  // size classes: M <= 128 two reads per wave, 128 < M <= 1024 one read per wave, larger: sequential kernel above
+  // size classes (kernels.hip: REL_SMALL_*): M <= 256 two reads per wave, up to 1024 one read per wave, larger: sequential kernel above
   hipLaunchKernelGGL(k_order_by_work,dim3(1),dim3(1024),0,st,(const int32_t *)ws->nrel.p,nreads,0,(int32_t *)ws->perm.p);
   // (the classes touch disjoint reads; the long-read class is a handful of latency-bound waves, so it
   //  runs beside the main class on the auxiliary stream)
@@ -334,7 +334,7 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   hipLaunchKernelGGL(k_classify_unrel,dim3(nreads),dim3(WAVE),0,st,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
                      (int32_t *)ws->ord.p);
-  // size classes: N <= 256 eight reads per wave, 256 < N <= 1024 two reads per wave, larger: sequential kernel above
+  // size classes (kernels.hip: UNREL_SMALL_*): N <= 256 four reads per wave, up to 1024 two reads per wave, larger: sequential kernel above
   ENSURE(ws->memo_val,(size_t)totalI*8*8);
   ENSURE(ws->memo_key,(size_t)totalI*8*4);
   hipLaunchKernelGGL(k_order_by_work,dim3(1),dim3(1024),0,st,(const int32_t *)ws->nintvl.p,nreads,0,(int32_t *)ws->perm.p);

@@ -76,10 +76,37 @@ CP_HD double cp_bessi1(double x)
         }                                                               \
     }
 
-// (Tried and dropped: testing the bound once per 2 or 4 steps -- fmax of the new values, or a conservative
-//  integer test of their high words -- and replaying a tripped group with the per-step test.  Exact, but
-//  7.65-8.07 ms per bench step against 7.23 for the per-step test below; so is writing the odd last step
-//  as a loop instead of an `if`: 7.66.)
+// One step with the rescale applied as a multiplication by 1.0 or 1e-10 (multiplying by 1.0 is exact, so the
+// values are those of the reference's `if`).  scripts/microbench/bessi_bench.hip, ms for the same work with
+// 1 / 3 / 8 waves per SIMD:  branch per step, unrolled by 2: 1.67 / 2.11 / 4.44;  unrolled by 4: 1.32 /
+// 2.01 / 4.13;  one test per 2 or 4 steps with an exact replay of a tripped group: slower than either;
+// no test at all (inexact bound): 0.73 / 1.17 / 2.67;  this form, unrolled by 4: 0.84 / 1.93 / 4.66.  The
+// classify kernels run at 1-3 waves per SIMD and their long reads finish alone, so this form is used.
+#define CP_BESSI_STEPF(t,a,b,WITH_ANS)                                  \
+  { t = a+dj*tox*b;                                                     \
+    dj -= 1.0;                                                          \
+    const double s_ = fabs(t) > 1.0e10 ? 1.0e-10 : 1.0;                 \
+    t *= s_; b *= s_;                                                   \
+    if (WITH_ANS) ans *= s_;                                            \
+  }
+#define CP_BESSI_LOOP(WITH_ANS)                                         \
+  for (; c >= 4; c -= 4)                                                \
+    { CP_BESSI_STEPF(t1,a,b,WITH_ANS)                                   \
+      CP_BESSI_STEPF(t2,b,t1,WITH_ANS)                                  \
+      CP_BESSI_STEPF(t3,t1,t2,WITH_ANS)                                 \
+      CP_BESSI_STEPF(t4,t2,t3,WITH_ANS)                                 \
+      a = t3; b = t4;                                                   \
+    }                                                                   \
+  if (c >= 2)                                                           \
+    { CP_BESSI_STEPF(t1,a,b,WITH_ANS)                                   \
+      CP_BESSI_STEPF(t2,b,t1,WITH_ANS)                                  \
+      a = t1; b = t2; c -= 2;                                           \
+    }                                                                   \
+  if (c == 1)                                                           \
+    { CP_BESSI_STEPF(t1,a,b,WITH_ANS)                                   \
+      a = b; b = t1;                                                    \
+    }
+
 CP_HD double cp_bessi(int n, double x)
 { if (n == 0) return cp_bessi0(x);
   if (n == 1) return cp_bessi1(x);
@@ -87,30 +114,14 @@ CP_HD double cp_bessi(int n, double x)
   const double tox = 2.0/fabs(x);
   const int jmax = 2*(n+(int)sqrt(40.0*n));
   double dj = (double)jmax;
-  double a = 0.0, b = 1.0, t1, t2, ans = 0.0;            // a = bip (older), b = bi (newer)
+  double a = 0.0, b = 1.0, t1, t2, t3, t4, ans = 0.0;    // a = bip (older), b = bi (newer)
   // j = jmax .. n: ans is still 0, so the reference's `ans *= BIGNI` is a no-op here (bessel.c:500-509)
   int c = jmax-n+1;
-  for (; c >= 2; c -= 2)
-    { CP_BESSI_STEP(t1,a,b,false)
-      CP_BESSI_STEP(t2,b,t1,false)
-      a = t1; b = t2;
-    }
-  if (c == 1)
-    { CP_BESSI_STEP(t1,a,b,false)
-      a = b; b = t1;
-    }
+  CP_BESSI_LOOP(false)
   ans = a;                                               // `if (j == n) ans = bip` (bessel.c:510)
   // j = n-1 .. 1
   c = n-1;
-  for (; c >= 2; c -= 2)
-    { CP_BESSI_STEP(t1,a,b,true)
-      CP_BESSI_STEP(t2,b,t1,true)
-      a = t1; b = t2;
-    }
-  if (c == 1)
-    { CP_BESSI_STEP(t1,a,b,true)
-      a = b; b = t1;
-    }
+  CP_BESSI_LOOP(true)
   ans *= cp_bessi0(x)/b;
   return (x < 0.0 && (n & 1)) ? -ans : ans;
 }

@@ -959,14 +959,17 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
 #ifndef REL_SMALL_G
 #define REL_SMALL_G 2
 #endif
+// Chosen on the bench batch (per read: M <= 132, N <= 230; a read that falls into the next class runs alone
+// there, and a lone wave was the tail of its stage): with (MAXM; G,MAXN) = (128; 8,192) 6.68 ms per step,
+// (192; 8,192) 6.48, (128; 4,256) 6.51, (192; 4,256) 6.31, (256; 4,256) 6.29.
 #ifndef REL_SMALL_MAXM
-#define REL_SMALL_MAXM 128
+#define REL_SMALL_MAXM 256
 #endif
 #ifndef UNREL_SMALL_G
-#define UNREL_SMALL_G 8
+#define UNREL_SMALL_G 4
 #endif
 #ifndef UNREL_SMALL_MAXN
-#define UNREL_SMALL_MAXN 192             // (8,256): 7.40 ms per step, (4,256): 7.24, (8,192): 7.22, (8,128): 7.55
+#define UNREL_SMALL_MAXN 256
 #endif
 #ifndef REL_WAVES_PER_EU
 #define REL_WAVES_PER_EU 1
