@@ -471,14 +471,7 @@ extern "C" int cp_seq_context(const char *d_seq, const int64_t *d_seq_off, int n
 }
 
 #ifdef CP_PROF_WALK
-// diagnostic builds only: cycle accumulators of the candidate walk (see cp_wall.h), then reset
-extern "C" int cp_debug_walk_prof(unsigned long long *out16)
-{ HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpyFromSymbol(out16,HIP_SYMBOL(g_walk_prof),16*sizeof(unsigned long long)));
-  unsigned long long z[16] = {0};
-  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_walk_prof),z,sizeof(z)));
-  return CP_OK;
-}
+// diagnostic builds only: per-phase wave times of k_find_wall (max / sum / arg-max over reads), then reset
 extern "C" int cp_debug_phase_prof(unsigned long long *out24)
 { HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpyFromSymbol(out24,HIP_SYMBOL(g_phase_max),8*sizeof(unsigned long long)));

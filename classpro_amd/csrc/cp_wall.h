@@ -29,39 +29,91 @@ struct cp_perr_dense
   { double *a;
     CP_HDM double get(int pos, int e, int w) const { return a[(size_t)pos*4+e*2+w]; }
     CP_HDM void   set(int pos, int e, int w, double v) { a[(size_t)pos*4+e*2+w] = v; }
+    // handle API: the cell of (pos,e,w), created unset if the store is sparse
+    CP_HDM long long cell(int pos, int e, int w) { return (long long)pos*4+e*2+w; }
+    CP_HDM double    load(long long c) const { return a[c]; }
+    CP_HDM void      store(long long c, double v) { a[c] = v; }
   };
 
 // sparse store: open addressing, linear probing, insert-only; keys[] start at -1, a slot's four
 // values are set to -inf when the slot is claimed.  Capacity (mask+1) is a power of two >= 4*ncand+16
 // while at most 3*ncand+2 positions can ever be touched, so the table never fills.
 struct cp_perr_hash
-  { int32_t *keys;
+  { int32_t *keys;                 // table of error type e at keys+e*tsize, vals+e*tsize*4
     double  *vals;
-    uint32_t mask;
+    uint32_t mask;                 // tsize-1
     CP_HDM uint32_t slot0(int pos) const { return ((uint32_t)pos*0x9E3779B1u >> 7) & mask; }
     CP_HDM double get(int pos, int e, int w) const
-    { uint32_t h = slot0(pos);
+    { const int32_t *ke = keys+(size_t)e*(mask+1);
+      uint32_t h = slot0(pos);
       while (true)
-        { int32_t k = keys[h];
-          if (k == pos) return vals[(size_t)h*4+e*2+w];
+        { int32_t k = ke[h];
+          if (k == pos) return vals[((size_t)e*(mask+1)+h)*4+e*2+w];
           if (k < 0) return -INFINITY;
           h = (h+1) & mask;
         }
     }
-    CP_HDM void set(int pos, int e, int w, double v)
-    { uint32_t h = slot0(pos);
+    CP_HDM long long cell(int pos, int e, int w)
+    { int32_t *ke = keys+(size_t)e*(mask+1);
+      double *ve = vals+(size_t)e*(mask+1)*4;
+      uint32_t h = slot0(pos);
       while (true)
-        { int32_t k = keys[h];
+        { int32_t k = ke[h];
           if (k == pos) break;
           if (k < 0)
-            { keys[h] = pos;
-              for (int x = 0; x < 4; x++) vals[(size_t)h*4+x] = -INFINITY;
+            { ke[h] = pos;
+              for (int x = 0; x < 4; x++) ve[(size_t)h*4+x] = -INFINITY;
               break;
             }
           h = (h+1) & mask;
         }
-      vals[(size_t)h*4+e*2+w] = v;
+      return ((long long)e*(mask+1)+h)*4+e*2+w;
     }
+    CP_HDM double load(long long c) const { return vals[c]; }
+    CP_HDM void   store(long long c, double v) { vals[c] = v; }
+    CP_HDM void   set(int pos, int e, int w, double v) { store(cell(pos,e,w),v); }
+  };
+
+#ifdef __HIP_DEVICE_COMPILE__
+// real LDS pointers: a generic (flat) access would also wait for the replay's outstanding global stores
+#define CP_LDS_PTR(T) __attribute__((address_space(3))) T *
+#else
+#define CP_LDS_PTR(T) T *
+#endif
+struct cp_perr_hybrid
+  { cp_perr_hash g;
+    CP_LDS_PTR(int32_t) lkeys;    // -1 = empty; the OTHERS table follows the SELF table
+    CP_LDS_PTR(double)  lvals;
+    int                 lcap0, lcap1;   // slots of the SELF / OTHERS table (powers of two)
+    int                 use_lds;        // bit e: pass e keeps its memo on chip
+    CP_HDM double get(int pos, int e, int w) const
+    { if (!((use_lds >> e) & 1)) return g.get(pos,e,w);
+      const int key = pos*2+w, off = e ? lcap0 : 0;
+      const uint32_t m = (uint32_t)(e ? lcap1 : lcap0)-1;
+      uint32_t h = ((uint32_t)key*0x9E3779B1u >> 9) & m;
+      while (true)
+        { int32_t k = lkeys[off+h];
+          if (k == key) return lvals[off+h];
+          if (k < 0) return -INFINITY;
+          h = (h+1) & m;
+        }
+    }
+    CP_HDM long long cell(int pos, int e, int w)
+    { if (!((use_lds >> e) & 1)) return g.cell(pos,e,w);
+      const int key = pos*2+w, off = e ? lcap0 : 0;
+      const uint32_t m = (uint32_t)(e ? lcap1 : lcap0)-1;
+      uint32_t h = ((uint32_t)key*0x9E3779B1u >> 9) & m;
+      while (true)
+        { int32_t k = lkeys[off+h];
+          if (k == key) break;
+          if (k < 0) { lkeys[off+h] = key; lvals[off+h] = -INFINITY; break; }
+          h = (h+1) & m;
+        }
+      return -1-(long long)(off+h);                     // negative: an on-chip cell
+    }
+    CP_HDM double load(long long c) const { return c < 0 ? lvals[-1-c] : g.load(c); }
+    CP_HDM void   store(long long c, double v) { if (c < 0) lvals[-1-c] = v; else g.store(c,v); }
+    CP_HDM void   set(int pos, int e, int w, double v) { store(cell(pos,e,w),v); }
   };
 
 // SEQ / PROF / LF: anything indexable like the read's bases, its counts and the log-factorial table
@@ -75,36 +127,34 @@ struct cp_read_t
     int                  plen, rlen;
     uint8_t             *wall;      // flags written by the OTHERS pass + PAIRED_M/ERROR (and everything, if shared)
     uint8_t             *wall_s;    // flags written by the SELF pass (may alias `wall`: the bits are disjoint)
-    PE                   perror[2]; // memo per error type (may share storage: entries are keyed by etype too)
+    PE                   perror;    // memo of both error types (one object: indexing an array of stores by the
+                                    // error type at run time would push the whole record into scratch memory)
     cp_eintvl           *eintvl, *ointvl;
     int                  ecap;
     int                  eidx, oidx;
     int                  overflow;
-#ifdef CP_PROF_WALK
-    long long            tacc[8] = {0,0,0,0,0,0,0,0};
-#endif
+    // Device replay only (use_win != 0): the "already paired" flag of a pass (wall.c:639) is set by that
+    // pass alone, on partners at most K+25 positions ahead in all but pathological low-complexity runs, so
+    // the lane that replays the pass keeps it in a 128-position bit window instead of re-reading the flag
+    // array (a cold miss per candidate); a partner beyond the window switches the window off for the rest
+    // of the read, after which the flags -- always written -- are read as in the reference.
+    int                  use_win = 0, win_base = 0;
+    uint64_t             win_lo = 0, win_hi = 0;
+    // Device replay only: the OTHERS pass's "wall by the count change alone" stores (CP_CF_WALLNOW, most real
+    // walls) were issued for all candidates at once before the replay, which then only visits live
+    // candidates.  The reference skips such a store when an earlier pair took the position as its partner;
+    // the replay restores that by writing the partner's flag byte outright when it accepts a pair.
+    int                  spec_wallnow = 0;
   };
 
-// Diagnostic build (-DCP_PROF_WALK): cycle accumulators per region of the walk, summed per pass into
-// g_walk_prof by k_find_wall and read back with cp_debug_walk_prof.  Not part of the product build.
-#if defined(CP_PROF_WALK) && defined(__HIP_DEVICE_COMPILE__)
-#define CP_T0(R,k) ((R)->tacc[k] -= (long long)wall_clock64())
-#define CP_T1(R,k) ((R)->tacc[k] += (long long)wall_clock64())
-#define CP_TC(R,k) ((R)->tacc[k] += 1)
-#else
-#define CP_T0(R,k) ((void)0)
-#define CP_T1(R,k) ((void)0)
-#define CP_TC(R,k) ((void)0)
-#endif
-
-#define CP_PERR(R,i,e,w) ((R)->perror[e].get(i,e,w))
+#define CP_PERR(R,i,e,w) ((R)->perror.get(i,e,w))
 #define CP_NEG_INF (-INFINITY)
 
 // wall.c:310-315
 template <class RD>
 CP_HD void cp_update_perror(RD *R, int i, int e, int w, int cout, int cin, double erate, double lpe, double l1mpe)
 { if (CP_PERR(R,i,e,w) == CP_NEG_INF)
-    R->perror[e].set(i,e,w,cp_p_errorin(R->lf,e,erate,lpe,l1mpe,cout,cin));
+    R->perror.set(i,e,w,cp_p_errorin(R->lf,e,erate,lpe,l1mpe,cout,cin));
 }
 
 // wall.c:317-322
@@ -188,36 +238,37 @@ CP_HD void cp_wall_candidate_pre(const RD *R, int i, cp_wall_pre *pre)
   pre->l1mpe = P->l1mpe[maxt][maxl];
 }
 
-template <class RD>
-CP_HD void cp_wall_candidate_pure(RD *R, int i, int e, const cp_wall_pre &pre, cp_cand_pure *out)
-{ const cp_dev_params *P = R->P;
-  const auto &pr = R->prof;
-  const int plen = R->plen, K = P->K, CMAX = P->cmax;
-  const int cng = pre.cng, w = pre.wtype, cin = pre.cin, cout = pre.cout;
-  const int t = pre.maxt, l = pre.maxl;
-  out->flags = 0; out->lc_kind = CP_LC_NONE; out->lc_j = -1; out->hc_j = -1;
-  out->own_pe = out->lc_v = out->hc_pe = CP_NEG_INF;
-
+// The threshold filters of one pass (wall.c:643-653, 672-676): 0, CP_CF_WALLNOW or CP_CF_LIVE.
+CP_HD int cp_wall_candidate_filter(const cp_dev_params *P, int e, const cp_wall_pre &pre)
+{ const int CMAX = P->cmax;
+  const int cng = pre.cng, cin = pre.cin, cout = pre.cout;
   int ct_init = 0, ct_final = 0;
   if (cout < CMAX)                                       // wall.c:643-648
-    { ct_init  = P->cthres[t][l][cout][CP_INIT][e];
-      ct_final = P->cthres[t][l][cout][CP_FINAL][e];
+    { ct_init  = P->cthres[pre.maxt][pre.maxl][cout][CP_INIT][e];
+      ct_final = P->cthres[pre.maxt][pre.maxl][cout][CP_FINAL][e];
       if (!(cng > CP_MAX_CNT_CHANGE || cin < (ct_init > 3 ? ct_init : 3)))
-        return;
+        return 0;
     }
   if (e == CP_SELF)                                      // wall.c:651-653
     { if (cout < CMAX && cin >= ct_final)
-        return;
+        return 0;
     }
   else if (cng >= P->cov[CP_HAPLO] || (cout < CMAX && cin < ct_final))       // wall.c:672-676
-    { out->flags = CP_CF_WALLNOW;
-      return;
-    }
-  out->flags = CP_CF_LIVE;
-  CP_TC(R,5); CP_T0(R,1);
+    return CP_CF_WALLNOW;
+  return CP_CF_LIVE;
+}
+
+// The expensive, read-only part of a pass whose filter said CP_CF_LIVE.
+template <class RD>
+CP_HD void cp_wall_candidate_live(RD *R, int i, int e, const cp_wall_pre &pre, cp_cand_pure *out)
+{ const cp_dev_params *P = R->P;
+  const auto &pr = R->prof;
+  const int plen = R->plen, K = P->K, CMAX = P->cmax;
+  const int w = pre.wtype, cin = pre.cin, cout = pre.cout;
+  const int t = pre.maxt, l = pre.maxl;
+  out->flags = CP_CF_LIVE; out->lc_kind = CP_LC_NONE; out->lc_j = -1; out->hc_j = -1;
+  out->lc_v = out->hc_pe = CP_NEG_INF;
   out->own_pe = cp_p_errorin(R->lf,e,pre.maxpe,pre.lpe,pre.l1mpe,cout,cin);
-  CP_T1(R,1);
-  CP_T0(R,2);
 
   // find_gain (w == DROP: partner GAIN to the right of i) / find_drop (w == GAIN: partner DROP to the
   // left), wall.c:331-507, folded into one routine by mirroring the index arithmetic.
@@ -238,9 +289,7 @@ CP_HD void cp_wall_candidate_pure(RD *R, int i, int e, const cp_wall_pre &pre, c
     }
   j = right ? (i+K-1)+n-m : (i-K+1)-n+m;
   if (right ? (j <= i) : (j >= i))
-    { CP_T1(R,2);
-      return;                                            // lc_kind NONE: no pair at all (wall.c:355 / 442)
-    }
+    return;                                              // lc_kind NONE: no pair at all (wall.c:355 / 442)
   if (right ? (j >= plen) : (j <= 0))
     { out->lc_kind = CP_LC_BOUNDARY;
       out->lc_j = right ? plen : 0;
@@ -259,8 +308,6 @@ CP_HD void cp_wall_candidate_pure(RD *R, int i, int e, const cp_wall_pre &pre, c
         out->lc_kind = CP_LC_REJECT;
     }
 
-  CP_T1(R,2);
-  CP_T0(R,3);
   // high-complexity partners (wall.c:380-404 / 469-493)
   bool   have_pe_i = false;
   double pe_i = 0., max_pe = CP_NEG_INF;
@@ -291,7 +338,15 @@ CP_HD void cp_wall_candidate_pure(RD *R, int i, int e, const cp_wall_pre &pre, c
     }
   out->hc_j = max_j;
   out->hc_pe = max_pe;
-  CP_T1(R,3);
+}
+
+template <class RD>
+CP_HD void cp_wall_candidate_pure(RD *R, int i, int e, const cp_wall_pre &pre, cp_cand_pure *out)
+{ out->flags = cp_wall_candidate_filter(R->P,e,pre);
+  out->lc_kind = CP_LC_NONE; out->lc_j = -1; out->hc_j = -1;
+  out->own_pe = out->lc_v = out->hc_pe = CP_NEG_INF;
+  if (out->flags & CP_CF_LIVE)
+    cp_wall_candidate_live(R,i,e,pre,out);
 }
 
 // find_gain / find_drop with the memo state of the moment.  The reference keeps one running maximum
@@ -299,19 +354,22 @@ CP_HD void cp_wall_candidate_pure(RD *R, int i, int e, const cp_wall_pre &pre, c
 // strictly larger score; starting the high-complexity scan from -inf instead (cp_wall_candidate_pure)
 // and comparing its winner with the low-complexity score picks the same partner.
 template <class RD>
-CP_HD bool cp_find_pair_replay(RD *R, int i, int e, int w, const cp_cand_pure &c, cp_eintvl *out)
+CP_HD bool cp_find_pair_replay(RD *R, int i, int e, int w, const cp_cand_pure &c, double pe_i, cp_eintvl *out)
 { if (c.lc_kind == CP_LC_NONE)
     return false;
   const bool right = (w == CP_DROP);
   int max_j = -1;
   double pe = CP_NEG_INF, max_pe = CP_NEG_INF;
   if (c.lc_kind == CP_LC_BOUNDARY)
-    pe = CP_PERR(R,i,e,w) * CP_PERR(R,i,e,w);
+    pe = pe_i * pe_i;                                     // pe_i = perror[i][e][w], read by the caller
   else if (c.lc_kind == CP_LC_PAIR)
-    { if (CP_PERR(R,c.lc_j,e,1-w) == CP_NEG_INF)            // update_perror(j), wall.c:310-315
-        R->perror[e].set(c.lc_j,e,1-w,c.lc_v);
-      pe = right ? CP_PERR(R,i,e,CP_DROP)*CP_PERR(R,c.lc_j,e,CP_GAIN)
-                 : CP_PERR(R,c.lc_j,e,CP_DROP)*CP_PERR(R,i,e,CP_GAIN);
+    { const long long cj = R->perror.cell(c.lc_j,e,1-w);
+      double pe_j = R->perror.load(cj);
+      if (pe_j == CP_NEG_INF)                             // update_perror(j), wall.c:310-315
+        { pe_j = c.lc_v;
+          R->perror.store(cj,pe_j);
+        }
+      pe = right ? pe_i*pe_j : pe_j*pe_i;                 // perror[.][DROP] * perror[.][GAIN]
     }
   if (max_pe < pe)
     { max_j  = c.lc_j;
@@ -330,41 +388,76 @@ CP_HD bool cp_find_pair_replay(RD *R, int i, int e, int w, const cp_cand_pure &c
 }
 
 template <class RD>
+CP_HD bool cp_win_paired(RD *R, int i)                  // advance the window to position i; is i paired?
+{ const int d = i-R->win_base;
+  if (d >= 128)     { R->win_lo = R->win_hi = 0; }
+  else if (d >= 64) { R->win_lo = R->win_hi >> (d-64); R->win_hi = 0; }
+  else if (d > 0)   { R->win_lo = (R->win_lo >> d) | (R->win_hi << (64-d)); R->win_hi >>= d; }
+  R->win_base = i;
+  return (R->win_lo & 1) != 0;
+}
+template <class RD>
+CP_HD void cp_win_mark(RD *R, int j)                    // position j is now paired
+{ const int d = j-R->win_base;
+  if (d <= 0) return;                                   // behind the walk: never asked again
+  if (d < 64)       R->win_lo |= 1ull << d;
+  else if (d < 128) R->win_hi |= 1ull << (d-64);
+  else              R->use_win = 0;                     // out of reach: fall back to the flag array from here on
+}
+
+template <class RD>
 CP_HD void cp_wall_candidate_replay(RD *R, int i, int e, int wtype, const cp_cand_pure &c)
-{ if (e == CP_SELF ? (R->wall_s[i] & CP_W_PAIRED_S) : (R->wall[i] & CP_W_PAIRED_O))      // wall.c:639
+{ // wall.c:639.  With the window, "not paired" also means the pass has not written position i yet.
+  const bool win = R->use_win != 0;
+  if (win ? cp_win_paired(R,i)
+          : (e == CP_SELF ? (R->wall_s[i] & CP_W_PAIRED_S) != 0 : (R->wall[i] & CP_W_PAIRED_O) != 0))
     return;
   if (c.flags == 0)
     return;
   if (c.flags & CP_CF_WALLNOW)
-    { R->wall[i] |= CP_W_WALL_O;
+    { if (win) R->wall[i] = CP_W_WALL_O; else R->wall[i] |= CP_W_WALL_O;
       return;
     }
-  if (CP_PERR(R,i,e,wtype) == CP_NEG_INF)                  // update_perror(i), wall.c:310-315
-    R->perror[e].set(i,e,wtype,c.own_pe);
+  const long long ci = R->perror.cell(i,e,wtype);
+  double pe_i = R->perror.load(ci);
+  if (pe_i == CP_NEG_INF)                                  // update_perror(i), wall.c:310-315
+    { pe_i = c.own_pe;
+      R->perror.store(ci,pe_i);
+    }
   cp_eintvl I;
   if (e == CP_SELF)                                      // wall.c:651-670
-    { if (CP_PERR(R,i,e,wtype) < CP_PE_THRES_FINAL)
+    { if (pe_i < CP_PE_THRES_FINAL)
         return;
-      if (cp_find_pair_replay(R,i,e,wtype,c,&I) && I.pe >= CP_PE_THRES_FINAL)
-        { R->wall_s[I.b] |= (CP_W_WALL_S|CP_W_PAIRED_S);
-          R->wall_s[I.e] |= (CP_W_WALL_S|CP_W_PAIRED_S);
+      if (cp_find_pair_replay(R,i,e,wtype,c,pe_i,&I) && I.pe >= CP_PE_THRES_FINAL)
+        { if (win)                                       // the SELF array only ever holds these two bits
+            { R->wall_s[I.b] = (CP_W_WALL_S|CP_W_PAIRED_S);
+              R->wall_s[I.e] = (CP_W_WALL_S|CP_W_PAIRED_S);
+              cp_win_mark(R,I.b == i ? I.e : I.b);
+            }
+          else
+            { R->wall_s[I.b] |= (CP_W_WALL_S|CP_W_PAIRED_S);
+              R->wall_s[I.e] |= (CP_W_WALL_S|CP_W_PAIRED_S);
+            }
           if (R->eidx < R->ecap) R->eintvl[R->eidx++] = I;
           else R->overflow = 1;
         }
     }
   else                                                   // wall.c:671-690
-    { if (CP_PERR(R,i,e,wtype) < CP_PE_THRES_FINAL)
-        { R->wall[i] |= CP_W_WALL_O;
+    { if (pe_i < CP_PE_THRES_FINAL)
+        { if (win) R->wall[i] = CP_W_WALL_O; else R->wall[i] |= CP_W_WALL_O;
           return;
         }
-      if (cp_find_pair_replay(R,i,e,wtype,c,&I) && I.pe >= CP_PE_THRES_FINAL)
-        { R->wall[I.b] |= CP_W_PAIRED_O;
-          R->wall[I.e] |= CP_W_PAIRED_O;
+      if (cp_find_pair_replay(R,i,e,wtype,c,pe_i,&I) && I.pe >= CP_PE_THRES_FINAL)
+        { const int j = (I.b == i) ? I.e : I.b;
+          R->wall[i] |= CP_W_PAIRED_O;
+          if (R->spec_wallnow && j > i) R->wall[j] = CP_W_PAIRED_O;    // not reached yet: the reference has 0 there
+          else                          R->wall[j] |= CP_W_PAIRED_O;
+          if (win) cp_win_mark(R,j);
           if (R->oidx < R->ecap) R->ointvl[R->oidx++] = I;
           else R->overflow = 1;
           return;
         }
-      R->wall[i] |= CP_W_WALL_O;
+      if (win) R->wall[i] = CP_W_WALL_O; else R->wall[i] |= CP_W_WALL_O;
     }
 }
 

@@ -242,7 +242,6 @@ __device__ __forceinline__ void wave_wall_or(uint8_t *wall, int b, int e, uint8_
 //  k_find_wall: wall.c:570-958, one wave per read.
 // ---------------------------------------------------------------------------------------------
 #ifdef CP_PROF_WALK
-__device__ unsigned long long g_walk_prof[16];
 __device__ unsigned long long g_phase_max[8], g_phase_sum[8], g_phase_arg[8];
 #define PH_STAMP(k) do { if (lane == 0) { unsigned long long t_ = wall_clock64(); unsigned long long d_ = t_-ph_t; ph_t = t_; \
       atomicAdd(&g_phase_sum[k],d_); unsigned long long o_ = atomicMax(&g_phase_max[k],d_); if (d_ > o_) g_phase_arg[k] = ((unsigned long long)r << 32) | (unsigned)n_c; } } while (0)
@@ -272,17 +271,24 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   const int plen = (int)(prof_off[r+1]-po);
   const int rlen = (int)(seq_off[r+1]-seq_off[r]);
 
-  cp_read_t<cp_perr_hash> R;
+  constexpr int LCAP0 = 256, LCAP1 = 64;                 // on-chip memo slots of the SELF / OTHERS pass
+  __shared__ int32_t s_mkey[LCAP0+LCAP1];
+  __shared__ double  s_mval[LCAP0+LCAP1];
+  cp_read_t<cp_perr_hybrid> R;
   R.P = P; R.prof = prof+po; R.seq = seq+seq_off[r]; R.lf = P->logfact; R.plen = plen; R.rlen = rlen;
   R.wall = wall_all+po+r;
   R.wall_s = walls_all+po+r;
   { const int64_t ho = hoff[r], hc = (hoff[r+1]-ho) >> 1;     // two tables, one per error type
-    for (int e = 0; e < 2; e++)
-      { R.perror[e].keys = hkeys+ho+e*hc;
-        R.perror[e].vals = hvals+(ho+e*hc)*4;
-        R.perror[e].mask = (uint32_t)hc-1;
-      }
+    R.perror.g.keys = hkeys+ho;
+    R.perror.g.vals = hvals+ho*4;
+    R.perror.g.mask = (uint32_t)hc-1;
+    R.perror.lkeys = (CP_LDS_PTR(int32_t))s_mkey;
+    R.perror.lvals = (CP_LDS_PTR(double))s_mval;
+    R.perror.lcap0 = LCAP0; R.perror.lcap1 = LCAP1;
+    R.perror.use_lds = 0;
   }
+  for (int k = lane; k < LCAP0+LCAP1; k += WAVE)
+    s_mkey[k] = -1;
   R.eintvl = eintvl_all+eoff[r];
   R.ointvl = ointvl_all+eoff[r];
   R.ecap = (int)(eoff[r+1]-eoff[r]);
@@ -298,15 +304,21 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   // 200-Mbase batch do not stay in L2), a candidate's loads depend on each other, and its Bessel /
   // binomial-tail evaluations are long serial chains.  The walk is therefore split (cp_wall.h):
   //   0. the wave lists the read's candidate positions from the bitmap (64 words per step);
-  //   1. for 64 candidates at a time, lane k evaluates everything about candidate k that is a function
-  //      of the read alone (cp_wall_candidate_pre, cp_wall_candidate_pure for both error types) --
-  //      64 chains in parallel -- and leaves the results in LDS;
+  //   1a. 64 candidates at a time, lane k evaluates candidate k's shared prelude and the threshold
+  //       filters of both error types (cp_wall_candidate_pre / _filter) and the (candidate, error type)
+  //       pairs that stay alive -- ~40 % for SELF, ~3 % for OTHERS -- are appended to a task list;
+  //   1b. 64 tasks at a time, lane k evaluates everything else about its pair that is a function of the
+  //       read alone (cp_wall_candidate_live: own P(error), low-complexity partner, best high-complexity
+  //       partner).  Dense lanes matter: this is where the kernel's instructions are;
   //   2. the candidates are replayed in order (cp_wall_candidate_replay: paired flags, perror memo,
   //      flag and interval-list updates), the SELF pass on lane 0 and the OTHERS pass on lane 1
   //      (disjoint state: own flag array, own memo table, own interval list).
-  __shared__ double s_own[2][WAVE], s_lcv[2][WAVE], s_hcpe[2][WAVE];
-  __shared__ int    s_lcj[2][WAVE], s_hcj[2][WAVE], s_flags[2][WAVE], s_pos[WAVE], s_wtype[WAVE];
-  int32_t *clist = wl+icap;                             // free until the components are built below
+  // Scratch: the four int lists of `wl` (free until the post-walk phases) hold per candidate
+  // [0] maxt,maxl and both filter results, [1] the position, [2] the count pair, and [3] the task list;
+  // task results stay on chip.
+  struct task_res { double own_pe, lc_v, hc_pe; int lc_j, hc;  };   // hc: lc_kind | (hc_j >= 0) << 2 | (hc_j - i) << 16
+  __shared__ task_res s_res[WAVE];
+  int32_t *cinfo = wl, *clist = wl+icap, *ccnt = wl+2*(int64_t)icap, *tlist = wl+3*(int64_t)icap;
   int n_c = 0;
 #ifdef CP_PROF_WALK
   unsigned long long ph_t = wall_clock64();
@@ -333,58 +345,85 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   if (n_c > icap) n_c = icap;                           // cannot happen: icap = 2*ncand+4
   wave_sync();
   PH_STAMP(0);
-#ifdef CP_PROF_WALK
-  if (lane < 2 && plen > 1) CP_T0(&R,0);
-#endif
-  for (int base = 0; base < n_c; base += WAVE)
-    { const int nb = (n_c-base < WAVE) ? n_c-base : WAVE;
-#ifdef CP_PROF_WALK
-      CP_T0(&R,4);
-#endif
-      if (lane < nb)
+  int n_t = 0, n_live0 = 0;                             // tasks so far, SELF tasks among them
+  for (int base = 0; base < n_c; base += WAVE)          // 1a
+    { int f0 = 0, f1 = 0;
+      if (base+lane < n_c)
         { const int i = clist[base+lane];
           cp_wall_pre pre;
           cp_wall_candidate_pre(&R,i,&pre);
-          s_pos[lane] = i;
-          s_wtype[lane] = pre.wtype;
-          unsigned touch = (unsigned)wall[i] | (unsigned)wall_s[i];
-          asm volatile("" :: "v"(touch));               // keep the two flag loads (they warm the cache)
-#pragma unroll 1
-          for (int e = 0; e < 2; e++)
+          f0 = cp_wall_candidate_filter(P,CP_SELF,pre);
+          f1 = cp_wall_candidate_filter(P,CP_OTHERS,pre);
+          cinfo[base+lane] = pre.maxt*32+pre.maxl+(f0 << 8)+(f1 << 12);
+          ccnt[base+lane] = (int)R.prof[i-1] | ((int)R.prof[i] << 16);
+          if (f1 & CP_CF_WALLNOW) wall[i] = CP_W_WALL_O;   // ahead of the replay, see cp_read_t::spec_wallnow
+        }
+      const int l0 = (f0 & CP_CF_LIVE) ? 1 : 0, l1 = (f1 & CP_CF_LIVE) ? 1 : 0;
+      int c = l0+l1, off = c;
+      for (int o = 1; o < WAVE; o <<= 1)
+        { int x = __shfl_up(off,o); if (lane >= o) off += x; }
+      const int tot = __shfl(off,WAVE-1);
+      off = n_t+off-c;
+      if (l0) { if (off < icap) tlist[off] = (base+lane)*2;   off++; }
+      if (l1) { if (off < icap) tlist[off] = (base+lane)*2+1; }
+      n_t += tot;
+      n_live0 += __popcll(__ballot(l0));
+    }
+  if (n_t > icap) { R.overflow = 1; n_t = 0; n_c = 0; }   // cannot happen: 2*n_c <= icap
+  // a pass memoises at most two entries per live candidate (its own and its low-complexity partner's)
+  R.perror.use_lds = ((8*n_live0 <= 3*LCAP0) ? 1 : 0) | ((8*(n_t-n_live0) <= 3*LCAP1) ? 2 : 0);
+  wave_sync();
+  // 1b + 2, 64 tasks at a time: lane k evaluates task k and leaves the result in LDS; then the chunk is
+  //    replayed in order, lane 0 taking the SELF tasks and lane 1 the OTHERS tasks (one lane active per task;
+  //    position and count pair come from the evaluating lane's registers by readlane).
+  if (lane < 2)
+    { R.use_win = (P->K+24+CP_MAX_N_HC < 128) ? 1 : 0;
+      R.win_base = 0; R.win_lo = R.win_hi = 0;
+      R.spec_wallnow = 1;
+    }
+  for (int tb = 0; tb < n_t; tb += WAVE)
+    { const int nb = (n_t-tb < WAVE) ? n_t-tb : WAVE;
+      int code_l = 0, cc_l = 0, pos_l = 1;
+      if (lane < nb)
+        { const int code = tlist[tb+lane], k = code >> 1, e = code & 1;
+          const int i = clist[k], tl = cinfo[k] & 255, cc = ccnt[k];
+          code_l = code; cc_l = cc; pos_l = i;
+          cp_wall_pre pre;
+          const int cim1 = cc & 0xffff, ci = (cc >> 16) & 0xffff;
+          pre.cng = cim1 > ci ? cim1-ci : ci-cim1;
+          if (cim1 > ci) { pre.wtype = CP_DROP; pre.cin = ci;   pre.cout = cim1; }
+          else           { pre.wtype = CP_GAIN; pre.cin = cim1; pre.cout = ci;   }
+          pre.maxt = tl >> 5; pre.maxl = tl & 31;
+          pre.maxpe = P->pe[pre.maxt][pre.maxl];
+          pre.lpe   = P->lpe[pre.maxt][pre.maxl];
+          pre.l1mpe = P->l1mpe[pre.maxt][pre.maxl];
+          cp_cand_pure c;
+          cp_wall_candidate_live(&R,i,e,pre,&c);
+          task_res q;
+          q.own_pe = c.own_pe; q.lc_v = c.lc_v; q.hc_pe = c.hc_pe;
+          q.lc_j = c.lc_j;
+          q.hc = c.lc_kind | (c.hc_j >= 0 ? 4 : 0) | ((c.hc_j >= 0 ? c.hc_j-i : 0) << 16);
+          s_res[lane] = q;
+        }
+      wave_sync();
+      PH_STAMP(6);
+      for (int k = 0; k < nb; k++)
+        { const int code = __builtin_amdgcn_readlane(code_l,k), cc = __builtin_amdgcn_readlane(cc_l,k);
+          const int pos = __builtin_amdgcn_readlane(pos_l,k);
+          if (lane == (code & 1))
             { cp_cand_pure c;
-              cp_wall_candidate_pure(&R,i,e,pre,&c);
-              s_own[e][lane] = c.own_pe; s_lcv[e][lane] = c.lc_v; s_hcpe[e][lane] = c.hc_pe;
-              s_lcj[e][lane] = c.lc_j;   s_hcj[e][lane] = c.hc_j;
-              s_flags[e][lane] = c.flags | (c.lc_kind << 4);
+              const task_res &q = s_res[k];
+              c.flags = CP_CF_LIVE;
+              c.own_pe = q.own_pe; c.lc_v = q.lc_v; c.hc_pe = q.hc_pe;
+              c.lc_j = q.lc_j; c.lc_kind = q.hc & 3;
+              c.hc_j = (q.hc & 4) ? pos+(q.hc >> 16) : -1;
+              cp_wall_candidate_replay(&R,pos,lane,(cc & 0xffff) > ((cc >> 16) & 0xffff) ? CP_DROP : CP_GAIN,c);
             }
         }
       wave_sync();
-#ifdef CP_PROF_WALK
-      CP_T1(&R,4);
-      CP_T0(&R,6);
-#endif
-      if (lane < 2)
-        for (int k = 0; k < nb; k++)
-          { cp_cand_pure c;
-            const int f = s_flags[lane][k];
-            c.flags = f & 15; c.lc_kind = f >> 4;
-            c.own_pe = s_own[lane][k]; c.lc_v = s_lcv[lane][k]; c.hc_pe = s_hcpe[lane][k];
-            c.lc_j = s_lcj[lane][k];   c.hc_j = s_hcj[lane][k];
-            cp_wall_candidate_replay(&R,s_pos[k],lane,s_wtype[k],c);
-          }
-      wave_sync();
-#ifdef CP_PROF_WALK
-      CP_T1(&R,6);
-#endif
+      PH_STAMP(1);
     }
-#ifdef CP_PROF_WALK
-  if (lane < 2 && plen > 1)
-    { CP_T1(&R,0);
-      for (int k = 0; k < 7; k++)
-        atomicAdd(&g_walk_prof[lane*8+k],(unsigned long long)R.tacc[k]);
-      if (lane == 0) atomicAdd(&g_walk_prof[7],1ull);
-    }
-#endif
+  R.use_win = 0; R.spec_wallnow = 0;
   PH_STAMP(1);
   int NS = __shfl(R.eidx,0), NO = __shfl(R.oidx,1);
   int overflow = __shfl(R.overflow,0) | __shfl(R.overflow,1);

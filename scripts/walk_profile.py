@@ -17,24 +17,13 @@ low, high, il, ih, h = ds["hist"]
 hc, dc = hist_covs(h, low, high, il, ih, 0)
 clf = Classifier(40, 20000, hc, dc)
 b = Batch.from_reads(ds["seqs"], ds["profiles"])
-out = (C.c_ulonglong * 16)()
 ph = (C.c_ulonglong * 24)()
 clf.run(b, STAGE_WALL)
-lib().cp_debug_walk_prof(out)
 lib().cp_debug_phase_prof(ph)
 clf.run(b, STAGE_WALL)
-lib().cp_debug_walk_prof(out)
 lib().cp_debug_phase_prof(ph)
-pn = ["0 candidate list", "1 walk (pure + replay)", "2 unwall/sort/olist", "3 wall_mult (lane 0)", "4 merge + sorts", "5 boundaries + records"]
-print("phase                          max over reads (ticks)   mean      argmax read / its ncand")
-for k in range(6):
-    print("  %-28s %12d %12.1f      %d / %d" % (pn[k], ph[k], ph[8 + k] / b.nreads, ph[16 + k] >> 32, ph[16 + k] & 0xffffffff))
-v = np.array(list(out), dtype=np.float64)
-names = ["walk total", "pure: own_pe", "pure: LC", "pure: HC", "phase 1 (pre+pure, wave)", "#live (lane view)", "phase 2 (replay, wave)"]
-nreads = v[7]
-for e, nm in ((0, "lane 0 (candidate 0 of each batch; pure timers cover both error types)"), (1, "lane 1")):
-    print(nm)
-    for k in range(7):
-        x = v[e * 8 + k]
-        print("   %-18s %14.0f  per read %10.1f" % (names[k], x, x / nreads))
-print("reads", nreads, "(clock = 100 MHz wall_clock64 ticks)")
+pn = ["0 candidate list", "1 replay (2 lanes)", "2 unwall/sort/olist", "3 wall_mult (lane 0)", "4 merge + sorts",
+      "5 boundaries + records", "6 prelude/filter + live tasks", "7 replay: chunk staging"]
+print("phase                          max over reads (ticks)   mean      argmax read / its ncand   (100 MHz ticks)")
+for k in (0, 6, 7, 1, 2, 3, 4, 5):
+    print("  %-30s %12d %12.1f      %d / %d" % (pn[k], ph[k], ph[8 + k] / b.nreads, ph[16 + k] >> 32, ph[16 + k] & 0xffffffff))

@@ -55,7 +55,7 @@ int hh_classify_read(void *Pv, const char *seq, int rlen, const uint16_t *prof, 
   std::vector<cp_eintvl> ev(ecap), ov(ecap);
   cp_read_t<cp_perr_dense> R;
   R.P = P; R.prof = prof; R.seq = seq; R.lf = P->logfact; R.plen = plen; R.rlen = rlen;
-  R.wall = wall.data(); R.wall_s = wall.data(); R.perror[0].a = R.perror[1].a = perror.data();
+  R.wall = wall.data(); R.wall_s = wall.data(); R.perror.a = perror.data();
   R.eintvl = ev.data(); R.ointvl = ov.data();
   R.ecap = ecap; R.eidx = R.oidx = 0; R.overflow = 0;
 
