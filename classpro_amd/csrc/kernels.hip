@@ -238,6 +238,67 @@ __device__ __forceinline__ void wave_wall_and(uint8_t *wall, int b, int e, uint8
 __device__ __forceinline__ void wave_wall_or(uint8_t *wall, int b, int e, uint8_t mask)
 { for (int j = b+lane_id(); j < e; j += WAVE) wall[j] |= mask; }
 
+// sort by (b,e) and keep the first of each run of equal (b,e) (wall.c:548-568, 734): rank sort into tmp,
+// then an ordered compaction back into v.  Returns the new length.
+__device__ int wave_sort_dedupe_eintvl(cp_eintvl *v, int n, cp_eintvl *tmp)
+{ if (n < 2) return n;
+  const int lane = lane_id();
+  for (int k = lane; k < n; k += WAVE)
+    { const cp_eintvl x = v[k];
+      int rank = 0;
+      for (int m = 0; m < n; m++)
+        rank += cp_eintvl_before(v[m],m,x,k) ? 1 : 0;
+      tmp[rank] = x;
+    }
+  wave_sync();
+  int out = 0;
+  for (int base = 0; base < n; base += WAVE)
+    { const int k = base+lane;
+      bool keep = false;
+      cp_eintvl x = { 0, 0, 0. };
+      if (k < n)
+        { x = tmp[k];
+          keep = (k == 0) || !(tmp[k-1].b == x.b && tmp[k-1].e == x.e);
+        }
+      const uint64_t m = __ballot(keep);
+      if (keep) v[out+__popcll(m & ((1ull << lane)-1))] = x;
+      out += __popcll(m);
+    }
+  wave_sync();
+  return out;
+}
+
+// wall.c:722-731 / 868-872: clear WALL_O at every position strictly inside one of the E-intervals ev[lo..hi).
+// OTHERS walls only exist at candidate positions, so the lanes test the candidates instead of sweeping
+// the flag array once per interval; the interval ends are staged in LDS (sbuf, 2*scap ints) when they fit.
+__device__ void wave_unwall_inside(uint8_t *wall, const int32_t *clist, int n_c, const cp_eintvl *ev, int lo, int hi,
+                                   int *sbuf, int scap)
+{ const int lane = lane_id();
+  const int n = hi-lo;
+  if (n <= 0) return;
+  const bool staged = n <= scap;
+  if (staged)
+    { for (int k = lane; k < n; k += WAVE)
+        { sbuf[2*k] = ev[lo+k].b; sbuf[2*k+1] = ev[lo+k].e; }
+      wave_sync();
+    }
+  for (int q = lane; q < n_c; q += WAVE)
+    { const int i = clist[q];
+      bool in = false;
+      if (staged)
+        for (int k = 0; k < n && !in; k++)
+          in = (sbuf[2*k] < i && i < sbuf[2*k+1]);
+      else
+        for (int k = lo; k < hi && !in; k++)
+          in = (ev[k].b < i && i < ev[k].e);
+      if (in)
+        { const uint8_t f = wall[i];
+          if (f & CP_W_WALL_O) wall[i] = f & (uint8_t)~CP_W_WALL_O;
+        }
+    }
+  wave_sync();
+}
+
 // ---------------------------------------------------------------------------------------------
 //  k_find_wall: wall.c:570-958, one wave per read.
 // ---------------------------------------------------------------------------------------------
@@ -431,55 +492,40 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   wave_sync();
 
   // ---- un-wall positions explained by O-pairs / inside E-intervals (wall.c:722-731) --------
+  // From here on the lists of the walk are dead except the candidate positions (clist, second quarter of
+  // wl); s_res is reused as an int buffer for short lists.
+  int *sbuf = reinterpret_cast<int *>(s_res);
+  constexpr int SBUF = (int)(sizeof(task_res)*WAVE/sizeof(int));      // 512 ints
   if (lane == 0)
     for (int k = 0; k < NO; k++)
       { wall[R.ointvl[k].b] &= ~CP_W_WALL_O;
         wall[R.ointvl[k].e] &= ~CP_W_WALL_O;
       }
   wave_sync();
-  for (int k = 0; k < NS; k++)
-    wave_wall_and(wall,R.eintvl[k].b+1,R.eintvl[k].e,(uint8_t)~CP_W_WALL_O);
-  wave_sync();
+  wave_unwall_inside(wall,clist,n_c,R.eintvl,0,NS,sbuf,SBUF/2);
 
   // ---- sort + dedupe E-intervals (wall.c:734); the O list is not used again ------------------
-  wave_sort_eintvl(R.eintvl,NS,R.ointvl);
-  if (lane == 0)
-    NS = cp_dedupe_sorted(R.eintvl,NS);
-  NS = __shfl(NS,0);
-  wave_sync();
+  NS = wave_sort_dedupe_eintvl(R.eintvl,NS,R.ointvl);
 
   // ---- multi-error / boundary E-intervals (wall.c:760-861) -----------------------------------
   // The reference scans every position for O-only walls; OTHERS walls are only ever set at wall
-  // candidates, so the lanes walk the candidate bitmap instead (64 words per step) and compact the
-  // qualifying positions, in order, into a short list that one lane then processes sequentially
-  // (processing a wall can mark later ones as paired, wall.c:766-767).
-  int32_t *olist = wl, *compB = wl+icap, *compE = wl+2*(int64_t)icap, *bnd = wl+3*(int64_t)icap;
+  // candidates, so the lanes test the candidates and compact the qualifying positions, in order, into a
+  // short list that one lane then processes sequentially (processing a wall can mark later ones as
+  // paired, wall.c:766-767).
+  int32_t *olist = wl, *compB = wl+2*(int64_t)icap, *compE = compB+(icap >> 1), *bnd = wl+3*(int64_t)icap;
+  const int ccap = icap >> 1;                           // components <= candidates+1 <= icap/2
   int n_o = 0;
-  if (plen > 1)
-    { const int64_t lo = po+1, hi = po+plen;
-      const int64_t w_lo = lo >> 6, w_hi = (hi-1) >> 6;
-      for (int64_t wb = w_lo; wb <= w_hi; wb += WAVE)
-        { const int64_t w = wb+lane;
-          uint64_t bits = (w <= w_hi) ? bitmap_word(bm,w,lo,hi) : 0ull, keep = 0ull;
-          for (uint64_t t = bits; t; t &= t-1)
-            { const int k = __ffsll((long long)t)-1;
-              const int i = (int)((w << 6)+k-po);
-              if ((wall[i] & CP_W_WALL_O) && !(wall_s[i] & CP_W_WALL_S)) keep |= 1ull << k;
-            }
-          int c = __popcll(keep), off = c;
-          for (int o = 1; o < WAVE; o <<= 1)               // inclusive scan over lanes
-            { int x = __shfl_up(off,o); if (lane >= o) off += x; }
-          const int tot = __shfl(off,WAVE-1);
-          off = n_o+off-c;
-          for (uint64_t t = keep; t; t &= t-1)
-            { const int k = __ffsll((long long)t)-1;
-              if (off < icap) olist[off] = (int)((w << 6)+k-po);
-              off++;
-            }
-          n_o += tot;
+  for (int base = 0; base < n_c; base += WAVE)
+    { const int q = base+lane;
+      int i = 0; bool keep = false;
+      if (q < n_c)
+        { i = clist[q];
+          keep = (wall[i] & CP_W_WALL_O) && !(wall_s[i] & CP_W_WALL_S);
         }
+      const uint64_t m = __ballot(keep);
+      if (keep) olist[n_o+__popcll(m & ((1ull << lane)-1))] = i;     // n_o < n_c <= icap
+      n_o += __popcll(m);
     }
-  if (n_o > icap) { overflow |= 2; n_o = icap; }
   wave_sync();
   PH_STAMP(2);
   int midx = NS;
@@ -494,9 +540,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   overflow |= __shfl(R.overflow,0);
   wave_sync();
   PH_STAMP(3);
-  for (int k = NS; k < midx; k++)                      // wall.c:868-872
-    wave_wall_and(wall,R.eintvl[k].b+1,R.eintvl[k].e,(uint8_t)~CP_W_WALL_O);
-  wave_sync();
+  wave_unwall_inside(wall,clist,n_c,R.eintvl,NS,midx,sbuf,SBUF/2);      // wall.c:868-872
   if (NS < midx)                                       // wall.c:873-876
     { NS = midx;
       wave_sort_eintvl(R.eintvl,NS,R.ointvl);
@@ -515,58 +559,64 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   //   error regions  = connected components of the union of the sorted E-intervals,
   //   boundaries     = component starts (>= 1) and ends, OTHERS walls (candidate positions) outside
   //                    every component, and plen; merged in increasing order.
+  // Short lists (the usual case) are staged in LDS, so that the one-lane loops below step through
+  // on-chip memory instead of paying a global-memory round trip per element:
+  //   sbuf[0..2*NS)  = E-interval ends while the components are built, then the walls (<= SBUF-2*SCOMP)
+  //   sbuf[SBUF-2*SCOMP..) = component starts / ends
+  constexpr int SCOMP = 64;
+  const bool small = (2*NS <= SBUF-2*SCOMP) && (n_c <= SBUF-2*SCOMP);
+  int *s_cb = sbuf+SBUF-2*SCOMP, *s_ce = sbuf+SBUF-SCOMP;
   int C = 0;
+  if (small)
+    { for (int k = lane; k < NS; k += WAVE)
+        { sbuf[2*k] = R.eintvl[k].b; sbuf[2*k+1] = R.eintvl[k].e; }
+      wave_sync();
+    }
   if (lane == 0)
     { int k = 0;
       while (k < NS)
-        { int cb = R.eintvl[k].b, ce = R.eintvl[k].e;
+        { int cb = small ? sbuf[2*k] : R.eintvl[k].b, ce = small ? sbuf[2*k+1] : R.eintvl[k].e;
           k++;
-          while (k < NS && R.eintvl[k].b <= ce)
-            { if (R.eintvl[k].e > ce) ce = R.eintvl[k].e;
+          while (k < NS && (small ? sbuf[2*k] : R.eintvl[k].b) <= ce)
+            { const int e2 = small ? sbuf[2*k+1] : R.eintvl[k].e;
+              if (e2 > ce) ce = e2;
               k++;
             }
-          if (C < icap) { compB[C] = cb; compE[C] = ce; }
+          if (C < ccap) { compB[C] = cb; compE[C] = ce; }
+          if (C < SCOMP) { s_cb[C] = cb; s_ce[C] = ce; }
           C++;
         }
     }
   C = __shfl(C,0);
-  if (C > icap) { overflow |= 2; C = icap; }
+  if (C > ccap) { overflow |= 2; C = ccap; }
+  const bool smallc = small && C <= SCOMP;              // components and walls both on chip
   wave_sync();
   int n_w = 0;                                         // OTHERS walls outside error regions, in order
-  if (plen > 1)
-    { const int64_t lo = po+1, hi = po+plen;
-      const int64_t w_lo = lo >> 6, w_hi = (hi-1) >> 6;
-      for (int64_t wb = w_lo; wb <= w_hi; wb += WAVE)
-        { const int64_t w = wb+lane;
-          uint64_t bits = (w <= w_hi) ? bitmap_word(bm,w,lo,hi) : 0ull, keep = 0ull;
-          for (uint64_t t = bits; t; t &= t-1)
-            { const int k = __ffsll((long long)t)-1;
-              const int i = (int)((w << 6)+k-po);
-              if (wall[i] & CP_W_WALL_O)
-                { int a = 0, z = C-1, in = 0;            // inside a component?  compB sorted, disjoint
-                  while (a <= z)
-                    { int m = (a+z) >> 1;
-                      if (i < compB[m]) z = m-1;
-                      else if (i >= compE[m]) a = m+1;
-                      else { in = 1; break; }
-                    }
-                  if (!in) keep |= 1ull << k;
+  for (int base = 0; base < n_c; base += WAVE)
+    { const int q = base+lane;
+      int i = 0; bool keep = false;
+      if (q < n_c)
+        { i = clist[q];
+          if (wall[i] & CP_W_WALL_O)
+            { int a = 0, z = C-1, in = 0;              // inside a component?  compB sorted, disjoint
+              while (a <= z)
+                { int m = (a+z) >> 1;
+                  const int mb = smallc ? s_cb[m] : compB[m], me = smallc ? s_ce[m] : compE[m];
+                  if (i < mb) z = m-1;
+                  else if (i >= me) a = m+1;
+                  else { in = 1; break; }
                 }
+              keep = !in;
             }
-          int c = __popcll(keep), off = c;
-          for (int o = 1; o < WAVE; o <<= 1)
-            { int x = __shfl_up(off,o); if (lane >= o) off += x; }
-          const int tot = __shfl(off,WAVE-1);
-          off = n_w+off-c;
-          for (uint64_t t = keep; t; t &= t-1)
-            { const int k = __ffsll((long long)t)-1;
-              if (off < icap) olist[off] = (int)((w << 6)+k-po);
-              off++;
-            }
-          n_w += tot;
         }
+      const uint64_t m = __ballot(keep);
+      if (keep)
+        { const int o = n_w+__popcll(m & ((1ull << lane)-1));
+          olist[o] = i;                                // n_w < n_c <= icap
+          if (smallc) sbuf[o] = i;
+        }
+      n_w += __popcll(m);
     }
-  if (n_w > icap) { overflow |= 2; n_w = icap; }
   wave_sync();
   int N = 0;
   if (lane == 0)                                       // merge: transitions, walls, plen
@@ -574,11 +624,11 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
       while (true)
         { int tpos = plen;
           while (ci < C)
-            { int v = phase ? compE[ci] : compB[ci];
+            { int v = smallc ? (phase ? s_ce[ci] : s_cb[ci]) : (phase ? compE[ci] : compB[ci]);
               if (v >= 1 && v < plen && v > last) { tpos = v; break; }
               if (phase) { ci++; phase = 0; } else phase = 1;
             }
-          int wpos = (wi < n_w) ? olist[wi] : plen;
+          int wpos = (wi < n_w) ? (smallc ? sbuf[wi] : olist[wi]) : plen;
           int nb = tpos < wpos ? tpos : wpos;
           if (nb >= plen) break;
           if (N < icap) bnd[N] = nb;
