@@ -299,6 +299,71 @@ __device__ void wave_unwall_inside(uint8_t *wall, const int32_t *clist, int n_c,
   wave_sync();
 }
 
+// cp_wall_mult (wall.c:763-860) with the whole wave: the reference walks up to 200 positions away from an
+// O-only wall i looking for walls j that would close an error interval, one flag load per step.  Here 64
+// positions are loaded at once; a ballot picks the ones the reference would act on (a wall of either
+// kind, or the read boundary) and the first OTHERS wall, where the walk ends; the picked positions are
+// then handled in order by all lanes together (same values everywhere, stores by lane 0).
+template <class RD>
+__device__ void wave_wall_mult(RD *R, int i, int NS, int *midx)
+{ const int lane = lane_id();
+  uint8_t *wall = R->wall;
+  const uint8_t *wall_s = R->wall_s;
+  const int plen = R->plen;
+  cp_eintvl *ev = R->eintvl;
+  for (int w = CP_DROP; w <= CP_GAIN; w++)
+    { const double pe_i = CP_PERR(R,i,CP_SELF,w);
+      if (pe_i < CP_PE_THRES_FINAL)
+        continue;
+      const bool right = (w == CP_DROP);
+      const int jend = right ? ((i+CP_MULT_WINDOW < plen+1) ? i+CP_MULT_WINDOW : plen+1)
+                             : ((i-CP_MULT_WINDOW > 0) ? i-CP_MULT_WINDOW : 0);
+      const int bound = right ? plen : 0;
+      bool done = false;
+      for (int c0 = 0; c0 < CP_MULT_WINDOW && !done; c0 += WAVE)
+        { const int j = right ? i+1+c0+lane : i-1-c0-lane;
+          const bool valid = right ? (j < jend) : (j >= jend);
+          const int fo = valid ? wall[j] : 0, fs = valid ? wall_s[j] : 0;
+          const bool isw = ((fo & CP_W_WALL_O) | (fs & CP_W_WALL_S)) != 0;
+          const uint64_t mi = __ballot(valid && (isw || j == bound));
+          const uint64_t mw = __ballot(valid && isw);
+          const uint64_t ms = __ballot(valid && (fo & CP_W_WALL_O));
+          if (__ballot(valid) == 0) break;
+          for (uint64_t t = mi; t; t &= t-1)
+            { const int b = __ffsll((long long)t)-1;
+              const int jj = right ? i+1+c0+b : i-1-c0-b;
+              if (jj == bound)                           // wall.c:772-789 / 816-833
+                { const double pe = pe_i * pe_i;
+                  if (pe < CP_PE_THRES_FINAL)
+                    continue;
+                  if (*midx >= R->ecap) { R->overflow = 1; return; }
+                  if (lane == 0)
+                    { ev[*midx].b = right ? i : 0; ev[*midx].e = right ? plen : i; ev[*midx].pe = pe;
+                      wall[i] |= CP_W_PAIRED_M;
+                    }
+                  (*midx)++;
+                }
+              if (!((mw >> b) & 1))
+                continue;
+              if (cp_bs_eintvl(ev,0,NS-1,right ? i : jj,right ? jj : i) == -1)
+                { const double pe_j = CP_PERR(R,jj,CP_SELF,right ? CP_GAIN : CP_DROP);
+                  const double pe = pe_i * pe_j;
+                  if (pe >= CP_PE_THRES_FINAL)
+                    { if (*midx >= R->ecap) { R->overflow = 1; return; }
+                      if (lane == 0)
+                        { ev[*midx].b = right ? i : jj; ev[*midx].e = right ? jj : i; ev[*midx].pe = pe;
+                          wall[i] |= CP_W_PAIRED_M;
+                          wall[jj] |= CP_W_PAIRED_M;
+                        }
+                      (*midx)++;
+                    }
+                }
+              if ((ms >> b) & 1) { done = true; break; }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 //  k_find_wall: wall.c:570-958, one wave per read.
 // ---------------------------------------------------------------------------------------------
@@ -529,15 +594,14 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   wave_sync();
   PH_STAMP(2);
   int midx = NS;
-  if (lane == 0)
-    for (int q = 0; q < n_o; q++)
-      { const int ii = olist[q];
-        if (wall[ii] & CP_W_PAIRED_M)                  // may have been set by an earlier i
-          continue;
-        cp_wall_mult(&R,ii,NS,&midx);
-      }
-  midx = __shfl(midx,0);
-  overflow |= __shfl(R.overflow,0);
+  for (int q = 0; q < n_o; q++)                        // all lanes together, see wave_wall_mult
+    { const int ii = olist[q];
+      wave_sync();                                     // lane 0's flag stores of the previous wall
+      if (wall[ii] & CP_W_PAIRED_M)                    // may have been set by an earlier i
+        continue;
+      wave_wall_mult(&R,ii,NS,&midx);
+    }
+  overflow |= R.overflow;
   wave_sync();
   PH_STAMP(3);
   wave_unwall_inside(wall,clist,n_c,R.eintvl,NS,midx,sbuf,SBUF/2);      // wall.c:868-872
