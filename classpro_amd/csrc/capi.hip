@@ -311,7 +311,7 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->parent.p,(int32_t *)ws->eff.p,
                      (uint8_t *)ws->rpos.p,(int8_t *)ws->asgn.p,totalI);
-  // size classes (kernels.hip: REL_SMALL_*): M <= 256 two reads per wave, up to 1024 one read per wave, larger: sequential kernel above
+  // size classes (kernels.hip: REL_SMALL_*): M <= 192 four reads per wave, up to 1024 one read per wave, larger: sequential kernel above
   hipLaunchKernelGGL(k_order_by_work,dim3(1),dim3(1024),0,st,(const int32_t *)ws->nrel.p,nreads,0,(int32_t *)ws->perm.p);
   // (the classes touch disjoint reads; the long-read class is a handful of latency-bound waves, so it
   //  runs beside the main class on the auxiliary stream)

@@ -904,12 +904,19 @@ struct rel_grp_rv
 template <int MAXM, int G>
 __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, const cp_intvl *rintvl, int M, int plen,
                              bool active, const int *COV)
-{ constexpr int L = WAVE/G;
+{ // Lanes of a read: LD per direction (forward first).  With LD = 16 (G <= 2) lane (s,t) owns transition
+  // s -> t; with LD = 8 (G = 4) lane (s,h) owns two, s -> H|D (a Skellam term, the expensive kind) and
+  // s -> E|R (table look-ups), so that every lane of the wave has a Bessel evaluation to do.
+  constexpr int L = WAVE/G, LD = (L >= 32) ? 16 : 8;
   const int lane = lane_id();
   const int g = lane/L, ql = lane%L;
-  const int d = (ql >> 4) & 1, F = (d == 0);
-  const int l16 = ql & 15, s = l16 >> 2, t = l16 & 3;
-  const bool in_grp = active && ql < 32 && M > 0;
+  const int d = (ql / LD) & 1, F = (d == 0);
+  const int ld = ql % LD;
+  const int s = (LD == 16) ? (ld >> 2) : (ld >> 1);
+  const int t1 = (LD == 16) ? (ld & 3) : -1;               // the single transition of a 16-lane direction
+  const int t_sk  = (LD == 16) ? ((t1 == CP_HAPLO || t1 == CP_DIPLO) ? t1 : -1) : ((ld & 1) ? CP_DIPLO : CP_HAPLO);
+  const int t_tab = (LD == 16) ? ((t1 == CP_ERROR || t1 == CP_REPEAT) ? t1 : -1) : ((ld & 1) ? CP_REPEAT : CP_ERROR);
+  const bool in_grp = active && ql < 2*LD && M > 0;
   rel_grp_view<MAXM,G> view; view.S = &S; view.g = g; view.d = d;
   rel_grp_rv<MAXM,G> rv; rv.S = &S; rv.g = g;
   int maxM = in_grp ? M : 0;
@@ -917,59 +924,59 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
     { int x = __shfl_xor(maxM,o); maxM = x > maxM ? x : maxM; }
 
   int i = F ? 0 : M-1;
-  if (in_grp && l16 < 4)                                   // init, class_rel.c:544-580
+  if (in_grp && ld < 4)                                    // init, class_rel.c:544-580
     { cp_riv I = rv(i);
       I.pe = rintvl[i].pe;
       cp_cell c;
-      cp_rel_init_cell(P,l16,I,i,plen,F,COV,&c);
-      S.cell[g][d][0][l16] = c;
-      S.tr[g][d][l16] = exp(c.dp);
-      if (l16 == 0)
+      cp_rel_init_cell(P,ld,I,i,plen,F,COV,&c);
+      S.cell[g][d][0][ld] = c;
+      S.tr[g][d][ld] = exp(c.dp);
+      if (ld == 0)
         { S.parent[g][d][i] = 0xe4;                        // each state its own parent: 3,2,1,0
           S.rpos[g][d][i] = 0;
           S.eff[g][d][i] = (int16_t)i;
         }
     }
   wave_sync();
-  if (in_grp && l16 < 4)                                   // :582-586
+  if (in_grp && ld < 4)                                    // :582-586
     { double psum = 0.;
       for (int x = 0; x < 4; x++)
         psum += S.tr[g][d][x];
-      S.cell[g][d][0][l16].dp = log(S.tr[g][d][l16]/psum);
+      S.cell[g][d][0][ld].dp = log(S.tr[g][d][ld]/psum);
     }
   wave_sync();
 
   int cur = 0;
   double pe_next = 0.;                                     // pe of the next interval (E lanes), one step ahead
-  if (in_grp && t == CP_ERROR && M > 1)
+  if (in_grp && t_tab == CP_ERROR && M > 1)
     pe_next = rintvl[F ? 1 : M-2].pe;
   for (int k = 1; k < maxM; k++)                           // _update, class_rel.c:279-513
     { const bool on = in_grp && k < M;
       const int i_pred = i;
       if (on) i = F ? k : M-1-k;
       cp_riv I; I.b = I.e = I.ccb = I.cce = 0; I.pe = 0.;
-      double v = 0.;
-      // ---- :300-319: 16 transitions per (read, direction), one lane each.  Every lane first works out
-      //      which table cells (log-factorials, log lambda) or which Skellam arguments its transition
-      //      needs; the table loads of all lanes are then issued together and the Skellam/Bessel
-      //      evaluation is one call for all H and D lanes.
+      double v_sk = 0., v_tab = 0.;
+      // ---- :300-319: the 16 transitions of a (read, direction).  Every lane first works out which table
+      //      cells (log-factorials, log lambda) and which Skellam arguments its transition(s) need; the
+      //      table loads of all lanes are then issued together and the Skellam/Bessel evaluation is one
+      //      call for all lanes that have one.
       bool live = false, is_sk = false, r_tab = false;
       int tb = 0, te = 0, tcb = 0, tce = 0, tcov = 0;
       int f0 = 0, f1 = 0, f2 = 0, li = 1, rk = 0, rn = 0;
-      double lp = -INFINITY;
+      double lp_sk = -INFINITY, lp_tab = -INFINITY;
       const double pe_now = pe_next;                       // fetched one step ahead
       if (on)
         { I = rv(i);
-          if (t == CP_ERROR && k+1 < M)
+          if (t_tab == CP_ERROR && k+1 < M)
             pe_next = rintvl[F ? k+1 : M-2-k].pe;
           const cp_cell &pr = S.cell[g][d][cur][s];
           live = pr.dp != -INFINITY;
           if (live)
-            { if (t == CP_ERROR)                           // logp_e, class_rel.c:158-170
+            { if (t_tab == CP_ERROR)                       // logp_e, class_rel.c:158-170
                 { I.pe = pe_now;
                   f0 = cp_check_cnt(I.ccb); f1 = cp_check_cnt(I.cce); li = COV[CP_ERROR];
                 }
-              else if (t == CP_REPEAT)                     // logp_r, class_rel.c:172-211
+              else if (t_tab == CP_REPEAT)                 // logp_r, class_rel.c:172-211
                 { const int beg_cnt = cp_beg_cnt(I,F), prc = pr.cnt[CP_REPEAT];
                   if (beg_cnt < prc)
                     { r_tab = true;
@@ -977,14 +984,14 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
                       f0 = rn; f1 = rk; f2 = rn-rk;
                     }
                 }
-              else
+              if (t_sk >= 0)
                 { is_sk = true;                            // logp_h / logp_d, class_rel.c:213-270
                   const int beg_pos = cp_beg_pos(I,F), beg_cnt = cp_beg_cnt(I,F);
-                  if (t == CP_HAPLO && pr.dhr == -INFINITY)
+                  if (t_sk == CP_HAPLO && pr.dhr == -INFINITY)
                     { tb = cp_pred(pr.pos[CP_HAPLO],F); te = beg_pos; tcb = pr.cnt[CP_HAPLO]; tce = beg_cnt; tcov = pr.cnt[CP_HAPLO]; }
                   else
                     { tb = cp_pred(pr.pos[CP_DIPLO],F); te = beg_pos; tcb = pr.cnt[CP_DIPLO];
-                      tce = (t == CP_HAPLO) ? (int)(pr.dhr*beg_cnt) : beg_cnt;
+                      tce = (t_sk == CP_HAPLO) ? (int)(pr.dhr*beg_cnt) : beg_cnt;
                       tcov = pr.cnt[CP_DIPLO];
                     }
                 }
@@ -993,45 +1000,50 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
       { const double A = P->logfact[f0], B = P->logfact[f1], C = P->logfact[f2];
         const double D = (li >= 0 && li <= CP_MAX_KMER_CNT) ? P->logint[li] : log((double)li);
         if (on && live)
-          { if (t == CP_ERROR)
+          { if (t_tab == CP_ERROR)
               { double po = (f0 * D - li - A)+(f1 * D - li - B)+CP_E_PO_BASE;       // prob.c:33-39 twice
-                lp = (po > I.pe) ? po : I.pe;
+                lp_tab = (po > I.pe) ? po : I.pe;
               }
-            else if (t == CP_REPEAT)
+            else if (t_tab == CP_REPEAT)
               { const cp_cell &pr = S.cell[g][d][cur][s];
                 double l = r_tab ? (A - B - C + rk * P->r_lp + (rn-rk) * P->r_l1mp) : -INFINITY;   // prob.c:67-73
                 if (!(l > CP_R_LOGP))
                   { int max_cc = I.ccb > I.cce ? I.ccb : I.cce;
                     if (max_cc >= COV[CP_REPEAT] || max_cc >= pr.cnt[CP_REPEAT]) l = CP_R_LOGP;
                   }
-                lp = l;
+                lp_tab = l;
               }
           }
       }
       if (is_sk)
-        lp = cp_logp_trans(P,tb,te,tcb,tce,tcov);
+        lp_sk = cp_logp_trans(P,tb,te,tcb,tce,tcov);
       if (on)
-        { if (live) v = exp(lp);
-          S.tr[g][d][l16] = v;
+        { if (live) { v_sk = exp(lp_sk); v_tab = exp(lp_tab); }
+          if (t_sk >= 0)  S.tr[g][d][s*4+t_sk]  = v_sk;
+          if (t_tab >= 0) S.tr[g][d][s*4+t_tab] = v_tab;
         }
       wave_sync();
-      double nv = 0.;
+      double nv_sk = 0., nv_tab = 0.;
       if (on)                                              // :320-336
         { double psum = 0.;
           for (int x = 0; x < 16; x++)
             psum += S.tr[g][d][x];
           if (psum == 0.)
-            { if (t == CP_ERROR) v = 1.;
+            { if (t_tab == CP_ERROR) v_tab = 1.;
               psum = 4.;
             }
-          nv = log(v/psum);
+          if (t_sk >= 0)  nv_sk  = log(v_sk/psum);
+          if (t_tab >= 0) nv_tab = log(v_tab/psum);
         }
       wave_sync();
       if (on)
-        S.tr[g][d][l16] = nv;
+        { if (t_sk >= 0)  S.tr[g][d][s*4+t_sk]  = nv_sk;
+          if (t_tab >= 0) S.tr[g][d][s*4+t_tab] = nv_tab;
+        }
       wave_sync();
-      if (on && l16 < 4)                                   // :348-499: one lane per state
-        { const double *tr = S.tr[g][d];
+      if (on && ld < 4)                                    // :348-499: one lane per state
+        { const int l16 = ld;
+          const double *tr = S.tr[g][d];
           double dp[4];
           for (int x = 0; x < 4; x++) dp[x] = S.cell[g][d][cur][x].dp;
           bool only_r = true;
@@ -1086,7 +1098,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
     }
   // the buffer holding the last interval's cells: M-1 swaps happened for this read
   const int fin = (M > 0) ? ((M-1) & 1) : 0;
-  if (in_grp && l16 == 0)                                  // traceback, class_rel.c:606-613
+  if (in_grp && ld == 0)                                   // traceback, class_rel.c:606-613
     { double max_logp = -INFINITY;
       int st = CP_ERROR;
       for (int x = 0; x < 4; x++)
@@ -1109,14 +1121,16 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
 }
 
 // size classes of the grouped classify kernels (reads per wave / largest interval count)
-#ifndef REL_SMALL_G
-#define REL_SMALL_G 2
-#endif
 // Chosen on the bench batch (per read: M <= 132, N <= 230; a read that falls into the next class runs alone
-// there, and a lone wave was the tail of its stage): with (MAXM; G,MAXN) = (128; 8,192) 6.68 ms per step,
-// (192; 8,192) 6.48, (128; 4,256) 6.51, (192; 4,256) 6.31, (256; 4,256) 6.29.
+// there, and a lone wave was the tail of its stage).  With two reads per wave in the rel kernel and
+// (MAXM; G,MAXN) = (128; 8,192) 6.68 ms per step, (192; 8,192) 6.48, (128; 4,256) 6.51, (192; 4,256) 6.31,
+// (256; 4,256) 6.29.  Later, with four reads per wave in the rel kernel (8 lanes per direction, every lane
+// with a Bessel term): 5.00 ms at MAXM 256, 4.77 at 192, 5.39 at 128.
+#ifndef REL_SMALL_G
+#define REL_SMALL_G 4
+#endif
 #ifndef REL_SMALL_MAXM
-#define REL_SMALL_MAXM 256
+#define REL_SMALL_MAXM 192
 #endif
 #ifndef UNREL_SMALL_G
 #define UNREL_SMALL_G 4
@@ -1153,9 +1167,10 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
     }
   wave_sync();
 
-  const int d = (ql >> 4) & 1, F = (d == 0);
-  const int leadlane = g*L+d*16;
-  const bool lead = (M > 0) && (ql < 32) && ((ql & 15) == 0);
+  constexpr int LD = (L >= 32) ? 16 : 8;                   // lanes per direction, see rel_grp_pass
+  const int d = (ql / LD) & 1, F = (d == 0);
+  const int leadlane = g*L+d*LD;
+  const bool lead = (M > 0) && (ql < 2*LD) && ((ql % LD) == 0);
   int COV[4] = { P->cov[0], P->cov[1], P->cov[2], P->cov[3] };
   rel_grp_rv<MAXM,G> rv; rv.S = &S; rv.g = g;
   rel_grp_pass<MAXM,G>(P,S,rintvl,M,plen,M > 0,COV);
@@ -1166,13 +1181,13 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
   rerun = __shfl(rerun,leadlane);
   COV[CP_HAPLO] = __shfl(COV[CP_HAPLO],leadlane);
   COV[CP_DIPLO] = __shfl(COV[CP_DIPLO],leadlane);
-  if (M == 0 || ql >= 32) rerun = 0;
+  if (M == 0 || ql >= 2*LD) rerun = 0;
   if (__ballot(rerun != 0))
     rel_grp_pass<MAXM,G>(P,S,rintvl,M,plen,rerun != 0,COV);
   double hdrr = 1.;
   if (lead)
     hdrr = cp_rel_post2(P,rv,M,F,S.asgn[g][d],rerun != 0);
-  const double hf = __shfl(hdrr,g*L), hb = __shfl(hdrr,g*L+16);
+  const double hf = __shfl(hdrr,g*L), hb = __shfl(hdrr,g*L+LD);
   wave_sync();
 
   int take_bw = 0;                                         // class_rel.c:904-938
