@@ -222,7 +222,8 @@ def main():
                        "reads_per_gpu": b.nreads, "bases_per_gpu": b.total_bases, "hcov": hcov, "dcov": dcov,
                        "parallelism": "read-sharded x%d, no collective" % world},
             "roofline": roof, "cpu_baseline": cpu,
-            "extras": {"pcie_inclusive_mbases_per_s": round(b.total_bases / t_e2e / 1e6, 2),
+            "extras": {"whole_step_algorithmic_gb_per_s": round((2.0 * b.total_kmers + 2.0 * b.total_bases) / (dt / a.steps) / 1e9, 1),
+                       "pcie_inclusive_mbases_per_s": round(b.total_bases / t_e2e / 1e6, 2),
                        "pcie_inclusive_pinned_codes_mbases_per_s": round(b.total_bases / min(t_codes) / 1e6, 2),
                        "accuracy_vs_synthetic_truth": None if acc is None else round(acc, 5),
                        "code_bytes_per_base": round(len(codes) / b.total_bases, 4),

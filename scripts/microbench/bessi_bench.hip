@@ -35,6 +35,16 @@
     double s_ = fabs(t) > 1.0e10 ? 1.0e-10 : 1.0;              \
     t *= s_; b *= s_; if (WITH_ANS) ans *= s_; }
 
+// exact replay of NS steps with the per-step test, out of line so that the fast loop stays small
+template <int NS, bool WA> __device__ __noinline__ void replay_steps(double &a, double &b, double &dj, double tox, double &ans)
+{ double t;
+  for (int q = 0; q < NS; q++)
+    { t = a+dj*tox*b; dj -= 1.0;
+      if (fabs(t) > 1.0e10) { if (WA) ans *= 1.0e-10; t *= 1.0e-10; b *= 1.0e-10; }
+      a = b; b = t;
+    }
+}
+
 template <int V> __device__ __forceinline__ double rec(int n, double x, double b0)
 { const double tox = 2.0/fabs(x);
   const int jmax = 2*(n+(int)sqrt(40.0*n));
@@ -98,6 +108,28 @@ template <int V> __device__ __forceinline__ double rec(int n, double x, double b
             }
           for (; c >= 2; c -= 2)
             { if (wa) { STEP(t1,a,b,true) STEP(t2,b,t1,true) } else { STEP(t1,a,b,false) STEP(t2,b,t1,false) }
+              a = t1; b = t2;
+            }
+        }
+      else if (V == 10 || V == 11)                             // one test per 8 / 4 steps, replay out of line
+        { constexpr int NS = (V == 10) ? 8 : 4;
+          for (; c >= NS; c -= NS)
+            { double p = a, q = b, m = 0.;
+#pragma unroll
+              for (int u = 0; u < NS; u++)
+                { const double t = p+(dj-(double)u)*tox*q;
+                  m = fmax(m,fabs(t));
+                  p = q; q = t;
+                }
+              if (__any(m > 1.0e10))
+                { if (m > 1.0e10)
+                    { if (wa) replay_steps<NS,true>(a,b,dj,tox,ans); else replay_steps<NS,false>(a,b,dj,tox,ans); }
+                  else { a = p; b = q; dj -= (double)NS; }
+                }
+              else { a = p; b = q; dj -= (double)NS; }
+            }
+          for (; c >= 2; c -= 2)
+            { if (wa) { STEPF(t1,a,b,true) STEPF(t2,b,t1,true) } else { STEPF(t1,a,b,false) STEPF(t2,b,t1,false) }
               a = t1; b = t2;
             }
         }
@@ -200,6 +232,8 @@ int main(int argc, char **argv)
       run<8>("V8 high-word test, unroll 8",dn,dx,reps,blocks,steps,dout,dcyc,ref);
       run<5>("V5 branch-free, unroll 2",dn,dx,reps,blocks,steps,dout,dcyc,ref);
       run<6>("V6 branch-free, unroll 4",dn,dx,reps,blocks,steps,dout,dcyc,ref);
+      run<11>("V11 test per 4, replay out of line",dn,dx,reps,blocks,steps,dout,dcyc,ref);
+      run<10>("V10 test per 8, replay out of line",dn,dx,reps,blocks,steps,dout,dcyc,ref);
       run<4>("V4 no test (bound, inexact)",dn,dx,reps,blocks,steps,dout,dcyc,ref);
     }
   return 0;
