@@ -1246,6 +1246,8 @@ struct unrel_grp_lds
     uint8_t  isrel[G][MAXN];
     int16_t  ord[G][MAXN];               // sorted index, bit 14 = fixed
     uint64_t rel[G][2][MAXN/64];         // [0] reliable & H, [1] reliable & D
+    int16_t  mail_idx[G][8];             // interval and new class of each speculative slot of a round
+    int8_t   mail_s[G][8];
   };
 
 __device__ __forceinline__ int bits_left(const uint64_t *bits, int idx)       // nearest set bit < idx
@@ -1339,15 +1341,26 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
     { int x = __shfl_xor(maxNF,o); maxNF = x > maxNF ? x : maxNF; }
   wave_sync();
 
-  // role of this lane inside its read's group: class (H,D) x side (L,R) x kind (0: max(er,sf), 1: sf_er)
-  const int s2 = (ql >> 2) & 1, side = (ql >> 1) & 1, kind = ql & 1;
+  // role of this lane inside its slot: class (H,D) x side (L,R) x kind (0: max(er,sf), 1: sf_er).
+  // The reference updates the non-fixed intervals one after the other (class_unrel.c:260-274), and an
+  // update costs one Bessel recurrence of latency.  An update reads the neighbouring intervals' classes
+  // and the reliable-H / reliable-D sets, which most updates leave untouched, so the K = L/8 groups of 8
+  // lanes of a read take K consecutive updates at once (slots), and one lane then commits them in order:
+  // a slot is committed only if no earlier slot of the round changed the class of one of its neighbours
+  // or either set; otherwise the round ends there and the next one starts from that update.
+  constexpr int K = L/8;
+  const int sub = ql >> 3, role = ql & 7, sbase = gbase+sub*8;
+  const int s2 = (role >> 2) & 1, side = (role >> 1) & 1, kind = role & 1;
   const int s = s2 ? CP_DIPLO : CP_HAPLO;
-  for (int pass = 0; pass < 2; pass++)                     // class_unrel.c:260-274
-    for (int it = 0; it < maxNF; it++)
-      { bool on = it < nnf;
+  int pass = 0, it = 0;                                    // class_unrel.c:260-274, position of this read
+  bool done = (N == 0) || (nnf == 0);
+  while (__ballot(!done) != 0)
+      { const int myit = it+sub;
+        const bool act = !done && myit < nnf;              // this slot has an update to do
+        bool on = act;
         int idx = 0;
-        if (on)
-          idx = S.ord[g][pass == 0 ? nnf-1-it : it];
+        if (act)
+          idx = S.ord[g][pass == 0 ? nnf-1-myit : myit];
         int snew = -1;
         bool do_sf = false, do_bin = false;
         int tb = 0, te = 0, tcb = 0, tce = 0, tcov = 0, est = 0, c = 0;
@@ -1364,8 +1377,7 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
               { const int lH = bits_left(S.rel[g][0],idx), rH = bits_right(S.rel[g][0],idx,nwords);
                 lD = bits_left(S.rel[g][1],idx); rD = bits_right(S.rel[g][1],idx,nwords);
                 const int l_rel = s2 ? lD : lH, r_rel = s2 ? rD : rH;
-                if (ql < 8)                                // class_unrel.c:123-163, arguments only
-                  { if (kind == 0)
+                { if (kind == 0)                           // class_unrel.c:123-163, arguments only
                       { if (side == 0)
                           { if (idx-1 >= 0 && S.asgn[g][idx-1] == (int8_t)s) er = intvl[idx].peo_b;
                             if (l_rel != -1)
@@ -1405,23 +1417,23 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
         double val = -INFINITY;
         const int key = do_sf ? ((side == 0) ? tb : te) : (do_bin ? est : -1);   // tb/te identify the neighbour
         if (pass == 1 && (do_sf || do_bin))
-          { if (mkey[idx*8+ql] == key)
-              { val = mval[idx*8+ql];
+          { if (mkey[idx*8+role] == key)
+              { val = mval[idx*8+role];
                 do_sf = do_bin = false;
               }
           }
         const bool fresh = do_sf || do_bin;
-        // one convergent call per kind for every read of the wave
+        // one convergent call per kind for every slot of every read of the wave
         if (do_sf)
           val = cp_logp_trans(P,tb,te,tcb,tce,tcov);
         if (do_bin)
           val = log(cp_p_errorin(P->logfact,CP_OTHERS,0.1,P->u_lpe,P->u_l1mpe,est,c));
-        if (pass == 0 && on && ql < 8)
-          { mkey[idx*8+ql] = fresh ? key : -1;
-            mval[idx*8+ql] = val;
+        if (pass == 0 && on)
+          { mkey[idx*8+role] = fresh ? key : -1;
+            mval[idx*8+role] = val;
           }
         if (on)
-          { if (ql < 8 && kind == 0)
+          { if (kind == 0)
               val = (er > val) ? er : val;
             double v1 = __shfl_down(val,1);
             double sidev = (val > v1) ? val : v1;              // MAX(MAX(er,sf),sf_er) on lanes with kind 0
@@ -1434,7 +1446,7 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
             else if (logp_l == -INFINITY) logp_l = logp_r;
             else if (logp_r == -INFINITY) logp_r = logp_l;
             const double logp_s = logp_l+logp_r;
-            const double vH = __shfl(logp_s,gbase), vD = __shfl(logp_s,gbase+4);
+            const double vH = __shfl(logp_s,sbase), vD = __shfl(logp_s,sbase+4);
             // E and R are table look-ups (class_unrel.c:53-113)
             const double pe = intvl[idx].pe;
             const double po = cp_logp_poisson(P,Icb,P->cov[CP_ERROR])+cp_logp_poisson(P,Ice,P->cov[CP_ERROR])+CP_E_PO_BASE;
@@ -1458,17 +1470,41 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
             if (logpmax < vH) { logpmax = vH; snew = CP_HAPLO; }
             if (logpmax < vD) { logpmax = vD; snew = CP_DIPLO; }
           }
-        wave_sync();                                           // every read's lanes have read the old state
-        if (ql == 0 && snew >= 0)
-          { const int old = S.asgn[g][idx];
-            if (S.isrel[g][idx] && old != snew)
-              { const uint64_t bit = 1ull << (idx & 63);
-                if (old == CP_HAPLO) S.rel[g][0][idx >> 6] &= ~bit;
-                if (old == CP_DIPLO) S.rel[g][1][idx >> 6] &= ~bit;
-                if (snew == CP_HAPLO) S.rel[g][0][idx >> 6] |= bit;
-                if (snew == CP_DIPLO) S.rel[g][1][idx >> 6] |= bit;
+        if (role == 0)
+          { S.mail_idx[g][sub] = (int16_t)idx;
+            S.mail_s[g][sub] = (int8_t)(act ? snew : -1);
+          }
+        wave_sync();                                           // every slot has read the old state
+        int napplied = 0;
+        if (ql == 0 && !done)                                  // commit the round's slots in order
+          { bool sets_changed = false;
+            int changed[K], nch = 0;
+            for (int j = 0; j < K; j++)
+              { const int sj = S.mail_s[g][j], ij = S.mail_idx[g][j];
+                if (sj < 0) break;                             // no update in this slot (end of the sweep)
+                bool clash = sets_changed;
+                for (int m = 0; m < nch; m++)
+                  clash = clash || changed[m] == ij-1 || changed[m] == ij+1;
+                if (clash) break;                              // computed from a state an earlier slot changed
+                const int old = S.asgn[g][ij];
+                if (old != sj)
+                  { if (S.isrel[g][ij])
+                      { const uint64_t bit = 1ull << (ij & 63);
+                        if (old == CP_HAPLO) { S.rel[g][0][ij >> 6] &= ~bit; sets_changed = true; }
+                        if (old == CP_DIPLO) { S.rel[g][1][ij >> 6] &= ~bit; sets_changed = true; }
+                        if (sj == CP_HAPLO)  { S.rel[g][0][ij >> 6] |= bit;  sets_changed = true; }
+                        if (sj == CP_DIPLO)  { S.rel[g][1][ij >> 6] |= bit;  sets_changed = true; }
+                      }
+                    S.asgn[g][ij] = (int8_t)sj;
+                    changed[nch++] = ij;
+                  }
+                napplied++;
               }
-            S.asgn[g][idx] = (int8_t)snew;
+          }
+        napplied = __shfl(napplied,gbase);
+        if (!done)
+          { it += napplied;
+            if (it >= nnf) { it = 0; pass++; if (pass == 2) done = true; }
           }
         wave_sync();
       }
