@@ -334,7 +334,7 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   hipLaunchKernelGGL(k_classify_unrel,dim3(nreads),dim3(WAVE),0,st,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
                      (int32_t *)ws->ord.p);
-  // size classes (kernels.hip: UNREL_SMALL_*): N <= 256 four reads per wave, up to 1024 two reads per wave, larger: sequential kernel above
+  // size classes (kernels.hip: UNREL_SMALL_*): N <= 256 and up to 1024, two reads per wave each (four speculative update slots per read), larger: sequential kernel above
   ENSURE(ws->memo_val,(size_t)totalI*8*8);
   ENSURE(ws->memo_key,(size_t)totalI*8*4);
   hipLaunchKernelGGL(k_order_by_work,dim3(1),dim3(1024),0,st,(const int32_t *)ws->nintvl.p,nreads,0,(int32_t *)ws->perm.p);

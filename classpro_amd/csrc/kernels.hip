@@ -1132,8 +1132,9 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
 #ifndef REL_SMALL_MAXM
 #define REL_SMALL_MAXM 192
 #endif
+// (unrel, later, with K = 64/G/8 speculative update slots per read: G = 4 4.28 ms per step, G = 2 4.07, G = 1 4.04)
 #ifndef UNREL_SMALL_G
-#define UNREL_SMALL_G 4
+#define UNREL_SMALL_G 2
 #endif
 #ifndef UNREL_SMALL_MAXN
 #define UNREL_SMALL_MAXN 256
