@@ -151,31 +151,47 @@ k_count_caps(const uint64_t *__restrict__ bm, const int64_t *__restrict__ prof_o
 }
 
 // exclusive prefix sums of three int64 arrays, in place, totals appended at [n]; single block.
+// exclusive prefix sum of one value per thread over a 1024-thread block (16 waves): wave scans by shuffle,
+// the 16 wave totals scanned by the first wave; *total gets the block sum.  `tmp` holds 16 values.
+template <class T>
+__device__ __forceinline__ T block_scan_excl_1024(T x, T *tmp, T *total)
+{ const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  T inc = x;
+  for (int o = 1; o < WAVE; o <<= 1)
+    { T y = __shfl_up(inc,o); if (lane >= o) inc += y; }
+  if (lane == WAVE-1) tmp[wv] = inc;
+  __syncthreads();
+  if (wv == 0)
+    { T w = (lane < 16) ? tmp[lane] : (T)0, winc = w;
+      for (int o = 1; o < 16; o <<= 1)
+        { T y = __shfl_up(winc,o); if (lane >= o) winc += y; }
+      if (lane < 16) tmp[lane] = winc-w;                  // exclusive offsets of the waves
+      if (lane == 15) *total = winc;
+    }
+  __syncthreads();
+  return tmp[wv]+inc-x;
+}
+
 __global__ void __launch_bounds__(1024)
 k_prefix_caps(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__restrict__ c, int n)
-{ __shared__ int64_t sa[1024], sb[1024], sc[1024];
+{ __shared__ int64_t tmp[16], tot;
   const int t = threadIdx.x, T = blockDim.x;
   const int per = (n+T-1)/T;
   const int lo = t*per, hi = (lo+per < n) ? lo+per : n;
-  int64_t xa = 0, xb = 0, xc = 0;
-  for (int i = lo; i < hi; i++) { xa += a[i]; xb += b[i]; xc += c[i]; }
-  sa[t] = xa; sb[t] = xb; sc[t] = xc;
-  __syncthreads();
-  if (t == 0)
-    { int64_t ra = 0, rb = 0, rc = 0;
-      for (int i = 0; i < T; i++)
-        { int64_t ya = sa[i], yb = sb[i], yc = sc[i];
-          sa[i] = ra; sb[i] = rb; sc[i] = rc;
-          ra += ya; rb += yb; rc += yc;
+  int64_t *arr[3] = { a, b, c };
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+    { int64_t *v = arr[q];
+      int64_t x = 0;
+      for (int i = lo; i < hi; i++) x += v[i];
+      int64_t off = block_scan_excl_1024<int64_t>(x,tmp,&tot);
+      for (int i = lo; i < hi; i++)
+        { int64_t y = v[i];
+          v[i] = off;
+          off += y;
         }
-      a[n] = ra; b[n] = rb; c[n] = rc;
-    }
-  __syncthreads();
-  xa = sa[t]; xb = sb[t]; xc = sc[t];
-  for (int i = lo; i < hi; i++)
-    { int64_t ya = a[i], yb = b[i], yc = c[i];
-      a[i] = xa; b[i] = xb; c[i] = xc;
-      xa += ya; xb += yb; xc += yc;
+      if (t == 0) v[n] = tot;
+      __syncthreads();
     }
 }
 
@@ -199,13 +215,11 @@ k_order_by_work(const int32_t *__restrict__ key, int n, int shift, int32_t *__re
       atomicAdd(&hist[b < ORDER_BINS ? b : ORDER_BINS-1],1);
     }
   __syncthreads();
-  if (t == 0)
-    { int acc = 0;
-      for (int b = ORDER_BINS-1; b >= 0; b--)              // descending keys
-        { start[b] = acc;
-          acc += hist[b];
-        }
-    }
+  { __shared__ int tmp[16], tot;                           // descending keys: bin b starts after all larger bins
+    const int rb = ORDER_BINS-1-t;                         // thread t scans bin 1023-t
+    const int off = block_scan_excl_1024<int>(hist[rb],tmp,&tot);
+    start[rb] = off;
+  }
   __syncthreads();
   for (int i = t; i < n; i += 1024)
     { int b = key[i] >> shift;
