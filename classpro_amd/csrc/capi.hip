@@ -199,10 +199,8 @@ static int launch_scan(const cp_dev_params *hostP, const uint16_t *d_prof, int64
                        int64_t nwords, hipStream_t st)
 { if (((uintptr_t)d_prof) & 15)
     return set_err(CP_EINVAL,"profile buffer must be 16-byte aligned");
-  int64_t first = total >> 3;                        // bytes from here to the end must start out zero
-  HIPCHK(hipMemsetAsync((uint8_t *)d_bitmap+first,0,(size_t)(nwords*8-first),st));
   hipLaunchKernelGGL(k_scan_candidates,dim3(scan_grid(total)),dim3(256),0,st,
-                     d_prof,total,hostP->cov[CP_REPEAT],(uint8_t *)d_bitmap);
+                     d_prof,total,hostP->cov[CP_REPEAT],(uint8_t *)d_bitmap,nwords*8);
   HIPCHK(hipGetLastError());
   return CP_OK;
 }

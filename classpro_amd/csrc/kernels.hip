@@ -42,10 +42,14 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE-1); }
 //  (wall.c:592-608).  Each lane loads 8 consecutive counts with one 16-byte load, gets the count
 //  before its first one from the neighbouring lane, and stores one byte of flags.  Bits at the
 //  first position of a read compare across a read boundary; consumers skip position 0.
-//  Algorithmic traffic: 2 B read + 1/8 B written per position.
+//  Algorithmic traffic: 2 B read + 1/8 B written per position.  The bitmap buffer has `nbytes` bytes (whole
+//  64-bit words plus one spare word); the bytes after the last group are cleared here.
 // ---------------------------------------------------------------------------------------------
+typedef unsigned cp_u4v __attribute__((ext_vector_type(4)));
 #ifdef SCAN_NT
-#define SCAN_LOAD(p) __builtin_nontemporal_load(p)
+__device__ __forceinline__ uint4 scan_load(const uint4 *p)
+{ cp_u4v x = __builtin_nontemporal_load(reinterpret_cast<const cp_u4v *>(p)); return make_uint4(x.x,x.y,x.z,x.w); }
+#define SCAN_LOAD(p) scan_load(p)
 #else
 #define SCAN_LOAD(p) (*(p))
 #endif
@@ -57,12 +61,51 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE-1); }
 #endif
 
 __global__ void __launch_bounds__(256)
-k_scan_candidates(const uint16_t *__restrict__ prof, int64_t total, int rep, uint8_t *__restrict__ bitmap)
+k_scan_candidates(const uint16_t *__restrict__ prof, int64_t total, int rep, uint8_t *__restrict__ bitmap, int64_t nbytes)
 { const int64_t ngroups = total >> 3;                   // full groups of 8 positions
   const int64_t nthreads = (int64_t)gridDim.x*blockDim.x;
   const int lane = lane_id();
   const uint4 *vp = reinterpret_cast<const uint4 *>(prof);
 
+#ifndef SCAN_INTERLEAVED
+  // every wave owns SCAN_UNROLL consecutive 1-KB rows, so that lane 0 takes the count before its group from
+  // lane 63 of the previous row instead of a second (2-byte) load per row
+  const int64_t wavesz = (int64_t)WAVE*SCAN_UNROLL;
+  const int64_t nwaves = nthreads/WAVE;
+  const int64_t wid = ((int64_t)blockIdx.x*blockDim.x+threadIdx.x)/WAVE;
+  for (int64_t base = wid*wavesz; base < ngroups; base += nwaves*wavesz)
+    { uint4 v[SCAN_UNROLL];
+      int64_t g[SCAN_UNROLL];
+#pragma unroll
+      for (int u = 0; u < SCAN_UNROLL; u++)
+        { g[u] = base+(int64_t)u*WAVE+lane;
+          v[u] = (g[u] < ngroups) ? SCAN_LOAD(&vp[g[u]]) : make_uint4(0,0,0,0);
+        }
+      unsigned carry = 0;
+      if (lane == 0)
+        carry = (base > 0) ? prof[base*8-1] : (v[0].x & 0xffff);
+#pragma unroll
+      for (int u = 0; u < SCAN_UNROLL; u++)
+        { const bool live = g[u] < ngroups;
+          unsigned last = v[u].w >> 16;
+          unsigned prev = __shfl_up(last,1);
+          if (lane == 0) prev = carry;
+          carry = __shfl(last,WAVE-1);                  // lane 0's predecessor in the next row
+          unsigned c[8] = { v[u].x & 0xffff, v[u].x >> 16, v[u].y & 0xffff, v[u].y >> 16,
+                            v[u].z & 0xffff, v[u].z >> 16, v[u].w & 0xffff, v[u].w >> 16 };
+          unsigned bits = 0;
+#pragma unroll
+          for (int k = 0; k < 8; k++)
+            { unsigned a = prev, b = c[k];
+              unsigned mn = a < b ? a : b, df = a < b ? b-a : a-b;
+              bits |= ((mn < (unsigned)rep) && (df >= CP_MIN_CNT_CHANGE)) ? (1u << k) : 0u;
+              prev = b;
+            }
+          if (live)
+            bitmap[g[u]] = (uint8_t)bits;
+        }
+    }
+#else
   for (int64_t base = (int64_t)blockIdx.x*blockDim.x*SCAN_UNROLL; base < ngroups; base += nthreads*SCAN_UNROLL)
     { uint4 v[SCAN_UNROLL];
       int64_t g[SCAN_UNROLL];
@@ -96,6 +139,8 @@ k_scan_candidates(const uint16_t *__restrict__ prof, int64_t total, int rep, uin
         }
     }
 
+#endif
+
   if (blockIdx.x == 0 && threadIdx.x == 0)              // ragged tail (< 8 positions) + zero pad to a word
     { int64_t p0 = ngroups << 3;
       if (p0 < total)
@@ -107,7 +152,10 @@ k_scan_candidates(const uint16_t *__restrict__ prof, int64_t total, int rep, uin
                 if (mn < (unsigned)rep && df >= CP_MIN_CNT_CHANGE) bits |= 1u << (p-p0);
               }
           bitmap[ngroups] = (uint8_t)bits;
+          p0 += 8;
         }
+      for (int64_t q = p0 >> 3; q < nbytes; q++)          // zero pad to the end of the bitmap's last words
+        bitmap[q] = 0;
     }
 }
 
