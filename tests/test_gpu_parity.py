@@ -404,3 +404,27 @@ def test_cli_on_dazzler_database(torch_dev, tmp_path, dam):
     assert (nr, sz, len(roffs), len(rraw)) == (n, 0, 1, 0)
     r = subprocess.run([cli, "-s", os.path.join(d, "reads")], capture_output=True, text=True)
     assert r.returncode == 1 and "-s" in r.stderr
+
+
+@pytest.mark.parametrize("k,read_len,cov", [(25, 6000, 30), (63, 12000, 50), (101, 12000, 50)], ids=["k25", "k63", "k101_no_window"])
+def test_other_kmer_lengths(torch_dev, k, read_len, cov):
+    """Nothing in the path is specialised to K = 40: labels for other k-mer lengths (the paired-flag window
+    and the partner offsets of find_wall scale with K) equal the oracle's."""
+    from classpro_amd import synth
+    from classpro_amd.api import Classifier, Batch, hist_covs
+    from oracle.oracle import Oracle
+    ds = synth.make_dataset(genome_len=150000, cov=cov, read_len=read_len, K=k, seed=90 + k, err_indel=0.001)
+    low, high, il, ih, h = ds["hist"]
+    hc, dc = hist_covs(h, low, high, il, ih, 0)
+    O = Oracle(k, 20000, hc, dc)
+    seqs, profs, want = [], [], []
+    for s_, p_ in zip(ds["seqs"], ds["profiles"]):
+        try:
+            want.append(O.classify_read(s_, p_))
+        except OverflowError:
+            continue
+        seqs.append(s_); profs.append(p_)
+    clf = Classifier(K=k, read_len=20000, hcov=hc, dcov=dc)
+    got = clf.classify(Batch.from_reads(seqs, profs))
+    assert got.tobytes() == b"".join(want)
+    clf.close()
