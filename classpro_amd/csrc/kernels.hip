@@ -1592,12 +1592,28 @@ k_paint_labels(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ 
   char *pasgn = lab+(K-1);
   const cp_intvl *intvl = intvl_all+ioff[r];
   const int N = nintvl[r];
-  for (int k = 0; k < N; k++)
-    { const int b = intvl[k].b, e = intvl[k].e;
-      const int a = intvl[k].asgn;
-      const char c = (a == CP_ERROR) ? 'E' : (a == CP_REPEAT) ? 'R' : (a == CP_HAPLO) ? 'H' : (a == CP_DIPLO) ? 'D' : '?';
-      for (int j = b+lane; j < e; j += WAVE)
-        pasgn[j] = c;
+  for (int base = 0; base < N; base += WAVE)             // 64 interval records per round of loads
+    { int b_l = 0, e_l = 0, a_l = -1;
+      if (base+lane < N)
+        { b_l = intvl[base+lane].b; e_l = intvl[base+lane].e; a_l = intvl[base+lane].asgn; }
+      const int nb = (N-base < WAVE) ? N-base : WAVE;
+      for (int k = 0; k < nb; k++)
+        { const int b = __builtin_amdgcn_readlane(b_l,k), e = __builtin_amdgcn_readlane(e_l,k);
+          const int a = __builtin_amdgcn_readlane(a_l,k);
+          const unsigned c = (a == CP_ERROR) ? 'E' : (a == CP_REPEAT) ? 'R' : (a == CP_HAPLO) ? 'H' : (a == CP_DIPLO) ? 'D' : '?';
+          char *p0 = pasgn+b, *p1 = pasgn+e;               // [p0,p1): bytes up to the first aligned word, words, rest
+          char *w0 = (char *)(((uintptr_t)p0+3) & ~(uintptr_t)3), *w1 = (char *)((uintptr_t)p1 & ~(uintptr_t)3);
+          if (w0 >= w1)
+            { for (char *q = p0+lane; q < p1; q += WAVE) *q = (char)c; }
+          else
+            { if (p0+lane < w0) p0[lane] = (char)c;
+              if (w1+lane < p1) w1[lane] = (char)c;
+              uint32_t *ww = (uint32_t *)w0;
+              const int nw = (int)((w1-w0) >> 2);
+              for (int j = lane; j < nw; j += WAVE)
+                ww[j] = c*0x01010101u;
+            }
+        }
     }
 }
 
