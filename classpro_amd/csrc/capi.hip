@@ -470,6 +470,13 @@ extern "C" int cp_seq_context(const char *d_seq, const int64_t *d_seq_off, int n
 
 #ifdef CP_PROF_WALK
 // diagnostic builds only: per-phase wave times of k_find_wall (max / sum / arg-max over reads), then reset
+extern "C" int cp_debug_live_prof(unsigned long long *out8)
+{ HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out8,HIP_SYMBOL(g_live_prof),8*sizeof(unsigned long long)));
+  unsigned long long z[8] = {0};
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_live_prof),z,sizeof(z)));
+  return CP_OK;
+}
 extern "C" int cp_debug_phase_prof(unsigned long long *out24)
 { HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpyFromSymbol(out24,HIP_SYMBOL(g_phase_max),8*sizeof(unsigned long long)));

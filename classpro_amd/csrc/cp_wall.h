@@ -147,6 +147,15 @@ struct cp_read_t
     int                  spec_wallnow = 0;
   };
 
+#if defined(CP_PROF_WALK) && defined(__HIP_DEVICE_COMPILE__)
+extern __device__ unsigned long long g_live_prof[8];
+#define CP_LT(k) do { unsigned long long t_ = wall_clock64(); if (__ffsll((long long)__ballot(1))-1 == (int)(threadIdx.x & 63)) atomicAdd(&g_live_prof[k],t_-lt_); lt_ = wall_clock64(); } while (0)
+#define CP_LT0() unsigned long long lt_ = wall_clock64()
+#else
+#define CP_LT(k) ((void)0)
+#define CP_LT0() ((void)0)
+#endif
+
 #define CP_PERR(R,i,e,w) ((R)->perror.get(i,e,w))
 #define CP_NEG_INF (-INFINITY)
 
@@ -268,7 +277,9 @@ CP_HD void cp_wall_candidate_live(RD *R, int i, int e, const cp_wall_pre &pre, c
   const int t = pre.maxt, l = pre.maxl;
   out->flags = CP_CF_LIVE; out->lc_kind = CP_LC_NONE; out->lc_j = -1; out->hc_j = -1;
   out->lc_v = out->hc_pe = CP_NEG_INF;
+  CP_LT0();
   out->own_pe = cp_p_errorin(R->lf,e,pre.maxpe,pre.lpe,pre.l1mpe,cout,cin);
+  CP_LT(0);
 
   // find_gain (w == DROP: partner GAIN to the right of i) / find_drop (w == GAIN: partner DROP to the
   // left), wall.c:331-507, folded into one routine by mirroring the index arithmetic.
@@ -287,6 +298,7 @@ CP_HD void cp_wall_candidate_live(RD *R, int i, int e, const cp_wall_pre &pre, c
         break;
       n++;
     }
+  CP_LT(1);
   j = right ? (i+K-1)+n-m : (i-K+1)-n+m;
   if (right ? (j <= i) : (j >= i))
     return;                                              // lc_kind NONE: no pair at all (wall.c:355 / 442)
@@ -308,6 +320,7 @@ CP_HD void cp_wall_candidate_live(RD *R, int i, int e, const cp_wall_pre &pre, c
         out->lc_kind = CP_LC_REJECT;
     }
 
+  CP_LT(2);
   // high-complexity partners (wall.c:380-404 / 469-493)
   bool   have_pe_i = false;
   double pe_i = 0., max_pe = CP_NEG_INF;
@@ -338,6 +351,7 @@ CP_HD void cp_wall_candidate_live(RD *R, int i, int e, const cp_wall_pre &pre, c
     }
   out->hc_j = max_j;
   out->hc_pe = max_pe;
+  CP_LT(3);
 }
 
 template <class RD>

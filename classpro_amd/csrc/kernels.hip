@@ -431,6 +431,7 @@ __device__ void wave_wall_mult(RD *R, int i, int NS, int *midx)
 // ---------------------------------------------------------------------------------------------
 #ifdef CP_PROF_WALK
 __device__ unsigned long long g_phase_max[8], g_phase_sum[8], g_phase_arg[8];
+__device__ unsigned long long g_live_prof[8];
 #define PH_STAMP(k) do { if (lane == 0) { unsigned long long t_ = wall_clock64(); unsigned long long d_ = t_-ph_t; ph_t = t_; \
       atomicAdd(&g_phase_sum[k],d_); unsigned long long o_ = atomicMax(&g_phase_max[k],d_); if (d_ > o_) g_phase_arg[k] = ((unsigned long long)r << 32) | (unsigned)n_c; } } while (0)
 #else
