@@ -36,7 +36,7 @@ def build(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
     cmd = [hipcc, "-O2", "-std=c++17", os.path.join(CSRC, "host", "classpro_main.cpp"), "-o", CLI,
-           "-L" + _HERE, "-lclasspro_amd", "-lz", "-Wl,-rpath,$ORIGIN"]
+           "-L" + _HERE, "-lclasspro_amd", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -30,6 +30,9 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
 #include "../../../include/classpro_amd.h"
 #include "host_io.h"
 #include "dazz_db.h"
@@ -194,15 +197,23 @@ int main(int argc, char **argv)
   std::vector<char> obuf(1 << 22);
   setvbuf(out,obuf.data(),_IOFBF,obuf.size());
 
-  const size_t BATCH_BASES = (size_t)256 << 20, BATCH_READS = 1 << 17;
-  Batch B[2];
-  B[0].alloc(BATCH_BASES+CP_MAX_READ_LEN,BATCH_READS);
-  B[1].alloc(BATCH_BASES+CP_MAX_READ_LEN,BATCH_READS);
+  // Three batches in flight: the main thread reads batch k+1 from the input while the device classifies
+  // batch k and a writer thread prints batch k-1.
+  const size_t BATCH_BASES = (size_t)128 << 20, BATCH_READS = 1 << 16;
+  constexpr int NB = 3;
+  Batch B[NB];
+  for (int k = 0; k < NB; k++)
+    B[k].alloc(BATCH_BASES+CP_MAX_READ_LEN,BATCH_READS);
 
   int64_t id = 0, total_bases = 0;
   bool more = true;
+  double t_stage = 0., t_wait = 0., t_write = 0.;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b-a).count(); };
+  const double t_setup = secs(t_start,now());
   auto stage = [&](Batch &b)                       // fill one batch from the input; false when nothing was read
-    { b.reset();
+    { const auto t0_ = now();
+      b.reset();
       b.h_soff[0] = b.h_poff[0] = b.h_coff[0] = 0;
       while (more && (size_t)b.bases < BATCH_BASES && (size_t)b.n < BATCH_READS)
         { if (id >= P.nreads) { more = false; break; }
@@ -245,6 +256,7 @@ int main(int argc, char **argv)
           id++;
         }
       if (id >= P.nreads) more = false;
+      t_stage += secs(t0_,now());
       return !b.headers.empty();
     };
   auto submit = [&](Batch &b)
@@ -258,8 +270,9 @@ int main(int argc, char **argv)
       CPOK(cp_classify_batch(params,b.ws,b.d_seq,b.d_soff,b.d_prof,b.d_poff,b.n,b.bases,b.kmers,b.d_lab,b.st));
       HIPOK(hipMemcpyAsync(b.h_lab,b.d_lab,(size_t)b.bases,hipMemcpyDeviceToHost,b.st));
     };
-  auto finish = [&](Batch &b)
-    { if (b.n > 0)
+  auto wait_device = [&](Batch &b)
+    { const auto t0_ = now();
+      if (b.n > 0)
         { HIPOK(hipStreamSynchronize(b.st));
           if (cp_workspace_check(b.ws) != CP_OK)
             { // a failed decode: find the read on the host so the message is the reference's (ClassPro.c:234-237)
@@ -273,6 +286,10 @@ int main(int argc, char **argv)
               die("%s\n",cp_last_error());
             }
         }
+      t_wait += secs(t0_,now());
+    };
+  auto write_out = [&](Batch &b)                   // runs on the writer thread
+    { const auto t1_ = now();
       size_t si = 0;
       for (size_t r = 0; r < b.headers.size(); r++)              // ClassPro.c:215,289
         { fputs(b.headers[r].c_str(),out); fputc('\n',out);
@@ -293,17 +310,54 @@ int main(int argc, char **argv)
             }
         }
       total_bases += b.bases;
+      t_write += secs(t1_,now());
+    };
+
+  // writer thread: prints the batches it is handed, in order
+  std::mutex mu;
+  std::condition_variable cv;
+  int to_write[NB], nq = 0, qhead = 0;             // queue of batch indices
+  bool busy[NB] = { false, false, false }, quit = false;
+  std::thread writer([&]
+    { for (;;)
+        { int k;
+          { std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk,[&] { return nq > 0 || quit; });
+            if (nq == 0) return;
+            k = to_write[qhead]; qhead = (qhead+1)%NB; nq--;
+          }
+          write_out(B[k]);
+          { std::lock_guard<std::mutex> lk(mu); busy[k] = false; }
+          cv.notify_all();
+        }
+    });
+  auto hand_to_writer = [&](int k)
+    { { std::lock_guard<std::mutex> lk(mu); busy[k] = true; to_write[(qhead+nq)%NB] = k; nq++; }
+      cv.notify_all();
+    };
+  auto wait_free = [&](int k)
+    { std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk,[&] { return !busy[k]; });
     };
 
   int cur = 0;
   bool have = stage(B[cur]);
   while (have)
     { submit(B[cur]);
-      bool have_next = more ? stage(B[cur^1]) : false;       // host stages the next batch while the GPU works
-      finish(B[cur]);
-      cur ^= 1;
+      const int nxt = (cur+1)%NB;
+      bool have_next = false;
+      if (more)
+        { wait_free(nxt);                                    // its previous contents have been printed
+          have_next = stage(B[nxt]);                         // the host reads the next batch while the device works
+        }
+      wait_device(B[cur]);
+      hand_to_writer(cur);
+      cur = nxt;
       have = have_next;
     }
+  { std::lock_guard<std::mutex> lk(mu); quit = true; }
+  cv.notify_all();
+  writer.join();
   fclose(out);
   class_track.close();
 
@@ -311,6 +365,8 @@ int main(int argc, char **argv)
     { double s = std::chrono::duration<double>(std::chrono::steady_clock::now()-t_start).count();
       fprintf(stderr,"\nResources for phase:  %.3f (s) wall, %.1f Mbases classified (%.1f Mbases/s end to end)\n",
               s,total_bases/1e6,total_bases/1e6/s);
+      fprintf(stderr,"    host: %.3f s set-up, %.3f s reading, %.3f s waiting for the device, %.3f s writing\n",
+              t_setup,t_stage,t_wait,t_write);
     }
   cp_params_destroy(params);
   return 0;

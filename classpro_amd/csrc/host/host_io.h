@@ -59,16 +59,42 @@ struct FastxReader
     bool have_comment;
     bool bad_qual = false;         // FASTQ record whose quality string is not as long as its sequence (kseq: -2)
 
-    explicit FastxReader(const char *path) : f(gzopen(path,"r")), buf(1 << 16), beg(0), end(0), eof(false), last(0), have_comment(false) {}
+    explicit FastxReader(const char *path) : f(gzopen(path,"r")), buf(1 << 20), beg(0), end(0), eof(false), last(0), have_comment(false)
+    { if (f) gzbuffer(f,1 << 20); }
     ~FastxReader() { if (f) gzclose(f); }
+    bool fill()
+    { if (eof) return false;
+      beg = 0;
+      end = gzread(f,buf.data(),(unsigned)buf.size());
+      if (end <= 0) { eof = true; end = 0; return false; }
+      return true;
+    }
     int getc()
-    { if (beg >= end)
-        { if (eof) return -1;
-          beg = 0;
-          end = gzread(f,buf.data(),(unsigned)buf.size());
-          if (end <= 0) { eof = true; end = 0; return -1; }
-        }
+    { if (beg >= end && !fill()) return -1;
       return buf[beg++];
+    }
+    // Appends the rest of the current line (without its newline) to *dst, a block at a time; with `graph`
+    // only the characters above ' ' (what the per-character loop of the sequence lines keeps).  Returns
+    // false when the input ended before a newline.
+    bool rest_of_line(std::string *dst, bool graph)
+    { for (;;)
+        { if (beg >= end && !fill()) return false;
+          const unsigned char *p = buf.data()+beg;
+          const size_t n = (size_t)(end-beg);
+          const unsigned char *nl = (const unsigned char *)memchr(p,'\n',n);
+          const size_t len = nl ? (size_t)(nl-p) : n;
+          if (dst)
+            { bool clean = true;
+              if (graph)
+                for (size_t k = 0; k < len; k++) clean &= (p[k] > 32);
+              if (clean) dst->append((const char *)p,len);
+              else
+                for (size_t k = 0; k < len; k++)
+                  if (p[k] > 32) dst->push_back((char)p[k]);
+            }
+          beg += (int)(len+(nl ? 1 : 0));
+          if (nl) return true;
+        }
     }
     // returns sequence length, or -1 at end of file
     int next()
@@ -84,27 +110,25 @@ struct FastxReader
       while ((c = getc()) != -1 && c != ' ' && c != '\t' && c != '\n' && c != '\r') name.push_back((char)c);
       if (c == ' ' || c == '\t')
         { got_comment = true;
-          while ((c = getc()) != -1 && c != '\n') cm.push_back((char)c);
+          rest_of_line(&cm,false);
           if (!cm.empty() && cm.back() == '\r') cm.pop_back();
         }
       else if (c == '\r')
-        while ((c = getc()) != -1 && c != '\n') ;
+        rest_of_line(nullptr,false);
       if (got_comment) { comment = cm; have_comment = true; }    // kseq leaves the old comment buffer otherwise
       while ((c = getc()) != -1 && c != '>' && c != '+' && c != '@')
         { if (c == '\n') continue;
           if (c > 32) seq.push_back((char)c);
-          while ((c = getc()) != -1 && c != '\n')
-            if (c > 32) seq.push_back((char)c);
+          rest_of_line(&seq,true);
         }
       if (c == '>' || c == '@') last = c;
       else last = 0;
       if (c == '+')                                             // FASTQ: skip the rest of the '+' line, read the qualities
-        { while ((c = getc()) != -1 && c != '\n') ;
-          if (c == -1) { bad_qual = true; return -1; }           // kseq: "no quality string" (-2)
+        { if (!rest_of_line(nullptr,false)) { bad_qual = true; return -1; }   // kseq: "no quality string" (-2)
           while (qual.size() < seq.size())                      // whole lines, as kseq does
-            { while ((c = getc()) != -1 && c != '\n') qual.push_back((char)c);
+            { const bool more = rest_of_line(&qual,false);
               if (!qual.empty() && qual.back() == '\r') qual.pop_back();
-              if (c == -1) break;
+              if (!more) break;
             }
           last = 0;
           if (qual.size() != seq.size()) { bad_qual = true; return -1; }
