@@ -14,7 +14,7 @@ SYMBOLS = [
     "cp_params_export", "cp_decode_profile", "cp_workspace_create", "cp_workspace_destroy",
     "cp_workspace_bytes", "cp_classify_batch", "cp_workspace_check", "cp_run_stages", "cp_get_counts",
     "cp_get_intervals", "cp_get_rel_asgn", "cp_get_bitmap", "cp_seq_context", "cp_scan_candidates",
-    "cp_encode_profile", "cp_decode_profiles", "cp_params_create_model", "cp_load_error_model",
+    "cp_encode_profile", "cp_decode_profiles", "cp_params_create_model", "cp_load_error_model", "cp_unpack_bases",
 ]
 
 _lib = None
@@ -63,6 +63,7 @@ def lib():
     L.cp_encode_profile.argtypes = [vp, i32, vp, i64]
     L.cp_encode_profile.restype = i64
     L.cp_decode_profiles.argtypes = [vp, vp, vp, vp, i32, vp, vp]
+    L.cp_unpack_bases.argtypes = [vp, vp, vp, i32, vp, vp]
     _lib = L
     return L
 

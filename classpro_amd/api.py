@@ -157,6 +157,17 @@ class Classifier:
         check(self.L.cp_workspace_check(self.ws))
         return out
 
+    def unpack_bases(self, packed, pack_off, seq_off):
+        """Dazzler 2-bit bases -> upper-case characters on the device (uint8 tensor)."""
+        dev = self.device
+        pk = torch.from_numpy(np.ascontiguousarray(packed, np.uint8)).to(dev)
+        po = torch.from_numpy(np.ascontiguousarray(pack_off, np.int64)).to(dev)
+        so = torch.from_numpy(np.ascontiguousarray(seq_off, np.int64)).to(dev)
+        out = torch.zeros(max(int(seq_off[-1]), 8), dtype=torch.uint8, device=dev)
+        check(self.L.cp_unpack_bases(pk.data_ptr(), po.data_ptr(), so.data_ptr(), len(seq_off) - 1, out.data_ptr(), self._stream()))
+        torch.cuda.synchronize(dev)
+        return out
+
     def workspace_bytes(self):
         return int(self.L.cp_workspace_bytes(self.ws))
 

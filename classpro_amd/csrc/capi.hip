@@ -457,6 +457,16 @@ extern "C" int cp_decode_profiles(cp_workspace *ws, const uint8_t *d_codes, cons
   return CP_OK;
 }
 
+extern "C" int cp_unpack_bases(const uint8_t *d_packed, const int64_t *d_pack_off, const int64_t *d_seq_off,
+                               int nreads, char *d_seq, void *stream)
+{ if (nreads < 0 || (nreads > 0 && (!d_packed || !d_pack_off || !d_seq_off || !d_seq)))
+    return set_err(CP_EINVAL,"cp_unpack_bases: bad argument");
+  if (nreads == 0) return CP_OK;
+  hipLaunchKernelGGL(k_unpack_bases,dim3(nreads),dim3(256),0,(hipStream_t)stream,d_packed,d_pack_off,d_seq_off,nreads,d_seq);
+  HIPCHK(hipGetLastError());
+  return CP_OK;
+}
+
 extern "C" int cp_seq_context(const char *d_seq, const int64_t *d_seq_off, int nreads, int64_t total_bases,
                               uint8_t *d_lctx, uint8_t *d_rctx, void *stream)
 { if (!d_seq || !d_seq_off || !d_lctx || !d_rctx || nreads < 0)

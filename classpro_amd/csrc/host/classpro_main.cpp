@@ -49,7 +49,9 @@ static const char *EXT[10] = { ".db", ".dam", ".fastq", ".fasta", ".fq", ".fa",
 // ---- one batch in flight ----------------------------------------------------------------------------
 struct Batch
   { char *h_seq = nullptr, *h_lab = nullptr; uint8_t *h_code = nullptr;
-    int64_t *h_soff = nullptr, *h_poff = nullptr, *h_coff = nullptr;
+    int64_t *h_soff = nullptr, *h_poff = nullptr, *h_coff = nullptr, *h_boff = nullptr;
+    uint8_t *h_pack = nullptr, *d_pack = nullptr;    // database inputs: 2-bit bases as stored in the .bps file
+    int64_t *d_boff = nullptr; int64_t packed = 0;
     char *d_seq = nullptr, *d_lab = nullptr; uint8_t *d_code = nullptr; uint16_t *d_prof = nullptr;
     int64_t *d_soff = nullptr, *d_poff = nullptr, *d_coff = nullptr;
     size_t cap_bases = 0, cap_reads = 0, cap_code = 0;
@@ -60,13 +62,17 @@ struct Batch
     std::vector<std::string> short_seq;
     hipStream_t st = nullptr;
     cp_workspace *ws = nullptr;
-    void alloc(size_t bases_cap, size_t reads_cap)
+    void alloc(size_t bases_cap, size_t reads_cap, bool with_pack)
     { cap_bases = bases_cap; cap_reads = reads_cap;
       HIPOK(hipHostMalloc((void **)&h_seq,bases_cap)); HIPOK(hipHostMalloc((void **)&h_lab,bases_cap));
       cap_code = bases_cap;                      // FASTK codes run ~0.1-0.3 B/base on HiFi data; a batch closes early if they fill up
       HIPOK(hipHostMalloc((void **)&h_code,cap_code));
       HIPOK(hipHostMalloc((void **)&h_soff,(reads_cap+1)*8)); HIPOK(hipHostMalloc((void **)&h_poff,(reads_cap+1)*8));
       HIPOK(hipHostMalloc((void **)&h_coff,(reads_cap+1)*8));
+      if (with_pack)
+        { HIPOK(hipHostMalloc((void **)&h_pack,bases_cap/4+reads_cap)); HIPOK(hipMalloc((void **)&d_pack,bases_cap/4+reads_cap));
+          HIPOK(hipHostMalloc((void **)&h_boff,(reads_cap+1)*8)); HIPOK(hipMalloc((void **)&d_boff,(reads_cap+1)*8));
+        }
       HIPOK(hipMalloc((void **)&d_seq,bases_cap)); HIPOK(hipMalloc((void **)&d_lab,bases_cap));
       HIPOK(hipMalloc((void **)&d_code,cap_code)); HIPOK(hipMalloc((void **)&d_prof,bases_cap*2));
       HIPOK(hipMalloc((void **)&d_soff,(reads_cap+1)*8)); HIPOK(hipMalloc((void **)&d_poff,(reads_cap+1)*8));
@@ -74,7 +80,7 @@ struct Batch
       HIPOK(hipStreamCreate(&st));
       CPOK(cp_workspace_create(&ws));
     }
-    void reset() { n = 0; bases = kmers = codes = 0; headers.clear(); slot.clear(); short_seq.clear(); read_id.clear(); }
+    void reset() { n = 0; bases = kmers = codes = packed = 0; headers.clear(); slot.clear(); short_seq.clear(); read_id.clear(); }
   };
 
 int main(int argc, char **argv)
@@ -203,7 +209,7 @@ int main(int argc, char **argv)
   constexpr int NB = 3;
   Batch B[NB];
   for (int k = 0; k < NB; k++)
-    B[k].alloc(BATCH_BASES+CP_MAX_READ_LEN,BATCH_READS);
+    B[k].alloc(BATCH_BASES+CP_MAX_READ_LEN,BATCH_READS,is_db);
 
   int64_t id = 0, total_bases = 0;
   bool more = true;
@@ -248,7 +254,13 @@ int main(int argc, char **argv)
           // the decode kernel and reported in finish().
           int plen = rlen-Km1;
           memcpy(b.h_code+b.codes,code,(size_t)clen);
-          memcpy(b.h_seq+b.bases,fx.seq.data(),(size_t)rlen);
+          memcpy(b.h_seq+b.bases,fx.seq.data(),(size_t)rlen);          // kept on the host for the output record
+          if (is_db)
+            { if (b.n == 0) b.h_boff[0] = 0;
+              memcpy(b.h_pack+b.packed,db.cbuf.data(),(size_t)db.clen);
+              b.packed += db.clen;
+              b.h_boff[b.n+1] = b.packed;
+            }
           b.slot.push_back(b.n);
           b.read_id.push_back(id);
           b.bases += rlen; b.kmers += plen; b.codes += clen; b.n++;
@@ -261,11 +273,17 @@ int main(int argc, char **argv)
     };
   auto submit = [&](Batch &b)
     { if (b.n == 0) return;
-      HIPOK(hipMemcpyAsync(b.d_seq,b.h_seq,(size_t)b.bases,hipMemcpyHostToDevice,b.st));
+      if (!is_db)
+        HIPOK(hipMemcpyAsync(b.d_seq,b.h_seq,(size_t)b.bases,hipMemcpyHostToDevice,b.st));
       HIPOK(hipMemcpyAsync(b.d_code,b.h_code,(size_t)b.codes,hipMemcpyHostToDevice,b.st));
       HIPOK(hipMemcpyAsync(b.d_soff,b.h_soff,(size_t)(b.n+1)*8,hipMemcpyHostToDevice,b.st));
       HIPOK(hipMemcpyAsync(b.d_poff,b.h_poff,(size_t)(b.n+1)*8,hipMemcpyHostToDevice,b.st));
       HIPOK(hipMemcpyAsync(b.d_coff,b.h_coff,(size_t)(b.n+1)*8,hipMemcpyHostToDevice,b.st));
+      if (is_db)                                                  // 2-bit bases in, characters made on the device
+        { HIPOK(hipMemcpyAsync(b.d_pack,b.h_pack,(size_t)b.packed,hipMemcpyHostToDevice,b.st));
+          HIPOK(hipMemcpyAsync(b.d_boff,b.h_boff,(size_t)(b.n+1)*8,hipMemcpyHostToDevice,b.st));
+          CPOK(cp_unpack_bases(b.d_pack,b.d_boff,b.d_soff,b.n,b.d_seq,b.st));
+        }
       CPOK(cp_decode_profiles(b.ws,b.d_code,b.d_coff,b.d_poff,b.n,b.d_prof,b.st));
       CPOK(cp_classify_batch(params,b.ws,b.d_seq,b.d_soff,b.d_prof,b.d_poff,b.n,b.bases,b.kmers,b.d_lab,b.st));
       HIPOK(hipMemcpyAsync(b.h_lab,b.d_lab,(size_t)b.bases,hipMemcpyDeviceToHost,b.st));

@@ -81,10 +81,13 @@ struct DazzDB
       cbuf.resize((size_t)maxlen/4+8);
     }
 
-    // Load_Read(db,i,seq,2): upper-case ASCII
+    // Load_Read(db,i,seq,2): upper-case ASCII.  The packed bytes stay in cbuf (clen of them) for callers that
+    // ship them to the device as they are.
+    int clen = 0;
     void load(int i, std::string &seq)
     { const DazzRead &r = reads[(size_t)i];
-      const int len = r.rlen, clen = (len+3) >> 2;
+      const int len = r.rlen;
+      clen = (len+3) >> 2;
       if ((size_t)clen > cbuf.size()) cbuf.resize((size_t)clen);
       if (fseeko(bases,(off_t)r.boff,SEEK_SET) != 0 || (clen > 0 && fread(cbuf.data(),(size_t)clen,1,bases) != 1))
         die("%s: Failed read of .bps file (Load_Read)\n",PROG);

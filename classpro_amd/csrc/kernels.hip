@@ -1718,6 +1718,31 @@ k_decode_profiles(const uint8_t *__restrict__ codes, const int64_t *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+//  k_unpack_bases: Dazzler 2-bit bases (4 per byte, first base in the top bits: Compress_Read /
+//  Uncompress_Read, DB.c:319-363) -> the upper-case characters Load_Read(...,2) hands ClassPro
+//  (a database ships 0.25 B/base over PCIe instead of 1).  One block per read,
+//  one packed byte (four characters) per thread and step.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_unpack_bases(const uint8_t *__restrict__ packed, const int64_t *__restrict__ pack_off,
+               const int64_t *__restrict__ seq_off, int nreads, char *__restrict__ seq)
+{ const int r = blockIdx.x;
+  if (r >= nreads) return;
+  const uint8_t *src = packed+pack_off[r];
+  char *dst = seq+seq_off[r];
+  const int rlen = (int)(seq_off[r+1]-seq_off[r]);
+  const int clen = (rlen+3) >> 2;
+  for (int k = threadIdx.x; k < clen; k += blockDim.x)
+    { const unsigned b = src[k];
+      const int p = 4*k;
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (p+q < rlen)
+          dst[p+q] = "ACGT"[(b >> (6-2*q)) & 3];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 //  k_seq_context: dense lctx/rctx ([base][3] uint8) for the stage API and parity tests.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)

@@ -122,6 +122,13 @@ int cp_classify_batch(const cp_params *p, cp_workspace *ws,
 int cp_decode_profiles(cp_workspace *ws, const uint8_t *d_codes, const int64_t *d_code_off,
                        const int64_t *d_prof_off, int nreads, uint16_t *d_prof, void *stream);
 
+/* Dazzler 2-bit bases on the device (Load_Read(db,i,buf,2), DB.c:1232-1298 with Uncompress_Read / Upper_Read,
+ * DB.c:342-381): read r's COMPRESSED_LEN(rlen_r) = (rlen_r+3)/4 bytes start at d_packed[d_pack_off[r]] (the bytes
+ * of the .bps file at DAZZ_READ.boff), 4 bases per byte, first base in the top two bits; d_seq receives
+ * 'A' 'C' 'G' 'T' at d_seq_off[r].  A database input then crosses PCIe at 0.25 B/base. */
+int  cp_unpack_bases(const uint8_t *d_packed, const int64_t *d_pack_off, const int64_t *d_seq_off,
+                     int nreads, char *d_seq, void *stream);
+
 /* Waits for the last run on `ws` and returns CP_EOVERFLOW if a read needed more E-interval /
  * interval scratch than its capacity (the reference aborts likewise: "# E-intvls >= plen",
  * src/wall.c:783-788).  Call after cp_classify_batch before trusting the labels. */

@@ -428,3 +428,21 @@ def test_other_kmer_lengths(torch_dev, k, read_len, cov):
     got = clf.classify(Batch.from_reads(seqs, profs))
     assert got.tobytes() == b"".join(want)
     clf.close()
+
+
+def test_unpack_bases_on_device(torch_dev):
+    """cp_unpack_bases == Load_Read(...,2) of DAZZ_DB (DB.c:1232-1298): 2-bit bases, first base in the top bits,
+    lengths that are not multiples of four, a read of length 1."""
+    from classpro_amd import dazz
+    from classpro_amd.api import Classifier
+    rng = np.random.default_rng(3)
+    lens = [1, 2, 3, 4, 5, 63, 64, 65, 1000, 4097, 20001]
+    seqs = [bytes(b"ACGT"[x] for x in rng.integers(0, 4, n)) for n in lens]
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    packed = [dazz.pack_2bit([code[c] for c in s]) for s in seqs]
+    poff = np.concatenate([[0], np.cumsum([len(p) for p in packed])]).astype(np.int64)
+    soff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    clf = Classifier(K=K, read_len=20000, hcov=20, dcov=40)
+    out = clf.unpack_bases(np.concatenate(packed), poff, soff)
+    assert out[:soff[-1]].cpu().numpy().tobytes() == b"".join(seqs)
+    clf.close()
