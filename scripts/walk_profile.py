@@ -26,9 +26,9 @@ clf.run(b, STAGE_WALL)
 lib().cp_debug_phase_prof(ph)
 lib().cp_debug_live_prof(lv)
 pn = ["0 candidate list", "1 replay (2 lanes)", "2 unwall/sort/olist", "3 wall_mult (lane 0)", "4 merge + sorts",
-      "5 boundaries + records", "6 prelude/filter + live tasks", "7 replay: chunk staging"]
+      "5 boundaries + records", "6 prelude/filter + live tasks"]
 print("phase                          max over reads (ticks)   mean      argmax read / its ncand   (100 MHz ticks)")
-for k in (0, 6, 7, 1, 2, 3, 4, 5):
+for k in (0, 6, 1, 2, 3, 4, 5):
     print("  %-30s %12d %12.1f      %d / %d" % (pn[k], ph[k], ph[8 + k] / b.nreads, ph[16 + k] >> 32, ph[16 + k] & 0xffffffff))
 print("inside the live-task evaluation (wave time, ticks per read): own P(error) %.0f, low-complexity partner search %.0f,"
       " its filters + P(error) %.0f, six high-complexity partners %.0f" % tuple(lv[k] / b.nreads for k in range(4)))
