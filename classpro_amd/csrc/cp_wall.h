@@ -652,6 +652,34 @@ CP_HD void cp_make_interval(const RD *R, int NS, int b, int e, cp_intvl *out)
   out->peo_e = (peoe != CP_NEG_INF) ? log(peoe) : CP_NEG_INF;
 }
 
+// Sum over i in [lo,hi) of the upward (sgn = +1) or downward (sgn = -1) steps prof[i+1]-prof[i] of a count
+// profile, eight counts per load where that stays inside the read's plen counts (the addresses are only
+// 2-byte aligned; gfx9 global loads take unaligned addresses).  Same terms as the loops of wall.c:972-1001.
+struct __attribute__((packed, aligned(2))) cp_u16x8 { uint16_t v[8]; };
+CP_HD int cp_sum_steps(const uint16_t *prof, int lo, int hi, int plen, int sgn)
+{ int acc = 0, i = lo;
+  if (lo >= hi) return 0;
+  int prev = prof[lo];
+  while (i+8 <= hi && i+8 < plen)
+    { const cp_u16x8 x = *reinterpret_cast<const cp_u16x8 *>(prof+i+1);
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+      for (int q = 0; q < 8; q++)
+        { const int cur = x.v[q], d = sgn*(cur-prev);
+          if (d > 0) acc += d;
+          prev = cur;
+        }
+      i += 8;
+    }
+  for (; i < hi; i++)
+    { const int cur = prof[i+1], d = sgn*(cur-prev);
+      if (d > 0) acc += d;
+      prev = cur;
+    }
+  return acc;
+}
+
 // correct_wall_cnt + the filters of find_rel_intvl, wall.c:960-1051, for interval `idx`.
 // The reference's position-indexed loops at wall.c:999-1006 only ever touch the interval itself when
 // its index equals its start position (SURVEY.md hazard 2); that case is applied explicitly.
@@ -666,11 +694,9 @@ CP_HD bool cp_rel_interval(const cp_dev_params *P, const uint16_t *prof, const c
     return false;
 
   int first, last, n_gain = 0, n_drop = 0, lmax;
+  const int plen = rlen-(K-1);
   last = (I->b+K-1 < I->e-1) ? I->b+K-1 : I->e-1;
-  for (int i = I->b; i < last; i++)
-    { int d = (int)prof[i+1]-prof[i];
-      if (d > 0) n_gain += d;
-    }
+  n_gain += cp_sum_steps(prof,I->b,last,plen,+1);
   if (I->b+K-1 < I->e)
     { lmax = 0;
       for (int t = 0; t < 3; t++)
@@ -678,16 +704,10 @@ CP_HD bool cp_rel_interval(const cp_dev_params *P, const uint16_t *prof, const c
           if (lmax < l) lmax = l;
         }
       last = I->b+lmax;
-      for (int i = I->b; i < last; i++)
-        { int d = (int)prof[i]-prof[i+1];
-          if (d > 0) n_gain -= d;
-        }
+      n_gain -= cp_sum_steps(prof,I->b,last,plen,-1);
     }
   first = (I->e-K+1 > I->b) ? I->e-K+1 : I->b;
-  for (int i = first; i < I->e-1; i++)
-    { int d = (int)prof[i]-prof[i+1];
-      if (d > 0) n_drop += d;
-    }
+  n_drop += cp_sum_steps(prof,first,I->e-1,plen,-1);
   if (I->b < I->e-K+1)
     { lmax = 0;
       for (int t = 0; t < 3; t++)
@@ -695,10 +715,7 @@ CP_HD bool cp_rel_interval(const cp_dev_params *P, const uint16_t *prof, const c
           if (lmax < l) lmax = l;
         }
       first = I->e-lmax;
-      for (int i = first; i < I->e-1; i++)
-        { int d = (int)prof[i+1]-prof[i];
-          if (d > 0) n_drop -= d;
-        }
+      n_drop -= cp_sum_steps(prof,first,I->e-1,plen,+1);
     }
   int ccb = I->cb+(n_gain > 0 ? n_gain : 0);
   int cce = I->ce+(n_drop > 0 ? n_drop : 0);
