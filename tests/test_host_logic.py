@@ -194,3 +194,24 @@ def test_device_functions_vs_oracle_long_reads(harness):
         N, lab, *_ = run_harness_read(harness, P, s, p)
         assert lab == O.classify_read(s, p)
     harness.hh_params_free(C.c_void_p(P))
+
+
+def test_device_functions_vs_oracle_adversarial(harness):
+    """The product's scalar functions (pre / filter / live / replay split of the candidate walk, post-walk,
+    classify) compiled for the host against the oracle on adversarial inputs (tests/adversarial.py)."""
+    from adversarial import adversarial_reads
+    from oracle.oracle import Oracle
+    seqs, profs = adversarial_reads(7, n=120)
+    O = Oracle(40, 20000, 20, 40)
+    P = harness.hh_params_new(40, 20000, 20, 40)
+    n = 0
+    for s, p in zip(seqs, profs):
+        try:
+            want = O.classify_read(s, p)
+        except OverflowError:
+            continue
+        N, lab, *_ = run_harness_read(harness, P, s, p)
+        assert lab == want
+        n += 1
+    assert n > 60
+    harness.hh_params_free(C.c_void_p(P))
