@@ -60,6 +60,18 @@ __device__ __forceinline__ uint4 scan_load(const uint4 *p)
 #define SCAN_BLOCKS_PER_CU 8
 #endif
 
+// per 16-bit half of (prevcur, cur): 1 if min < R and |difference| >= 3, else 0 (wall.c:592-608)
+typedef unsigned short cp_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned scan_pair_flags(unsigned prevcur, unsigned cur, int rep)
+{ const cp_us2 a = __builtin_bit_cast(cp_us2,prevcur), b = __builtin_bit_cast(cp_us2,cur);
+  const cp_us2 mn = __builtin_elementwise_min(a,b), mx = __builtin_elementwise_max(a,b);
+  const cp_us2 r2 = { (unsigned short)rep, (unsigned short)rep }, two = { 2, 2 }, one = { 1, 1 };
+  const cp_us2 s1 = __builtin_elementwise_sub_sat(r2,mn);              // != 0 <=> min < R
+  const cp_us2 s2 = __builtin_elementwise_sub_sat((cp_us2)(mx-mn),two);  // != 0 <=> difference >= 3
+  const cp_us2 m = __builtin_elementwise_min(__builtin_elementwise_min(s1,s2),one);
+  return __builtin_bit_cast(unsigned,m);
+}
+
 __global__ void __launch_bounds__(256)
 k_scan_candidates(const uint16_t *__restrict__ prof, int64_t total, int rep, uint8_t *__restrict__ bitmap, int64_t nbytes)
 { const int64_t ngroups = total >> 3;                   // full groups of 8 positions
@@ -87,20 +99,17 @@ k_scan_candidates(const uint16_t *__restrict__ prof, int64_t total, int rep, uin
 #pragma unroll
       for (int u = 0; u < SCAN_UNROLL; u++)
         { const bool live = g[u] < ngroups;
-          unsigned last = v[u].w >> 16;
-          unsigned prev = __shfl_up(last,1);
-          if (lane == 0) prev = carry;
-          carry = __shfl(last,WAVE-1);                  // lane 0's predecessor in the next row
-          unsigned c[8] = { v[u].x & 0xffff, v[u].x >> 16, v[u].y & 0xffff, v[u].y >> 16,
-                            v[u].z & 0xffff, v[u].z >> 16, v[u].w & 0xffff, v[u].w >> 16 };
-          unsigned bits = 0;
-#pragma unroll
-          for (int k = 0; k < 8; k++)
-            { unsigned a = prev, b = c[k];
-              unsigned mn = a < b ? a : b, df = a < b ? b-a : a-b;
-              bits |= ((mn < (unsigned)rep) && (df >= CP_MIN_CNT_CHANGE)) ? (1u << k) : 0u;
-              prev = b;
-            }
+          // packed 16-bit arithmetic, two counts per instruction: pair k of a dword holds (count, its
+          // predecessor); min < R and |difference| >= 3 become "both saturating differences non-zero"
+          unsigned before = __shfl_up(v[u].w,1);                      // the dword that ends with this lane's predecessor
+          if (lane == 0) before = carry << 16;
+          carry = __shfl(v[u].w,WAVE-1) >> 16;                        // lane 0's predecessor in the next row
+          const unsigned w0 = scan_pair_flags(__builtin_amdgcn_alignbit(v[u].x,before,16),v[u].x,rep);
+          const unsigned w1 = scan_pair_flags(__builtin_amdgcn_alignbit(v[u].y,v[u].x,16),v[u].y,rep);
+          const unsigned w2 = scan_pair_flags(__builtin_amdgcn_alignbit(v[u].z,v[u].y,16),v[u].z,rep);
+          const unsigned w3 = scan_pair_flags(__builtin_amdgcn_alignbit(v[u].w,v[u].z,16),v[u].w,rep);
+          const unsigned t = w0 | (w1 << 2) | (w2 << 4) | (w3 << 6);  // flags of the even counts in bits 0,2,4,6, odd ones 16 higher
+          const unsigned bits = (t & 0x55u) | ((t >> 15) & 0xaau);
           if (live)
             bitmap[g[u]] = (uint8_t)bits;
         }
