@@ -118,8 +118,8 @@ def main():
         # ---- roofline of the profile-scan kernel: HIP events on the launch stream ----------------
         nw = b.total_kmers // 64 + 2
         bm = torch.zeros(nw, dtype=torch.int64, device=dev)
-        iters = max(a.steps, 5) * 4
-        for _ in range(3):
+        iters = 200                                     # ~16 ms of back-to-back launches: a stable average
+        for _ in range(10):
             check(L.cp_scan_candidates(clf.p, b.prof.data_ptr(), b.total_kmers, bm.data_ptr(), stream))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(dev))
