@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py -- Mbases/s classified (k=40, 40x HiFi) on N MI355X, one process per GPU.
+"""bench.py -- BASELINE.json's metric, Mbases/s classified (k=40, 40x HiFi), on N MI355X, one process per GPU.
 
 A "step" is one pass of the whole hot path (cp_classify_batch: candidate scan, find_wall,
 find_rel_intvl, classify_rel, classify_unrel, label paint) over one batch of synthetic reads that is
@@ -213,7 +213,7 @@ def main():
                 nbad = int((lab[:so[-1]] != want).sum())
                 cpu["label_mismatches_vs_hip"] = nbad
         out = {
-            "metric": "Mbases/s classified (k=40, 40x HiFi)", "value": round(value, 2), "unit": "Mbases/s",
+            "metric": "Mbases/s classified (k=40, 40x HiFi) at 1/2/4/8 MI355X vs CPU -T16", "value": round(value, 2), "unit": "Mbases/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16/f64",
             "data": "synthetic",
