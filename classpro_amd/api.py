@@ -76,6 +76,17 @@ class Batch:
         self.labels = torch.zeros(max(self.total_bases, 1), dtype=torch.uint8, device=dev)
 
     @classmethod
+    def from_device(cls, rd):
+        """A batch over tensors that are already in HBM (a `DeviceSynth.reads()` result); nothing is copied."""
+        b = cls.__new__(cls)
+        b.device = rd["seq"].device
+        b.nreads, b.total_bases, b.total_kmers = rd["nreads"], rd["total_bases"], rd["total_kmers"]
+        b.seq_off_h, b.prof_off_h = rd["seq_off_h"], rd["prof_off_h"]
+        b.seq, b.prof, b.seq_off, b.prof_off = rd["seq"], rd["prof"], rd["seq_off"], rd["prof_off"]
+        b.labels = torch.zeros(max(b.total_bases, 1), dtype=torch.uint8, device=b.device)
+        return b
+
+    @classmethod
     def from_reads(cls, seqs, profiles, device="cuda:0"):
         from .synth import pack_batch
         return cls(*pack_batch(seqs, profiles), device=device)

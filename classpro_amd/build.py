@@ -9,6 +9,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OUT = os.path.join(_HERE, "libclasspro_amd.so")
+SYNTH = os.path.join(_HERE, "libcp_synth.so")  # device-side synthetic read sets: test / bench infrastructure (csrc/synth/)
 CLI = os.path.join(_HERE, "ClassPro")          # drop-in command line (csrc/host/classpro_main.cpp)
 TOOLS = {"prof2class": "prof2class.cpp", "class2acc": "class2acc.cpp"}   # host-only evaluation tools
 # -ffp-contract=off: the decision path compares doubles against thresholds and truncates them to
@@ -26,7 +27,7 @@ def _newest_src():
 
 
 def build(force=False, verbose=False):
-    outs = [OUT, CLI] + [os.path.join(_HERE, t) for t in TOOLS]
+    outs = [OUT, CLI, SYNTH] + [os.path.join(_HERE, t) for t in TOOLS]
     if (not force and all(os.path.exists(o) for o in outs)
             and min(os.path.getmtime(o) for o in outs) >= _newest_src()):
         return OUT
@@ -37,6 +38,11 @@ def build(force=False, verbose=False):
     subprocess.check_call(cmd, cwd=CSRC)
     cmd = [hipcc, "-O2", "-std=c++17", os.path.join(CSRC, "host", "classpro_main.cpp"), "-o", CLI,
            "-L" + _HERE, "-lclasspro_amd", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
+           os.path.join(CSRC, "synth", "synth_gen.hip"), "-o", SYNTH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
