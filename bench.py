@@ -1,19 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric, Mbases/s classified (k=40, 40x HiFi), on N MI355X, one process per GPU.
 
-A "step" is one pass of the whole hot path (cp_classify_batch: candidate scan, find_wall,
-find_rel_intvl, classify_rel, classify_unrel, label paint) over one batch of synthetic reads that is
-already resident in HBM.  Reads shard trivially: every rank classifies its own reads, there is no
-data-path collective (torch.distributed is used for the barrier and the max-over-ranks time only).
+Workload (N=1 default): BASELINE configs[2], a synthetic 200 Mbp diploid genome at 40x HiFi, r=20000: 400 000
+distinct seeded reads, 8.0 Gbases, 16 GB of uint16 count profiles, generated on the device
+(classpro_amd/synth_dev.py) and RESIDENT IN HBM before the timed region.  A "step" is one pass of the whole hot
+path (cp_classify_batch: candidate scan, find_wall, find_rel_intvl, classify_rel, classify_unrel, label paint)
+over the whole resident read set, issued as sub-batches of --batch-mbases (the size that fills the machine).
+
+N > 1 (strong scaling, BASELINE configs[3]'s shape): the SAME read set is sharded over the ranks as contiguous
+read ranges balanced by bases (classpro_amd.shard.plan_shards); every rank generates and classifies only its own
+range; there is no data-path collective (torch.distributed = barrier + max-over-ranks time only).
+`--scaling weak` gives every rank its own full-size set instead.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+`python bench.py --gpus N` without a launcher starts the N ranks itself (before any GPU call).
+Prints ONE JSON line on rank 0 (fields: README / DESIGN.md section 6).
 """
 import argparse
+import hashlib
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,6 +35,7 @@ if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec)
+K = 40
 
 
 def parse():
@@ -31,62 +43,103 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--genome", type=int, default=5_000_000, help="synthetic diploid genome length (MHC-like: 5 Mbp)")
+    ap.add_argument("--genome", type=float, default=200e6, help="synthetic diploid genome length (configs[2]: 200 Mbp)")
     ap.add_argument("--cov", type=int, default=40)
     ap.add_argument("--read-len", type=int, default=20000)
-    ap.add_argument("--tile", type=int, default=1, help="replicate the read set this many times in the batch")
+    ap.add_argument("--batch-mbases", type=float, default=800.0, help="sub-batch size of one cp_classify_batch call")
+    ap.add_argument("--streams", type=int, default=1, help="sub-batches alternate over this many streams / workspaces")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--cpu-sample-reads", type=int, default=1 << 30, help="reads of the batch timed on the CPU (default: all)")
+    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="target CPU time of each cpu_baseline leg (-T1, -T16, -T<all>)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the MHC-like / PCIe / CLI extras (profiling runs)")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with no launcher: start the N ranks here, before anything touches the GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+def scan_kernel_id():
+    """Hash of the scan kernel's source text: a PMC traffic figure is only quoted for the kernel it was measured on."""
+    src = open(os.path.join(_ROOT, "classpro_amd", "csrc", "kernels.hip")).read()
+    m = re.search(r"typedef unsigned cp_u4v.*?\n// -{20,}\n//  Candidate count per read", src, re.S)
+    return hashlib.sha1((m.group(0) if m else src).encode()).hexdigest()[:12]
 
 
 def main():
     a = parse()
-    import torch
-    import torch.distributed as dist
-    from classpro_amd import synth
-    from classpro_amd.api import Classifier, Batch, hist_covs
-    from classpro_amd._lib import lib, check
-    import ctypes as C
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(os.environ.get("WORLD_SIZE", "0"))
+    if world == 0:
+        if a.gpus > 1:
+            self_launch(a)
+        world = 1
+    if world != a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (a.gpus, world))
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    import torch.distributed as dist
+    import ctypes as C
+    from classpro_amd.synth_dev import DeviceSynth
+    from classpro_amd.api import Classifier, Batch, hist_covs
+    from classpro_amd.shard import plan_shards
+    from classpro_amd._lib import lib, check
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-
-    # ---- synthetic workload (weak scaling: every rank gets its own read set of the same size) ----
-    t0 = time.time()
-    ds = synth.make_dataset(genome_len=a.genome, cov=a.cov, read_len=a.read_len, K=40, het=0.001,
-                            n_repeats=max(3, a.genome // 80000), min_len=3000, seed=a.seed + rank)
-    seq, seq_off, prof, prof_off = synth.pack_batch(ds["seqs"], ds["profiles"])
-    low, high, il, ih, h = ds["hist"]
-    hcov, dcov = hist_covs(h, low, high, il, ih, 0)
-    if a.tile > 1:
-        n = len(seq_off) - 1
-        seq_off = np.concatenate([[0], np.cumsum(np.tile(np.diff(seq_off), a.tile))]).astype(np.int64)
-        prof_off = np.concatenate([[0], np.cumsum(np.tile(np.diff(prof_off), a.tile))]).astype(np.int64)
-        seq = np.tile(seq, a.tile)
-        prof = np.tile(prof, a.tile)
-    t_gen = time.time() - t0
-
-    clf = Classifier(K=40, read_len=a.read_len, hcov=hcov, dcov=dcov, device=str(dev))
-    t0 = time.time()
-    b = Batch(seq, seq_off, prof, prof_off, device=str(dev))
-    torch.cuda.synchronize()
-    t_h2d = time.time() - t0
     L = lib()
-    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    # ---- synthetic workload, generated in HBM -------------------------------------------------------------
+    t0 = time.time()
+    G = int(a.genome)
+    seed = a.seed + (rank if a.scaling == "weak" else 0)
+    ds = DeviceSynth(genome_len=G, cov=a.cov, read_len=a.read_len, K=K, seed=seed, device=str(dev))
+    low, high, il, ih, h = ds.hist
+    hcov, dcov = hist_covs(h, low, high, il, ih, 0)
+    if a.scaling == "strong":
+        bounds = plan_shards(ds.seq_off_all, world)
+        first, last = bounds[rank], bounds[rank + 1]
+    else:
+        first, last = 0, ds.n_reads
+    plan = ds.plan_batches(int(a.batch_mbases * 1e6), first, last)
+    batches = []
+    for i, (r0, n) in enumerate(plan):
+        rd = ds.reads(r0, n, truth=(i == 0 and rank == 0))
+        batches.append((rd, Batch.from_device(rd)))
+    torch.cuda.synchronize()
+    ds.check()
+    t_gen = time.time() - t0
+    my_bases = sum(b.total_bases for _, b in batches)
+    my_kmers = sum(b.total_kmers for _, b in batches)
+
+    clf = Classifier(K=K, read_len=a.read_len, hcov=hcov, dcov=dcov, device=str(dev))
+    nst = max(1, a.streams)
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nst - 1)]
+    wss = [clf.ws]
+    for _ in range(nst - 1):
+        w = C.c_void_p()
+        check(L.cp_workspace_create(C.byref(w)))
+        wss.append(w)
 
     def step():
-        check(L.cp_classify_batch(clf.p, clf.ws, b.seq.data_ptr(), b.seq_off.data_ptr(), b.prof.data_ptr(),
-                                  b.prof_off.data_ptr(), b.nreads, b.total_bases, b.total_kmers,
-                                  b.labels.data_ptr(), stream))
+        for i, (_, b) in enumerate(batches):
+            k = i % nst
+            check(L.cp_classify_batch(clf.p, wss[k], b.seq.data_ptr(), b.seq_off.data_ptr(), b.prof.data_ptr(),
+                                      b.prof_off.data_ptr(), b.nreads, b.total_bases, b.total_kmers,
+                                      b.labels.data_ptr(), C.c_void_p(streams[k].cuda_stream)))
 
     def barrier():
         if world > 1:
@@ -101,141 +154,207 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    clf.check()
+    for w in wss:
+        check(L.cp_workspace_check(w))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        nb = torch.tensor([b.total_bases], dtype=torch.int64, device=dev)
+        nb = torch.tensor([my_bases], dtype=torch.int64, device=dev)
         dist.all_reduce(nb, op=dist.ReduceOp.SUM)
         total_bases_all = int(nb.item())
     else:
-        total_bases_all = b.total_bases
+        total_bases_all = my_bases
     value = total_bases_all * a.steps / dt / 1e6
 
-    out = None
     if rank == 0:
-        # ---- roofline of the profile-scan kernel: HIP events on the launch stream ----------------
-        nw = b.total_kmers // 64 + 2
-        bm = torch.zeros(nw, dtype=torch.int64, device=dev)
-        iters = 200                                     # ~16 ms of back-to-back launches: a stable average
-        for _ in range(10):
-            check(L.cp_scan_candidates(clf.p, b.prof.data_ptr(), b.total_kmers, bm.data_ptr(), stream))
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        # ---- roofline of the profile-scan kernel: HIP events on the launch stream; every launch streams one
+        #      sub-batch's profile (1.6 GB at the default size), the whole resident set (16 GB >> the 256 MiB
+        #      Infinity Cache) in rotation ----------------------------------------------------------------------
+        bms = [torch.zeros(b.total_kmers // 64 + 2, dtype=torch.int64, device=dev) for _, b in batches]
+        reps = max(1, 200 // len(batches))
+
+        def scan_all():
+            for (_, b), bm in zip(batches, bms):
+                check(L.cp_scan_candidates(clf.p, b.prof.data_ptr(), b.total_kmers, bm.data_ptr(), stream))
+        scan_all()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(dev))
-        for _ in range(iters):
-            check(L.cp_scan_candidates(clf.p, b.prof.data_ptr(), b.total_kmers, bm.data_ptr(), stream))
+        for _ in range(reps):
+            scan_all()
         e1.record(torch.cuda.current_stream(dev))
         torch.cuda.synchronize()
-        scan_ms = e0.elapsed_time(e1) / iters          # back-to-back launches on the stream the kernel runs on
-        alg_bytes = 2.0 * b.total_kmers                 # 2 B (uint16 count) per position
+        nlaunch = reps * len(batches)
+        scan_ms = e0.elapsed_time(e1) / nlaunch
+        alg_bytes = 2.0 * my_kmers / len(batches)       # 2 B (uint16 count) per position; average launch
         achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
-        traffic = None
+        del bms
+        traffic, traffic_src = None, None
         pmc = os.path.join(_ROOT, "profiles", "scan_pmc.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                traffic = j["hbm_bytes_per_position"] * b.total_kmers
+                # quoted only for the kernel and launch size it was measured on (rocprofv3 --pmc pass of this command)
+                if j.get("kernel_id") == scan_kernel_id() and abs(j["positions_per_launch"] - alg_bytes / 2) < 0.02 * alg_bytes / 2:
+                    traffic = j["hbm_bytes_per_position"] * alg_bytes / 2
+                    traffic_src = j.get("source")
             except Exception:
                 traffic = None
         roof = {"kernel": "k_scan_candidates", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "ms_per_launch": round(scan_ms, 4), "algorithmic_bytes_per_launch": alg_bytes}
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "ms_per_launch": round(scan_ms, 4), "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": nlaunch,
+                "working_set_bytes": 2.0 * my_kmers}
 
-        # ---- PCIe-inclusive rate (never `value`): H2D of inputs + step + D2H of labels -------------
-        t0 = time.perf_counter()
-        b2 = Batch(seq, seq_off, prof, prof_off, device=str(dev))
-        lab = clf.classify(b2)
-        t_e2e = time.perf_counter() - t0
-        del b2
-        # the drop-in's own transfer pattern: pinned bases + FASTK code strings in, decode on the device
-        # (cp_decode_profiles), classify, pinned labels out
-        from classpro_amd.api import encode_profiles
-        prs = ds["profiles"] * a.tile
-        codes, code_off = encode_profiles(prs)
-        h_seq = torch.from_numpy(seq).pin_memory()
-        h_code = torch.from_numpy(codes).pin_memory()
-        h_lab = torch.empty(b.total_bases, dtype=torch.uint8).pin_memory()
-        d_coff = torch.from_numpy(code_off).to(dev)
-        d_prof = torch.empty_like(b.prof)
-        torch.cuda.synchronize()
-        t_codes = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            d_seq = h_seq.to(dev, non_blocking=True)
-            d_code = h_code.to(dev, non_blocking=True)
-            check(L.cp_decode_profiles(clf.ws, d_code.data_ptr(), d_coff.data_ptr(), b.prof_off.data_ptr(), b.nreads,
-                                       d_prof.data_ptr(), stream))
-            check(L.cp_classify_batch(clf.p, clf.ws, d_seq.data_ptr(), b.seq_off.data_ptr(), d_prof.data_ptr(),
-                                      b.prof_off.data_ptr(), b.nreads, b.total_bases, b.total_kmers,
-                                      b.labels.data_ptr(), stream))
-            h_lab.copy_(b.labels[:b.total_bases], non_blocking=True)
-            torch.cuda.synchronize()
-            t_codes.append(time.perf_counter() - t0)
-        clf.check()
-        decode_ok = bool(torch.equal(d_prof[:b.total_kmers], b.prof[:b.total_kmers])) and \
-            bool(np.array_equal(h_lab.numpy(), lab))
-        e0.record(torch.cuda.current_stream(dev))
-        for _ in range(10):
-            check(L.cp_decode_profiles(clf.ws, d_code.data_ptr(), d_coff.data_ptr(), b.prof_off.data_ptr(), b.nreads,
-                                       d_prof.data_ptr(), stream))
-        e1.record(torch.cuda.current_stream(dev))
-        torch.cuda.synchronize()
-        decode_ms = e0.elapsed_time(e1) / 10
+        rd0, b0 = batches[0]
+        extras = {"whole_step_algorithmic_gb_per_s": round((2.0 * my_kmers + 2.0 * my_bases) * world / (dt / a.steps) / 1e9, 1),
+                  "gen_seconds": round(t_gen, 2), "sub_batches_per_rank": len(batches), "streams": nst,
+                  "workspace_gb": round(sum(int(L.cp_workspace_bytes(w)) for w in wss) / 1e9, 2),
+                  "synth_err_kmer_fraction": round(ds.n_err_kmers / max(1, ds.total_bases), 4)}
 
-        # ---- accuracy against the generator's ground truth (prof2class.c:210-229 mapping of the genomic
-        #      multiplicity of every k-mer: 0 E, 1 H, 2 D, >=3 R); what class2acc reports as "Accuracy" ----
-        tmap = np.full(32768, ord("R"), np.uint8)
+        # ---- accuracy against the generator's ground truth (prof2class.c:210-229: multiplicity 0 E, 1 H, 2 D, >=3 R) ----
+        tmap = torch.full((256,), ord("R"), dtype=torch.uint8, device=dev)
         tmap[0], tmap[1], tmap[2] = ord("E"), ord("H"), ord("D")
-        rel = np.concatenate(ds["rel_profiles"] * a.tile)
-        kpos = np.ones(b.total_bases, bool)
-        for k in range(39):
-            kpos[seq_off[:-1] + k] = False
-        est = lab[kpos]
-        acc = float((est == tmap[rel]).mean()) if len(rel) == len(est) else None
+        kpos = torch.ones(b0.total_bases, dtype=torch.bool, device=dev)
+        for k in range(K - 1):
+            kpos[b0.seq_off[:-1] + k] = False
+        extras["accuracy_vs_synthetic_truth"] = round(float((b0.labels[:b0.total_bases][kpos] == tmap[rd0["truth"].long()]).float().mean()), 5)
+        del kpos
 
-        # ---- CPU baseline: the oracle (a port, pthreads) on a bounded sample of the same workload --
+        # ---- CPU baseline: the oracle (a port, pthreads) on bounded samples of the same workload; every label
+        #      of the samples is also compared with the HIP result --------------------------------------------
         cpu = None
         if not a.no_cpu:
-            from oracle.oracle import Oracle
-            ncpu = min(16, os.cpu_count() or 1)
-            ns = min(a.cpu_sample_reads, len(ds["seqs"]))
-            so, po = seq_off[:ns + 1], prof_off[:ns + 1]
-            O = Oracle(40, a.read_len, hcov, dcov)
-            O.classify_batch(seq[:so[min(64, ns)]], so[:min(64, ns) + 1], prof[:po[min(64, ns)]], po[:min(64, ns) + 1], nthreads=ncpu)
-            t0 = time.perf_counter()
-            want = O.classify_batch(seq[:so[-1]], so, prof[:po[-1]], po, nthreads=ncpu)
-            tc = time.perf_counter() - t0
-            cpu = {"value": round(int(so[-1]) / tc / 1e6, 2), "unit": "Mbases/s", "cores": ncpu, "kind": "port",
-                   "sample": "first %d reads (%d bases) of the same batch, oracle/classpro_oracle.c with %d pthreads" % (ns, int(so[-1]), ncpu),
-                   "seconds": round(tc, 2)}
-            if not a.no_verify:
-                nbad = int((lab[:so[-1]] != want).sum())
-                cpu["label_mismatches_vs_hip"] = nbad
+            cpu = cpu_baseline(a, ds, batches, hcov, dcov)
+        if not a.no_extras:
+            extras.update(extra_rates(a, ds, clf, batches, hcov, dcov, dev, stream))
+
         out = {
             "metric": "Mbases/s classified (k=40, 40x HiFi) at 1/2/4/8 MI355X vs CPU -T16", "value": round(value, 2), "unit": "Mbases/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16/f64",
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "u16/f64",
             "data": "synthetic",
-            "config": {"workload": "MHC-like synthetic diploid %.1f Mbp, %dx HiFi, r=%d, k=40 (BASELINE configs[1]), x%d tile" % (
-                           a.genome / 1e6, a.cov, a.read_len, a.tile),
-                       "reads_per_gpu": b.nreads, "bases_per_gpu": b.total_bases, "hcov": hcov, "dcov": dcov,
-                       "parallelism": "read-sharded x%d, no collective" % world},
-            "roofline": roof, "cpu_baseline": cpu,
-            "extras": {"whole_step_algorithmic_gb_per_s": round((2.0 * b.total_kmers + 2.0 * b.total_bases) / (dt / a.steps) / 1e9, 1),
-                       "pcie_inclusive_mbases_per_s": round(b.total_bases / t_e2e / 1e6, 2),
-                       "pcie_inclusive_pinned_codes_mbases_per_s": round(b.total_bases / min(t_codes) / 1e6, 2),
-                       "accuracy_vs_synthetic_truth": None if acc is None else round(acc, 5),
-                       "code_bytes_per_base": round(len(codes) / b.total_bases, 4),
-                       "decode_ms": round(decode_ms, 3), "decode_matches": decode_ok,
-                       "h2d_seconds": round(t_h2d, 3), "gen_seconds": round(t_gen, 1),
-                       "workspace_gb": round(clf.workspace_bytes() / 1e9, 2)},
+            "config": {"workload": "synthetic %.0f Mbp diploid, %dx HiFi, r=%d, k=40 (BASELINE configs[2]): %d distinct reads, %.2f Gbases, resident in HBM, "
+                                   "sub-batches of %.0f Mbases" % (G / 1e6, a.cov, a.read_len, ds.n_reads, ds.total_bases / 1e9, a.batch_mbases),
+                       "reads_total": ds.n_reads if a.scaling == "strong" else ds.n_reads * world, "bases_total": total_bases_all,
+                       "reads_rank0": last - first, "bases_rank0": my_bases, "hcov": hcov, "dcov": dcov,
+                       "parallelism": "contiguous read ranges balanced by bases x%d (%s), no collective" % (world, a.scaling)},
+            "roofline": roof, "cpu_baseline": cpu, "extras": extras,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    for w in wss[1:]:
+        L.cp_workspace_destroy(w)
     clf.close()
+
+
+def cpu_baseline(a, ds, batches, hcov, dcov):
+    """-T1, -T16 and -T<all cores> of the CPU port (oracle/classpro_oracle.c), each on about --cpu-seconds of work."""
+    from oracle.oracle import Oracle
+    O = Oracle(K, a.read_len, hcov, dcov)
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    rd0, b0 = batches[0]
+    so_all, po_all = rd0["seq_off_h"], rd0["prof_off_h"]
+
+    def host_sample(rd, b, nreads):
+        so, po = rd["seq_off_h"][:nreads + 1], rd["prof_off_h"][:nreads + 1]
+        return (rd["seq"][:so[-1]].cpu().numpy(), so, rd["prof"][:po[-1]].cpu().numpy().view(np.uint16), po,
+                b.labels[:so[-1]].cpu().numpy())
+
+    def run(sample, nt):
+        seq, so, prof, po, lab = sample
+        t0 = time.perf_counter()
+        want = O.classify_batch(seq, so, prof, po, nthreads=nt)
+        tc = time.perf_counter() - t0
+        return int(so[-1]) / tc / 1e6, tc, int((lab != want).sum()), int(so[-1])
+
+    # calibrate on 64 reads, then size each leg for ~cpu_seconds
+    cal = host_sample(rd0, b0, min(64, b0.nreads))
+    r1, _, _, _ = run(cal, 1)
+    legs = {}
+    mism = 0
+    for name, nt in (("T1", 1), ("T16", min(16, ncores)), ("Tall", ncores)):
+        if name == "Tall" and nt == min(16, ncores):
+            legs[name] = dict(legs["T16"], threads=nt)
+            continue
+        want_bases = r1 * 1e6 * a.cpu_seconds * nt * 0.8
+        parts, got = [], 0
+        for rd, b in batches:
+            if got >= want_bases:
+                break
+            n = int(np.searchsorted(rd["seq_off_h"], min(want_bases - got, rd["seq_off_h"][-1]), side="left"))
+            n = min(max(n, 1), b.nreads)
+            parts.append(host_sample(rd, b, n))
+            got += int(rd["seq_off_h"][n])
+        rate_b, secs, bad = 0, 0.0, 0
+        for s in parts:
+            _, tc, nb, nbases = run(s, nt)
+            rate_b += nbases
+            secs += tc
+            bad += nb
+        legs[name] = {"mbases_per_s": round(rate_b / secs / 1e6, 2), "threads": nt, "seconds": round(secs, 2), "bases": rate_b,
+                      "label_mismatches_vs_hip": bad}
+        mism += bad
+    t16 = legs["T16"]
+    return {"value": t16["mbases_per_s"], "unit": "Mbases/s", "cores": t16["threads"], "kind": "port",
+            "sample": "first %d bases of the same resident read set (%.1f s of CPU work), oracle/classpro_oracle.c with %d pthreads; "
+                      "the reference itself cannot be linked here (wall.c needs GSL)" % (t16["bases"], t16["seconds"], t16["threads"]),
+            "seconds": t16["seconds"], "label_mismatches_vs_hip": mism, "legs": legs, "host_cores": ncores}
+
+
+def extra_rates(a, ds, clf, batches, hcov, dcov, dev, stream):
+    """Reported beside `value`, never as `value`: the MHC-like configs[1] batch, the PCIe-inclusive rate of the
+    drop-in's own transfer pattern, and the drop-in binary end to end on files in tmpfs."""
+    import torch
+    import ctypes as C
+    from classpro_amd.synth_dev import DeviceSynth
+    from classpro_amd.api import Batch, encode_profiles
+    from classpro_amd._lib import lib, check
+    L = lib()
+    ex = {}
+    # MHC-like set (BASELINE configs[1] stand-in): 5 Mbp x 40x = 10 000 reads, 200 Mbases, ONE batch per step
+    m = DeviceSynth(genome_len=5_000_000, cov=a.cov, read_len=a.read_len, K=K, seed=a.seed, device=str(dev))
+    rdm = m.reads(0, m.n_reads)
+    bm = Batch.from_device(rdm)
+    for _ in range(3):
+        clf.run(bm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        clf.run(bm)
+    torch.cuda.synchronize()
+    ex["mhc_like_200mbase_batch_mbases_per_s"] = round(bm.total_bases * 20 / (time.perf_counter() - t0) / 1e6, 1)
+    clf.check()
+
+    # PCIe-inclusive, the drop-in's own transfer pattern on the MHC-like batch: pinned bases + FASTK code strings
+    # in, cp_decode_profiles, classify, pinned labels out (un-overlapped)
+    hm = m.to_host(rdm, names=False)
+    codes, code_off = encode_profiles(hm["profiles"])
+    h_seq = torch.from_numpy(np.frombuffer(b"".join(hm["seqs"]), np.uint8).copy()).pin_memory()
+    h_code = torch.from_numpy(codes).pin_memory()
+    h_lab = torch.empty(bm.total_bases, dtype=torch.uint8).pin_memory()
+    d_coff = torch.from_numpy(code_off).to(dev)
+    d_prof = torch.empty_like(bm.prof)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        d_seq = h_seq.to(dev, non_blocking=True)
+        d_code = h_code.to(dev, non_blocking=True)
+        check(L.cp_decode_profiles(clf.ws, d_code.data_ptr(), d_coff.data_ptr(), bm.prof_off.data_ptr(), bm.nreads,
+                                   d_prof.data_ptr(), stream))
+        check(L.cp_classify_batch(clf.p, clf.ws, d_seq.data_ptr(), bm.seq_off.data_ptr(), d_prof.data_ptr(),
+                                  bm.prof_off.data_ptr(), bm.nreads, bm.total_bases, bm.total_kmers, bm.labels.data_ptr(), stream))
+        h_lab.copy_(bm.labels[:bm.total_bases], non_blocking=True)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    clf.check()
+    ex["pcie_inclusive_pinned_codes_mbases_per_s"] = round(bm.total_bases / min(ts) / 1e6, 1)
+    ex["code_bytes_per_base"] = round(len(codes) / bm.total_bases, 4)
+    ex["decode_matches"] = bool(torch.equal(d_prof[:bm.total_kmers], bm.prof[:bm.total_kmers]))
+    return ex
 
 
 if __name__ == "__main__":
