@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--cov", type=int, default=40)
     ap.add_argument("--read-len", type=int, default=20000)
     ap.add_argument("--batch-mbases", type=float, default=800.0, help="sub-batch size of one cp_classify_batch call")
-    ap.add_argument("--streams", type=int, default=1, help="sub-batches alternate over this many streams / workspaces")
+    ap.add_argument("--streams", type=int, default=2, help="sub-batches alternate over this many streams / workspaces")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="target CPU time of each cpu_baseline leg (-T1, -T16, -T<all>)")
@@ -354,6 +354,44 @@ def extra_rates(a, ds, clf, batches, hcov, dcov, dev, stream):
     ex["pcie_inclusive_pinned_codes_mbases_per_s"] = round(bm.total_bases / min(ts) / 1e6, 1)
     ex["code_bytes_per_base"] = round(len(codes) / bm.total_bases, 4)
     ex["decode_matches"] = bool(torch.equal(d_prof[:bm.total_kmers], bm.prof[:bm.total_kmers]))
+    del m, rdm, bm, d_prof, h_seq, h_code, h_lab
+
+    # the drop-in binary end to end: FASTA + FASTK files of the first ~1.6 Gbases of the resident set written to
+    # tmpfs, `ClassPro -T16` from process start to exit, .class (2 B/base) written next to them
+    try:
+        import shutil
+        import tempfile
+        sys.path.insert(0, os.path.join(_ROOT, "scripts"))
+        import cli_e2e
+        parts, got = [], 0
+        for rd, b in batches:
+            if got >= 1.6e9:
+                break
+            parts.append((rd, b))
+            got += b.total_bases
+        seq = np.concatenate([rd["seq"][:b.total_bases].cpu().numpy() for rd, b in parts])
+        prof = np.concatenate([rd["prof"][:b.total_kmers].cpu().numpy().view(np.uint16) for rd, b in parts])
+        lens = np.concatenate([np.diff(rd["seq_off_h"]) for rd, b in parts])
+        so = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        d = tempfile.mkdtemp(prefix="cp_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        try:
+            path = cli_e2e.write_inputs(d, (seq, prof), so, ds.hist)
+            dt, lines = cli_e2e.run_cli(path, 16, reps=1)
+            ex["cli_end_to_end_mbases_per_s"] = round(int(so[-1]) / dt / 1e6, 1)
+            ex["cli_end_to_end"] = {"bases": int(so[-1]), "seconds_process_wall": round(dt, 3), "threads": 16,
+                                    "files": "plain FASTA + FASTK in, .class out, all on tmpfs", "phase_lines": lines}
+            # the binary's labels == the resident run's labels (first 2000 records)
+            lab = np.concatenate([b.labels[:b.total_bases].cpu().numpy() for rd, b in parts])
+            ok, k = True, 0
+            with open(os.path.join(d, "reads.class"), "rb") as f:
+                for i in range(2000):
+                    f.readline(); f.readline(); f.readline()
+                    ok &= f.readline()[:-1] == lab[so[i]:so[i + 1]].tobytes()
+            ex["cli_labels_match_resident_run"] = bool(ok)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    except Exception as e:                                  # the extras never take the bench line down
+        ex["cli_end_to_end_error"] = repr(e)[:200]
     return ex
 
 

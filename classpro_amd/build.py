@@ -36,7 +36,7 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
-    cmd = [hipcc, "-O2", "-std=c++17", os.path.join(CSRC, "host", "classpro_main.cpp"), "-o", CLI,
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", os.path.join(CSRC, "host", "classpro_main.cpp"), "-o", CLI,
            "-L" + _HERE, "-lclasspro_amd", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))

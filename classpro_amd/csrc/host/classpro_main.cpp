@@ -5,22 +5,31 @@
 //            [-M<model_path>] <source>[.db|.dam|.f[ast][aq][.gz]]
 // inputs  <fk_root>.hist, <fk_root>.prof, <dir>/.<root>.pidx.N, <dir>/.<root>.prof.N   (FASTK)
 // output  <dir>/<root>.class : "@name comment\nseq\n+\nlabels\n" per read              (ClassPro.c:289)
+//         for a Dazzler database also the tracks .<root>.class.anno/.data (and .<root>.rep.*)
 //
-// The reference's pthread-per-read-range loop is replaced by read batches: the host parses FASTX
-// (kseq semantics) and FASTK profile code strings into pinned staging buffers (decoded on the device by
-// cp_decode_profiles), copies
-// them with hipMemcpyAsync, calls cp_classify_batch, and writes the records in input order.  While
-// the GPU works on one batch the host stages the next one.
-//
-// Sources: FASTX (kseq semantics) or a Dazzler .db/.dam (dazz_db.h); for a database the labels are also
-// written as the DAZZ_DB track .<root>.class.anno/.data (and the header-only .<root>.rep.* mask track).
+// The reference's parallel structure -- T pthreads over contiguous read ranges, one input handle per thread,
+// per-thread temp files concatenated in order by merge_files (ClassPro.c:530,558-614; io.c:70-112) -- becomes:
+//   * ONE input sharded over all visible devices (CLASSPRO_DEVICES=0,1,.. or =0,0 to put two shards on one
+//     GPU): the input text is taken in windows; a window's reads are split into one contiguous range per device,
+//     balanced by bases; a range goes through its device in batches of up to 256 Mbases;
+//   * per device one feeder thread (hipSetDevice, its own cp_params, three batch slots = stream + cp_workspace +
+//     pinned and device buffers) and one completion thread;
+//   * -T host threads (a pool) do every data-parallel host loop: indexing the input text (fastx_index.h: plain
+//     FASTA in parallel chunks, FASTQ by one thread, .gz inflated by one thread = the .gz ceiling), staging copies
+//     into pinned memory, formatting the records;
+//   * no temp files and no merge pass: the size of every record is known once its window is indexed, so a batch's
+//     records are formatted by the pool into a memory buffer and one writer thread puts the buffer at its final
+//     offset of <root>.class (pwrite) -- the ordered concatenation merge_files produces, without the second copy.
+// FASTK profile code strings are shipped as stored (0.27 B/base) and decoded on the device (cp_decode_profiles);
+// database bases are shipped 2-bit packed (cp_unpack_bases).
 // Not supported yet: -s (seed selection, seed.c; exits with a message).
-// -T is accepted for compatibility; the device does the work, -T only sizes nothing here.
 #include <hip/hip_runtime.h>
 #include <zlib.h>
 #include <dirent.h>
 #include <fcntl.h>
 #include <unistd.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <strings.h>
 #include <cstdio>
 #include <cstdarg>
@@ -29,13 +38,18 @@
 #include <cstdint>
 #include <string>
 #include <vector>
+#include <deque>
 #include <chrono>
 #include <thread>
 #include <mutex>
+#include <atomic>
+#include <memory>
 #include <condition_variable>
 #include "../../../include/classpro_amd.h"
 #include "host_io.h"
 #include "dazz_db.h"
+#include "thread_pool.h"
+#include "fastx_index.h"
 
 static const char *USAGE = "[-vs] [-T<int(4)>] [-c<int>] [-r<int(20000)>] "
                            "[-P<tmp_dir(./)>] [-N<fastk_root>] [-M<model_path>] "
@@ -46,26 +60,126 @@ static const char *EXT[10] = { ".db", ".dam", ".fastq", ".fasta", ".fq", ".fa",
 #define HIPOK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) die("%s: %s: %s\n",PROG,#call,hipGetErrorString(e_)); } while (0)
 #define CPOK(call)  do { if ((call) < 0) die("%s\n",cp_last_error()); } while (0)
 
-// ---- one batch in flight ----------------------------------------------------------------------------
-struct Batch
-  { char *h_seq = nullptr, *h_lab = nullptr; uint8_t *h_code = nullptr;
+typedef std::chrono::steady_clock::time_point tp_t;
+static tp_t now() { return std::chrono::steady_clock::now(); }
+static double secs(tp_t a, tp_t b) { return std::chrono::duration<double>(b-a).count(); }
+
+// ---- read-only memory map of a file --------------------------------------------------------------------
+struct MapFile
+  { const char *p = nullptr; size_t len = 0; int fd = -1;
+    bool open(const std::string &path)
+    { fd = ::open(path.c_str(),O_RDONLY);
+      if (fd < 0) return false;
+      struct stat st;
+      if (fstat(fd,&st) != 0) return false;
+      len = (size_t)st.st_size;
+      if (len > 0)
+        { void *m = mmap(nullptr,len,PROT_READ,MAP_PRIVATE,fd,0);
+          if (m == MAP_FAILED) return false;
+          p = (const char *)m;
+          madvise(m,len,MADV_SEQUENTIAL);
+        }
+      return true;
+    }
+    ~MapFile() { if (p) munmap((void *)p,len); if (fd >= 0) close(fd); }
+  };
+
+// ---- FASTK profile index over memory-mapped parts (libfastk.c:1267-1370, 1414-1465) ----------------------
+struct ProfileMap
+  { int kmer = 0, nparts = 0;
+    int64_t nreads = 0;
+    std::vector<int64_t> index;         // end offset of read i inside its part
+    std::vector<int64_t> nbase;         // reads before the end of part p
+    std::vector<std::unique_ptr<MapFile>> part;
+    bool open(const std::string &fk_root)
+    { std::string dir = path_to(fk_root), root = root_of(fk_root,".prof");
+      FILE *f = fopen((dir+"/"+root+".prof").c_str(),"rb");
+      if (!f) return false;
+      int smer, nthreads;
+      if (fread(&smer,4,1,f) != 1 || fread(&nthreads,4,1,f) != 1) { fclose(f); return false; }
+      fclose(f);
+      const std::string prefix = dir+"/."+root+".";
+      for (int p = 0; p < nthreads; p++)
+        { std::string nm = prefix+"pidx."+std::to_string(p+1);
+          FILE *g = fopen(nm.c_str(),"rb");
+          if (!g) die("Profile part %s is misssing ?\n",nm.c_str());
+          int k; int64_t first, n;
+          if (fread(&k,4,1,g) != 1 || fread(&first,8,1,g) != 1 || fread(&n,8,1,g) != 1) die("Profile part %s is truncated\n",nm.c_str());
+          if (k != smer) die("Profile part %s does not have k-mer length matching stub ?\n",nm.c_str());
+          size_t o = index.size();
+          index.resize(o+(size_t)n);
+          if (n > 0 && fread(index.data()+o,8,(size_t)n,g) != (size_t)n) die("Profile part %s is truncated\n",nm.c_str());
+          fclose(g);
+          nreads += n;
+          nbase.push_back(nreads);
+          part.emplace_back(new MapFile());
+          nm = prefix+"prof."+std::to_string(p+1);
+          if (!part.back()->open(nm)) die("Profile part %s is misssing ?\n",nm.c_str());
+        }
+      kmer = smer; nparts = nthreads;
+      return true;
+    }
+    int part_of(int64_t id) const { int w = 0; while (w < nparts && id >= nbase[w]) w++; return w; }
+    int64_t code_len(int64_t id) const
+    { if (id >= nreads) return 0;
+      const int w = part_of(id);
+      const int64_t first = (w == 0) ? 0 : nbase[w-1];
+      return index[(size_t)id]-((id == first) ? 0 : index[(size_t)id-1]);
+    }
+    // code string of read `id` whose part is w (w = part_of(id))
+    void fetch(int64_t id, int w, const uint8_t **code, int64_t *len) const
+    { const int64_t first = (w == 0) ? 0 : nbase[w-1];
+      const int64_t off = (id == first) ? 0 : index[(size_t)id-1];
+      const int64_t end = index[(size_t)id];
+      if (end < off || (size_t)end > part[w]->len) die("Profile part %d is truncated\n",w+1);
+      *code = (const uint8_t *)part[w]->p+off;
+      *len = end-off;
+    }
+  };
+
+// ---- blocking queue ---------------------------------------------------------------------------------------
+template <class T> struct Chan
+  { std::deque<T> q; std::mutex m; std::condition_variable cv; bool closed = false;
+    void push(T v) { { std::lock_guard<std::mutex> lk(m); q.push_back(std::move(v)); } cv.notify_one(); }
+    void close() { { std::lock_guard<std::mutex> lk(m); closed = true; } cv.notify_all(); }
+    bool pop(T &v)
+    { std::unique_lock<std::mutex> lk(m);
+      cv.wait(lk,[&] { return closed || !q.empty(); });
+      if (q.empty()) return false;
+      v = std::move(q.front()); q.pop_front();
+      return true;
+    }
+  };
+
+// ---- a window of the input: text + records, alive until its last batch has been written --------------------
+struct Window
+  { std::vector<char> owned;                   // .gz: inflated text
+    std::vector<FxRec> recs;                   // FASTX: parsed records; DB: name = header, seq = packed bases
+    std::deque<std::string> keep;              // inherited comment / database headers
+    int64_t first_id = 0;                      // input index of recs[0]
+    std::vector<int64_t> out_off;              // offset of every record in <root>.class (+ end)
+    std::vector<int64_t> trk_off;              // database: offset of every read in .class.data (+ end)
+  };
+
+struct BatchJob { std::shared_ptr<Window> w; size_t r0, r1; };
+
+// ---- one batch slot of a device ------------------------------------------------------------------------------
+struct Slot
+  { char *h_seq = nullptr, *h_lab = nullptr; uint8_t *h_code = nullptr, *h_pack = nullptr;
     int64_t *h_soff = nullptr, *h_poff = nullptr, *h_coff = nullptr, *h_boff = nullptr;
-    uint8_t *h_pack = nullptr, *d_pack = nullptr;    // database inputs: 2-bit bases as stored in the .bps file
-    int64_t *d_boff = nullptr; int64_t packed = 0;
-    char *d_seq = nullptr, *d_lab = nullptr; uint8_t *d_code = nullptr; uint16_t *d_prof = nullptr;
-    int64_t *d_soff = nullptr, *d_poff = nullptr, *d_coff = nullptr;
+    char *d_seq = nullptr, *d_lab = nullptr; uint8_t *d_code = nullptr, *d_pack = nullptr; uint16_t *d_prof = nullptr;
+    int64_t *d_soff = nullptr, *d_poff = nullptr, *d_coff = nullptr, *d_boff = nullptr;
     size_t cap_bases = 0, cap_reads = 0, cap_code = 0;
-    int n = 0; int64_t bases = 0, kmers = 0, codes = 0;
-    std::vector<int64_t> read_id;                // classified read -> 0-based input index (for messages)
-    std::vector<std::string> headers;            // every record of the batch, in order (short reads included)
-    std::vector<int> slot;                       // record -> index among classified reads, or -1 (short read)
-    std::vector<std::string> short_seq;
     hipStream_t st = nullptr;
     cp_workspace *ws = nullptr;
+    // the batch in the slot
+    BatchJob job;
+    int n = 0; int64_t bases = 0, kmers = 0, codes = 0, packed = 0;
+    std::vector<int32_t> slot_of;              // record (relative to r0) -> index among classified reads, -1 = short read
+    std::vector<uint32_t> rec_of;              // classified read -> record (relative to r0)
     void alloc(size_t bases_cap, size_t reads_cap, bool with_pack)
-    { cap_bases = bases_cap; cap_reads = reads_cap;
+    { cap_bases = bases_cap; cap_reads = reads_cap; cap_code = bases_cap;
       HIPOK(hipHostMalloc((void **)&h_seq,bases_cap)); HIPOK(hipHostMalloc((void **)&h_lab,bases_cap));
-      cap_code = bases_cap;                      // FASTK codes run ~0.1-0.3 B/base on HiFi data; a batch closes early if they fill up
       HIPOK(hipHostMalloc((void **)&h_code,cap_code));
       HIPOK(hipHostMalloc((void **)&h_soff,(reads_cap+1)*8)); HIPOK(hipHostMalloc((void **)&h_poff,(reads_cap+1)*8));
       HIPOK(hipHostMalloc((void **)&h_coff,(reads_cap+1)*8));
@@ -80,11 +194,265 @@ struct Batch
       HIPOK(hipStreamCreate(&st));
       CPOK(cp_workspace_create(&ws));
     }
-    void reset() { n = 0; bases = kmers = codes = packed = 0; headers.clear(); slot.clear(); short_seq.clear(); read_id.clear(); }
+  };
+
+// ---- everything the pipeline threads share -----------------------------------------------------------------
+struct Run
+  { int K = 40, Km1 = 39;
+    bool is_db = false, is_dam = false, verbose = false;
+    int rlen_opt = 20000, hcov = 0, dcov = 0;
+    std::string model_path;
+    ProfileMap P;
+    ThreadPool *pool = nullptr;
+    int out_fd = -1, trk_fd = -1;
+    std::atomic<int64_t> total_bases{0};
+    std::atomic<int64_t> t_stage_us{0}, t_wait_us{0}, t_write_us{0};
+    size_t batch_bases = (size_t)256 << 20, batch_reads = 1 << 17;
+    // Output: records are formatted by the pool into reusable memory buffers and written by ONE thread with large
+    // pwrite calls.  A page-cache / tmpfs file takes fresh pages fastest from a single writer (the inode lock
+    // serialises writers, and first-touch faults of a shared mapping serialise too: scripts/microbench/tmpfs_write.cpp,
+    // profiles/r02_tmpfs_write.txt: 8.1 GB/s from one thread, 3.5-7.4 GB/s from sixteen).
+    struct OutBuf { std::vector<char> text, track; int64_t text_off = 0, track_off = 0; };
+    Chan<OutBuf *> out_free, out_full;
+    // window throttle
+    std::mutex wm; std::condition_variable wcv; int windows_alive = 0;
+  };
+
+static void pwrite_all(int fd, const char *buf, size_t n, int64_t off)
+{ while (n > 0)
+    { ssize_t w = pwrite(fd,buf,n,(off_t)off);
+      if (w <= 0) die("%s: write to the output failed\n",PROG);
+      buf += w; n -= (size_t)w; off += w;
+    }
+}
+
+static inline void unpack_bases(const unsigned char *pk, int len, char *dst)      // DB.c:342-381 (Uncompress_Read + Upper_Read)
+{ static const char letter[4] = { 'A', 'C', 'G', 'T' };
+  for (int k = 0; k < len; k++)
+    dst[k] = letter[(pk[k >> 2] >> (6-2*(k & 3))) & 3];
+}
+
+// ---- a device: feeder (stage + submit) and completion (wait + format + write) threads ----------------------
+struct Device
+  { Run *R; int dev; int index;
+    static constexpr int NSLOT = 3;
+    Slot slot[NSLOT];
+    cp_params *params = nullptr;
+    Chan<BatchJob> in;
+    Chan<int> inflight, freeslots;
+    std::thread feeder, completer;
+
+    void start(Run *run, int device, int idx)
+    { R = run; dev = device; index = idx;
+      feeder = std::thread([this] { feed(); });
+      completer = std::thread([this] { complete(); });
+    }
+
+    void feed()
+    { HIPOK(hipSetDevice(dev));
+      CPOK(cp_params_create_model(R->K,R->rlen_opt,R->hcov,R->dcov,R->model_path.empty() ? NULL : R->model_path.c_str(),&params));
+      if (index == 0 && R->verbose)                           // ClassPro.c:550, wall.c:169-172, ClassPro.c:572
+        { int c4[4];
+          cp_params_export(params,c4,NULL,NULL,NULL,NULL,NULL,NULL);
+          fprintf(stderr,"    Estimated R-threshold = %d\n",c4[CP_REPEAT]);
+          if (R->model_path.empty())
+            fprintf(stderr,"Error model not specified. Using the default error model.\n");
+          fprintf(stderr,"Classifying %d-mers...\n",R->K);
+        }
+      // the slots (0.8 GB of pinned memory each: the costly part of start-up) come up on a helper thread, one by
+      // one, while the first batches are already moving
+      std::thread allocator([this]
+        { HIPOK(hipSetDevice(dev));
+          for (int k = 0; k < NSLOT; k++)
+            { slot[k].alloc(R->batch_bases+CP_MAX_READ_LEN,R->batch_reads,R->is_db);
+              freeslots.push(k);
+            }
+        });
+      allocator.detach();
+      BatchJob job;
+      while (in.pop(job))
+        { int k;
+          if (!freeslots.pop(k)) break;
+          stage(slot[k],job);
+          submit(slot[k]);
+          inflight.push(k);
+        }
+      inflight.close();
+    }
+
+    // fill the slot's pinned buffers from the window (host threads of the pool)
+    void stage(Slot &s, const BatchJob &job)
+    { const tp_t t0 = now();
+      s.job = job;
+      const Window &w = *job.w;
+      const size_t nrec = job.r1-job.r0;
+      s.slot_of.assign(nrec,-1);
+      s.rec_of.clear();
+      s.n = 0; s.bases = s.kmers = s.codes = s.packed = 0;
+      s.h_soff[0] = s.h_poff[0] = s.h_coff[0] = 0;
+      if (R->is_db) s.h_boff[0] = 0;
+      std::vector<const uint8_t *> csrc;
+      csrc.reserve(nrec);
+      int part = R->P.part_of(w.first_id+(int64_t)job.r0);
+      for (size_t q = 0; q < nrec; q++)
+        { const FxRec &r = w.recs[job.r0+q];
+          const int64_t id = w.first_id+(int64_t)(job.r0+q);
+          if ((int)r.rlen <= R->Km1) continue;                  // ClassPro.c:209-226: printed, not classified
+          while (part < R->P.nparts && id >= R->P.nbase[part]) part++;
+          const uint8_t *code; int64_t clen;
+          R->P.fetch(id,part,&code,&clen);
+          if (clen > 2*(int64_t)r.rlen+2)
+            die("Read %lld: profile code of %lld bytes is longer than any code of a read of %u bases\n",(long long)id+1,(long long)clen,r.rlen);
+          s.slot_of[q] = s.n;
+          s.rec_of.push_back((uint32_t)q);
+          csrc.push_back(code);
+          s.bases += r.rlen; s.kmers += (int64_t)r.rlen-R->Km1; s.codes += clen; s.n++;
+          s.h_soff[s.n] = s.bases; s.h_poff[s.n] = s.kmers; s.h_coff[s.n] = s.codes;
+          if (R->is_db) { s.packed += (r.rlen+3) >> 2; s.h_boff[s.n] = s.packed; }
+        }
+      if ((size_t)s.codes > s.cap_code || (size_t)s.bases > s.cap_bases || (size_t)s.n > s.cap_reads)
+        die("%s: internal error: batch exceeds its slot\n",PROG);
+      const int n = s.n;
+      const int64_t blk = 64;
+      R->pool->parallel_for((n+blk-1)/blk,[&](int64_t t)
+        { const int a = (int)(t*blk), b = (int)std::min<int64_t>(n,(t+1)*blk);
+          for (int i = a; i < b; i++)
+            { const FxRec &r = w.recs[job.r0+s.rec_of[(size_t)i]];
+              memcpy(s.h_code+s.h_coff[i],csrc[(size_t)i],(size_t)(s.h_coff[i+1]-s.h_coff[i]));
+              if (R->is_db)
+                { memcpy(s.h_pack+s.h_boff[i],r.seq,(size_t)(s.h_boff[i+1]-s.h_boff[i]));
+                  unpack_bases((const unsigned char *)r.seq,(int)r.rlen,s.h_seq+s.h_soff[i]);     // for the output record
+                }
+              else
+                r.copy_seq(s.h_seq+s.h_soff[i]);
+            }
+        });
+      R->t_stage_us += (int64_t)(secs(t0,now())*1e6);
+    }
+
+    void submit(Slot &b)
+    { if (b.n == 0) return;
+      if (!R->is_db)
+        HIPOK(hipMemcpyAsync(b.d_seq,b.h_seq,(size_t)b.bases,hipMemcpyHostToDevice,b.st));
+      HIPOK(hipMemcpyAsync(b.d_code,b.h_code,(size_t)b.codes,hipMemcpyHostToDevice,b.st));
+      HIPOK(hipMemcpyAsync(b.d_soff,b.h_soff,(size_t)(b.n+1)*8,hipMemcpyHostToDevice,b.st));
+      HIPOK(hipMemcpyAsync(b.d_poff,b.h_poff,(size_t)(b.n+1)*8,hipMemcpyHostToDevice,b.st));
+      HIPOK(hipMemcpyAsync(b.d_coff,b.h_coff,(size_t)(b.n+1)*8,hipMemcpyHostToDevice,b.st));
+      if (R->is_db)                                               // 2-bit bases in, characters made on the device
+        { HIPOK(hipMemcpyAsync(b.d_pack,b.h_pack,(size_t)b.packed,hipMemcpyHostToDevice,b.st));
+          HIPOK(hipMemcpyAsync(b.d_boff,b.h_boff,(size_t)(b.n+1)*8,hipMemcpyHostToDevice,b.st));
+          CPOK(cp_unpack_bases(b.d_pack,b.d_boff,b.d_soff,b.n,b.d_seq,b.st));
+        }
+      // Fetch_Profile runs on the device: only the code string crosses PCIe.  plen is taken from rlen; the
+      // reference's rlen != plen+Km1 check (ClassPro.c:234) is made by the decode kernel (see complete()).
+      CPOK(cp_decode_profiles(b.ws,b.d_code,b.d_coff,b.d_poff,b.n,b.d_prof,b.st));
+      CPOK(cp_classify_batch(params,b.ws,b.d_seq,b.d_soff,b.d_prof,b.d_poff,b.n,b.bases,b.kmers,b.d_lab,b.st));
+      HIPOK(hipMemcpyAsync(b.h_lab,b.d_lab,(size_t)b.bases,hipMemcpyDeviceToHost,b.st));
+    }
+
+    void complete()
+    { HIPOK(hipSetDevice(dev));
+      int k;
+      while (inflight.pop(k))
+        { Slot &b = slot[k];
+          const tp_t t0 = now();
+          if (b.n > 0)
+            { HIPOK(hipStreamSynchronize(b.st));
+              if (cp_workspace_check(b.ws) != CP_OK)
+                { // a failed decode: find the read on the host so the message is the reference's (ClassPro.c:234-237)
+                  std::vector<uint16_t> tmp(CP_MAX_READ_LEN);
+                  for (int i = 0; i < b.n; i++)
+                    { int rlen = (int)(b.h_soff[i+1]-b.h_soff[i]);
+                      int plen = cp_decode_profile(b.h_code+b.h_coff[i],b.h_coff[i+1]-b.h_coff[i],tmp.data(),CP_MAX_READ_LEN);
+                      if (plen >= 0 && rlen != plen+R->Km1)
+                        die("Read %lld: rlen (%d) != plen+Km1 (%d)\n",(long long)(b.job.w->first_id+(int64_t)b.job.r0+b.rec_of[(size_t)i])+1,rlen,plen+R->Km1);
+                    }
+                  die("%s\n",cp_last_error());
+                }
+            }
+          const tp_t t1 = now();
+          write_out(b);
+          R->t_wait_us += (int64_t)(secs(t0,t1)*1e6);
+          R->t_write_us += (int64_t)(secs(t1,now())*1e6);
+          R->total_bases += b.bases;
+          b.job.w.reset();
+          freeslots.push(k);
+        }
+    }
+
+    // records of the batch (ClassPro.c:215,289; tracks: ClassPro.c:217-223,290-304) formatted into an output
+    // buffer that the writer thread puts at its final offset
+    void write_out(Slot &b)
+    { const Window &w = *b.job.w;
+      const size_t r0 = b.job.r0, nrec = b.job.r1-r0;
+      Run::OutBuf *ob;
+      if (!R->out_free.pop(ob)) return;
+      ob->text_off = w.out_off[r0];
+      ob->text.resize((size_t)(w.out_off[r0+nrec]-w.out_off[r0]));
+      if (R->is_db)
+        { ob->track_off = w.trk_off[r0];
+          ob->track.resize((size_t)(w.trk_off[r0+nrec]-w.trk_off[r0]));
+        }
+      const int64_t blk = 64;
+      R->pool->parallel_for(((int64_t)nrec+blk-1)/blk,[&](int64_t t)
+        { const size_t a = (size_t)(t*blk), z = std::min(nrec,(size_t)((t+1)*blk));
+          char *o = ob->text.data()+(w.out_off[r0+a]-ob->text_off);
+          for (size_t q = a; q < z; q++)
+            { const FxRec &r = w.recs[r0+q];
+              *o++ = '@';
+              memcpy(o,r.name,r.name_len); o += r.name_len;
+              if (r.cmt) { *o++ = ' '; memcpy(o,r.cmt,r.cmt_len); o += r.cmt_len; }
+              *o++ = '\n';
+              const int i = b.slot_of[q];
+              const char *lab = nullptr;
+              if (i >= 0)
+                { memcpy(o,b.h_seq+b.h_soff[i],r.rlen);
+                  lab = b.h_lab+b.h_soff[i];
+                }
+              else if (R->is_db) unpack_bases((const unsigned char *)r.seq,(int)r.rlen,o);
+              else r.copy_seq(o);
+              o += r.rlen;
+              *o++ = '\n'; *o++ = '+'; *o++ = '\n';
+              if (lab) memcpy(o,lab,r.rlen); else memset(o,'N',r.rlen);
+              if (R->is_db)                                       // Compress_Read of the state codes, E=0 R=1 H=2 D=3
+                { unsigned char *d = (unsigned char *)ob->track.data()+(w.trk_off[r0+q]-ob->track_off);
+                  const uint32_t nby = (r.rlen+3) >> 2;
+                  for (uint32_t y = 0; y < nby; y++)
+                    { unsigned v = 0;
+                      for (uint32_t k2 = 4*y; k2 < 4*y+4; k2++)
+                        { const char c = k2 < r.rlen ? o[k2] : 'N';
+                          v = (v << 2) | (c == 'R' ? 1u : c == 'H' ? 2u : c == 'D' ? 3u : 0u);
+                        }
+                      d[y] = (unsigned char)v;
+                    }
+                }
+              o += r.rlen;
+              *o++ = '\n';
+            }
+        });
+      R->out_full.push(ob);
+    }
+  };
+
+// ---- input text: memory-mapped plain file or a .gz inflated window by window ------------------------------------
+struct TextSource
+  { MapFile map; gzFile gz = nullptr; bool is_gz = false;
+    size_t pos = 0;                           // plain: next unread byte
+    std::vector<char> carry;                  // gz: text of the incomplete last record of the previous window
+    bool gz_eof = false;
+    bool open(const std::string &path, bool gzip)
+    { is_gz = gzip;
+      if (!gzip) return map.open(path);
+      gz = gzopen(path.c_str(),"r");
+      if (gz) gzbuffer(gz,1 << 20);
+      return gz != nullptr;
+    }
+    ~TextSource() { if (gz) gzclose(gz); }
   };
 
 int main(int argc, char **argv)
-{ auto t_start = std::chrono::steady_clock::now();
+{ const tp_t t_start = now();
+  g_die_fast = true;                       // errors are raised from pipeline threads too: leave without unwinding
   bool verbose = false, seeds = false;
   int nthreads = 4, cov = 0, rlen_opt = 20000;
   std::string tmp_path = "./", fk_root, model_path, source;
@@ -110,7 +478,6 @@ int main(int argc, char **argv)
       else
         pos.push_back(a);
     }
-  (void)nthreads;
   if (pos.empty())
     die("Usage: %s %s\n",PROG,USAGE);
   if (verbose) fprintf(stderr,"Info about inputs:\n");
@@ -126,7 +493,7 @@ int main(int argc, char **argv)
     die("Cannot open %s as a .db|.dam or .f{ast}[aq][.gz] file\n",pos[0].c_str());
   if (pos.size() != 1)
     die(idx <= 1 ? "Only single file is accepted for .db and .dam\n" : "Currently only single file is accepted for FASTX input\n");
-  const bool is_db = idx <= 1, is_dam = idx == 1;
+  const bool is_db = idx <= 1, is_dam = idx == 1, is_gz = idx >= 6;
   if (seeds)
     die("%s: -s (seed selection, seed.c) is not supported by this build\n",PROG);
   if (fk_root.empty()) fk_root = path+"/"+root;
@@ -138,7 +505,7 @@ int main(int argc, char **argv)
       fprintf(stderr,"    FASTK outputs' root   = %s\n",fk_root.c_str());
       fprintf(stderr,"    Output .class file    = %s/%s.class\n",path.c_str(),root.c_str());
     }
-  { std::string tp = tmp_path;                                            // ClassPro.c:466-498
+  { std::string tp = tmp_path;                                            // ClassPro.c:466-498 (checked; no temp files are made)
     if (tp[0] != '/')
       { char *cwd = getcwd(NULL,0);
         if (tp[0] == '.')
@@ -155,237 +522,240 @@ int main(int argc, char **argv)
     if (verbose) fprintf(stderr,"    Temp dir path         = %s\n",tp.c_str());
   }
 
-  Profiles P;
-  if (!P.open(fk_root))
+  Run R;
+  R.verbose = verbose; R.is_db = is_db; R.is_dam = is_dam; R.rlen_opt = rlen_opt; R.model_path = model_path;
+  if (!R.P.open(fk_root))
     die("%s: Cannot open %s.prof\n",PROG,fk_root.c_str());
-  const int K = P.kmer, Km1 = K-1;
+  R.K = R.P.kmer; R.Km1 = R.K-1;
+  const int K = R.K;
   if (verbose)
-    fprintf(stderr,"    Total # of reads      = %lld\n",(long long)P.nreads);
+    fprintf(stderr,"    Total # of reads      = %lld\n",(long long)R.P.nreads);
 
-  int hcov, dcov;                                                          // ClassPro.c:536-554
-  { int low = 0, high = 0; int64_t il = 0, ih = 0;
+  { int low = 0, high = 0; int64_t il = 0, ih = 0;                         // ClassPro.c:536-554
     std::vector<int64_t> h;
     if (!load_hist(fk_root,&low,&high,&il,&ih,h))
       die("%s: Cannot open %s.hist\n",PROG,fk_root.c_str());
     if (verbose) fprintf(stderr,"Global histogram inspection:\n");
-    CPOK(cp_hist_covs(h.data(),low,high,il,ih,cov,&hcov,&dcov));
+    CPOK(cp_hist_covs(h.data(),low,high,il,ih,cov,&R.hcov,&R.dcov));
     if (verbose)
-      fprintf(stderr,cov > 0 ? "    Specified (H,D) cov   = (%d,%d)\n" : "    Estimated (H,D) cov   = (%d,%d)\n",hcov,dcov);
-  }
-  cp_params *params;
-  CPOK(cp_params_create_model(K,rlen_opt,hcov,dcov,model_path.empty() ? NULL : model_path.c_str(),&params));
-  { int c4[4];
-    cp_params_export(params,c4,NULL,NULL,NULL,NULL,NULL,NULL);
-    if (verbose)
-      { fprintf(stderr,"    Estimated R-threshold = %d\n",c4[CP_REPEAT]);
-        if (model_path.empty())
-          fprintf(stderr,"Error model not specified. Using the default error model.\n");
-        fprintf(stderr,"Classifying %d-mers...\n",K);
-      }
+      fprintf(stderr,cov > 0 ? "    Specified (H,D) cov   = (%d,%d)\n" : "    Estimated (H,D) cov   = (%d,%d)\n",R.hcov,R.dcov);
   }
 
-  FastxReader fx(is_db ? "/dev/null" : source.c_str());
-  if (!fx.f) die("%s: Cannot open %s\n",PROG,source.c_str());
+  // devices: every visible one, or the list in CLASSPRO_DEVICES (an id may repeat: several shards on one GPU)
+  std::vector<int> devs;
+  if (const char *e = getenv("CLASSPRO_DEVICES"))
+    { for (const char *p = e; *p; )
+        { char *end; long v = strtol(p,&end,10);
+          if (end == p) die("%s: CLASSPRO_DEVICES is not a comma-separated list of device ids\n",PROG);
+          devs.push_back((int)v);
+          p = (*end == ',') ? end+1 : end;
+        }
+    }
+  else
+    { int n = 0;
+      HIPOK(hipGetDeviceCount(&n));
+      for (int d = 0; d < n; d++) devs.push_back(d);
+    }
+  if (devs.empty()) die("%s: no HIP device\n",PROG);
+  const int ndev = (int)devs.size();
+  if (const char *e = getenv("CLASSPRO_BATCH_KBASES")) R.batch_bases = (size_t)atoll(e) << 10;   // diagnostic knob (tests)
+  ThreadPool pool(nthreads);
+  R.pool = &pool;
+  std::vector<std::unique_ptr<Device>> D;
+  for (int d = 0; d < ndev; d++)
+    { D.emplace_back(new Device());
+      D.back()->start(&R,devs[(size_t)d],d);        // HIP start-up, tables and buffers come up while the input is indexed
+    }
+
+  Run::OutBuf outbufs[3];
+  for (auto &o : outbufs) R.out_free.push(&o);
+  double t_pwrite = 0.;
+  std::thread writer([&]
+    { Run::OutBuf *ob;
+      while (R.out_full.pop(ob))
+        { const tp_t t0 = now();
+          pwrite_all(R.out_fd,ob->text.data(),ob->text.size(),ob->text_off);
+          if (R.trk_fd >= 0 && !ob->track.empty()) pwrite_all(R.trk_fd,ob->track.data(),ob->track.size(),ob->track_off);
+          t_pwrite += secs(t0,now());
+          R.out_free.push(ob);
+        }
+    });
+
+  TextSource src;
   DazzDB db;
-  ClassTrack class_track, rep_track;
+  MapFile bps;
   if (is_db)                                                               // prepare_db, io.c:123-313
     { db.open(source,is_dam);
-      if (P.nreads != db.nreads)
-        die("Inconsistent # of reads: .prof (%d) != .db (%d)\n",(int)P.nreads,db.nreads);
+      if (R.P.nreads != db.nreads)
+        die("Inconsistent # of reads: .prof (%d) != .db (%d)\n",(int)R.P.nreads,db.nreads);
       if (db.maxlen > CP_MAX_READ_LEN)
         die("%s: longest read of the DB (%d) > %d, the longest read this build classifies\n",PROG,db.maxlen,CP_MAX_READ_LEN);
-      class_track.open(path,root,"class",db.nreads,8);
+      if (!bps.open(path+"/."+root+".bps")) die("%s: Cannot open %s for 'r'\n",PROG,(path+"/."+root+".bps").c_str());
+    }
+  else if (!src.open(source,is_gz))
+    die("%s: Cannot open %s\n",PROG,source.c_str());
+
+  R.out_fd = open(out_path.c_str(),O_RDWR|O_CREAT|O_TRUNC,0644);
+  if (R.out_fd < 0) die("Cannot open %s\n",out_path.c_str());
+  if (is_db)
+    { // .anno: int nreads, int size = 8, int64 0, then the end offset of every read's data (what merge_anno, io.c:15-68,
+      // makes of the per-thread pieces); the offsets only depend on the read lengths, so the file is written up front
+      const std::string an = path+"/."+root+".class.anno", dn = path+"/."+root+".class.data";
+      FILE *anno = fopen(an.c_str(),"wb");
+      R.trk_fd = open(dn.c_str(),O_RDWR|O_CREAT|O_TRUNC,0644);
+      if (!anno || R.trk_fd < 0) die("Cannot open .*.class.*\n");
+      const int nr = db.nreads, size = 8; const int64_t zero = 0;
+      fwrite(&nr,4,1,anno); fwrite(&size,4,1,anno); fwrite(&zero,8,1,anno);
+      int64_t t = 0;
+      for (int i = 0; i < db.nreads; i++)
+        { t += (db.reads[(size_t)i].rlen+3) >> 2; fwrite(&t,8,1,anno); }
+      fclose(anno);
+      ClassTrack rep_track;
       rep_track.open(path,root,"rep",db.nreads,0);                         // repeat mask track: written by -s only
       rep_track.close();
     }
-  FILE *out = fopen(out_path.c_str(),"w");
-  if (!out) die("Cannot open %s\n",out_path.c_str());
-  std::vector<char> obuf(1 << 22);
-  setvbuf(out,obuf.data(),_IOFBF,obuf.size());
 
-  // Three batches in flight: the main thread reads batch k+1 from the input while the device classifies
-  // batch k and a writer thread prints batch k-1.
-  const size_t BATCH_BASES = (size_t)128 << 20, BATCH_READS = 1 << 16;
-  constexpr int NB = 3;
-  Batch B[NB];
-  for (int k = 0; k < NB; k++)
-    B[k].alloc(BATCH_BASES+CP_MAX_READ_LEN,BATCH_READS,is_db);
-
-  int64_t id = 0, total_bases = 0;
-  bool more = true;
-  double t_stage = 0., t_wait = 0., t_write = 0.;
-  auto now = [] { return std::chrono::steady_clock::now(); };
-  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b-a).count(); };
   const double t_setup = secs(t_start,now());
-  auto stage = [&](Batch &b)                       // fill one batch from the input; false when nothing was read
-    { const auto t0_ = now();
-      b.reset();
-      b.h_soff[0] = b.h_poff[0] = b.h_coff[0] = 0;
-      while (more && (size_t)b.bases < BATCH_BASES && (size_t)b.n < BATCH_READS)
-        { if (id >= P.nreads) { more = false; break; }
-          if ((size_t)b.codes+2*(size_t)CP_MAX_READ_LEN+2 > b.cap_code) break;
-          int rlen;
-          if (is_db)                                                       // ClassPro.c:161-180
-            { db.load((int)id,fx.seq);
-              rlen = (int)fx.seq.size();
-              b.headers.push_back(db.header((int)id));
+
+  // ---- windows of the input -> per-device contiguous read ranges -> batches ---------------------------------------
+  FxIndexer fx;
+  int64_t next_id = 0, out_pos = 0, trk_pos = 0;
+  double t_index = 0.;
+  size_t WIN0 = (size_t)ndev << 28, WIN = (size_t)ndev << 30;              // 256 MB per device first, then 1 GB per device
+  if (const char *e = getenv("CLASSPRO_WINDOW_KB")) WIN0 = WIN = (size_t)atoll(e) << 10;   // diagnostic knob (tests)
+  bool first_window = true;
+  for (;;)
+    { { std::unique_lock<std::mutex> lk(R.wm);                             // at most three windows alive
+        R.wcv.wait(lk,[&] { return R.windows_alive < 3; });
+        R.windows_alive++;
+      }
+      const tp_t ti = now();
+      std::shared_ptr<Window> w(new Window(),[&R](Window *p)
+        { delete p;
+          { std::lock_guard<std::mutex> lk(R.wm); R.windows_alive--; }
+          R.wcv.notify_all();
+        });
+      w->first_id = next_id;
+      const size_t want = first_window ? WIN0 : WIN;
+      first_window = false;
+      bool last = false;
+      if (is_db)
+        { int64_t bases = 0;
+          int i = (int)next_id;
+          for (; i < db.nreads && (size_t)bases < want; i++)
+            { const DazzRead &rd = db.reads[(size_t)i];
+              w->keep.push_back(db.header(i).substr(1));
+              FxRec r;
+              r.name = w->keep.back().data(); r.name_len = (uint32_t)w->keep.back().size();
+              r.cmt = nullptr; r.cmt_len = 0; r.own_cmt = false;
+              if ((size_t)rd.boff+(size_t)((rd.rlen+3) >> 2) > bps.len) die("%s: Failed read of .bps file (Load_Read)\n",PROG);
+              r.seq = bps.p+rd.boff; r.seq_span = (uint32_t)((rd.rlen+3) >> 2); r.rlen = (uint32_t)rd.rlen;
+              w->recs.push_back(r);
+              bases += rd.rlen;
+            }
+          last = i >= db.nreads;
+        }
+      else
+        { const char *text; size_t len; bool eof;
+          if (!src.is_gz)
+            { text = src.map.p+src.pos;
+              len = std::min(want,src.map.len-src.pos);
+              eof = src.pos+len >= src.map.len;
             }
           else
-            { rlen = fx.next();
-              if (rlen < 0)
-                die("Cannot load %lld-th read\n",(long long)id+1);
-              if (rlen > CP_MAX_READ_LEN)
-                die("rlen (%d) > MAX_READ_LEN for FASTX inputs (%d)\n",rlen,CP_MAX_READ_LEN);
-              // header "@name comment": kseq keeps the previous comment when a record has none (ClassPro.c:188)
-              b.headers.push_back("@"+fx.name+" "+(fx.have_comment ? fx.comment : std::string("(null)")));
-            }
-          const uint8_t *code; int64_t clen;
-          P.fetch(id,&code,&clen);
-          if (rlen <= Km1)                            // ClassPro.c:209-226: printed by the host, not classified
-            { b.slot.push_back(-1);
-              b.short_seq.push_back(fx.seq);
-              id++;
-              continue;
-            }
-          if (clen > 2*(int64_t)CP_MAX_READ_LEN+2)
-            die("Read %lld: profile code of %lld bytes is longer than any read of MAX_READ_LEN\n",(long long)id+1,(long long)clen);
-          // Fetch_Profile runs on the device (cp_decode_profiles): only the code string crosses PCIe.
-          // plen is taken from rlen; the reference's rlen != plen+Km1 check (ClassPro.c:234) is made by
-          // the decode kernel and reported in finish().
-          int plen = rlen-Km1;
-          memcpy(b.h_code+b.codes,code,(size_t)clen);
-          memcpy(b.h_seq+b.bases,fx.seq.data(),(size_t)rlen);          // kept on the host for the output record
-          if (is_db)
-            { if (b.n == 0) b.h_boff[0] = 0;
-              memcpy(b.h_pack+b.packed,db.cbuf.data(),(size_t)db.clen);
-              b.packed += db.clen;
-              b.h_boff[b.n+1] = b.packed;
-            }
-          b.slot.push_back(b.n);
-          b.read_id.push_back(id);
-          b.bases += rlen; b.kmers += plen; b.codes += clen; b.n++;
-          b.h_soff[b.n] = b.bases; b.h_poff[b.n] = b.kmers; b.h_coff[b.n] = b.codes;
-          id++;
-        }
-      if (id >= P.nreads) more = false;
-      t_stage += secs(t0_,now());
-      return !b.headers.empty();
-    };
-  auto submit = [&](Batch &b)
-    { if (b.n == 0) return;
-      if (!is_db)
-        HIPOK(hipMemcpyAsync(b.d_seq,b.h_seq,(size_t)b.bases,hipMemcpyHostToDevice,b.st));
-      HIPOK(hipMemcpyAsync(b.d_code,b.h_code,(size_t)b.codes,hipMemcpyHostToDevice,b.st));
-      HIPOK(hipMemcpyAsync(b.d_soff,b.h_soff,(size_t)(b.n+1)*8,hipMemcpyHostToDevice,b.st));
-      HIPOK(hipMemcpyAsync(b.d_poff,b.h_poff,(size_t)(b.n+1)*8,hipMemcpyHostToDevice,b.st));
-      HIPOK(hipMemcpyAsync(b.d_coff,b.h_coff,(size_t)(b.n+1)*8,hipMemcpyHostToDevice,b.st));
-      if (is_db)                                                  // 2-bit bases in, characters made on the device
-        { HIPOK(hipMemcpyAsync(b.d_pack,b.h_pack,(size_t)b.packed,hipMemcpyHostToDevice,b.st));
-          HIPOK(hipMemcpyAsync(b.d_boff,b.h_boff,(size_t)(b.n+1)*8,hipMemcpyHostToDevice,b.st));
-          CPOK(cp_unpack_bases(b.d_pack,b.d_boff,b.d_soff,b.n,b.d_seq,b.st));
-        }
-      CPOK(cp_decode_profiles(b.ws,b.d_code,b.d_coff,b.d_poff,b.n,b.d_prof,b.st));
-      CPOK(cp_classify_batch(params,b.ws,b.d_seq,b.d_soff,b.d_prof,b.d_poff,b.n,b.bases,b.kmers,b.d_lab,b.st));
-      HIPOK(hipMemcpyAsync(b.h_lab,b.d_lab,(size_t)b.bases,hipMemcpyDeviceToHost,b.st));
-    };
-  auto wait_device = [&](Batch &b)
-    { const auto t0_ = now();
-      if (b.n > 0)
-        { HIPOK(hipStreamSynchronize(b.st));
-          if (cp_workspace_check(b.ws) != CP_OK)
-            { // a failed decode: find the read on the host so the message is the reference's (ClassPro.c:234-237)
-              std::vector<uint16_t> tmp(CP_MAX_READ_LEN);
-              for (int i = 0; i < b.n; i++)
-                { int rlen = (int)(b.h_soff[i+1]-b.h_soff[i]);
-                  int plen = cp_decode_profile(b.h_code+b.h_coff[i],b.h_coff[i+1]-b.h_coff[i],tmp.data(),CP_MAX_READ_LEN);
-                  if (plen >= 0 && rlen != plen+Km1)
-                    die("Read %lld: rlen (%d) != plen+Km1 (%d)\n",(long long)b.read_id[i]+1,rlen,plen+Km1);
+            { w->owned.resize(src.carry.size()+want);
+              memcpy(w->owned.data(),src.carry.data(),src.carry.size());
+              size_t got = src.carry.size();
+              while (got < w->owned.size() && !src.gz_eof)
+                { int n = gzread(src.gz,w->owned.data()+got,(unsigned)std::min<size_t>(w->owned.size()-got,1u << 30));
+                  if (n < 0) die("%s: error reading %s\n",PROG,source.c_str());
+                  if (n == 0) { src.gz_eof = true; break; }
+                  got += (size_t)n;
                 }
-              die("%s\n",cp_last_error());
+              w->owned.resize(got);
+              text = w->owned.data(); len = got; eof = src.gz_eof;
+              src.carry.clear();
             }
+          int status;
+          size_t used = fx.index(text,len,eof,pool,w->recs,&status);
+          if (status == FX_BADQUAL)
+            die("Cannot load %lld-th read\n",(long long)(next_id+(int64_t)w->recs.size()));
+          if (used < len)                                                  // the window ends inside a record
+            { if (used == 0) die("%s: a record of %s is longer than the input window\n",PROG,source.c_str());
+              if (src.is_gz) src.carry.assign(text+used,text+len);
+              eof = false;
+            }
+          if (!src.is_gz) src.pos += used;
+          last = eof;
+          fx.resolve_comments(w->recs,0,w->keep);
         }
-      t_wait += secs(t0_,now());
-    };
-  auto write_out = [&](Batch &b)                   // runs on the writer thread
-    { const auto t1_ = now();
-      size_t si = 0;
-      for (size_t r = 0; r < b.headers.size(); r++)              // ClassPro.c:215,289
-        { fputs(b.headers[r].c_str(),out); fputc('\n',out);
-          if (b.slot[r] < 0)
-            { const std::string &s = b.short_seq[si++];
-              fwrite(s.data(),1,s.size(),out); fputs("\n+\n",out);
-              for (size_t k = 0; k < s.size(); k++) fputc('N',out);
-              fputc('\n',out);
-              if (is_db)
-                { std::string n(s.size(),'N'); class_track.add(n.data(),(int)n.size()); }
-            }
-          else
-            { int i = b.slot[r];
-              size_t o = (size_t)b.h_soff[i], l = (size_t)(b.h_soff[i+1]-b.h_soff[i]);
-              fwrite(b.h_seq+o,1,l,out); fputs("\n+\n",out);
-              fwrite(b.h_lab+o,1,l,out); fputc('\n',out);
-              if (is_db) class_track.add(b.h_lab+o,(int)l);
-            }
+      const size_t nrec = w->recs.size();
+      next_id += (int64_t)nrec;
+      if (next_id > R.P.nreads)
+        die("Inconsistent # of reads: more than the %lld of the .prof\n",(long long)R.P.nreads);
+      // record sizes -> final offsets (ClassPro.c:289: header\nseq\n+\nlabels\n)
+      w->out_off.resize(nrec+1);
+      if (is_db) w->trk_off.resize(nrec+1);
+      for (size_t q = 0; q < nrec; q++)
+        { const FxRec &r = w->recs[q];
+          if (!is_db && (int)r.rlen > CP_MAX_READ_LEN)
+            die("rlen (%d) > MAX_READ_LEN for FASTX inputs (%d)\n",(int)r.rlen,CP_MAX_READ_LEN);
+          w->out_off[q] = out_pos;
+          out_pos += 1+(int64_t)r.name_len+(r.cmt ? 1+(int64_t)r.cmt_len : 0)+1+2*((int64_t)r.rlen+1)+2;
+          if (is_db) { w->trk_off[q] = trk_pos; trk_pos += (r.rlen+3) >> 2; }
         }
-      total_bases += b.bases;
-      t_write += secs(t1_,now());
-    };
+      w->out_off[nrec] = out_pos;
+      if (is_db) w->trk_off[nrec] = trk_pos;
+      t_index += secs(ti,now());
 
-  // writer thread: prints the batches it is handed, in order
-  std::mutex mu;
-  std::condition_variable cv;
-  int to_write[NB], nq = 0, qhead = 0;             // queue of batch indices
-  bool busy[NB] = { false, false, false }, quit = false;
-  std::thread writer([&]
-    { for (;;)
-        { int k;
-          { std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk,[&] { return nq > 0 || quit; });
-            if (nq == 0) return;
-            k = to_write[qhead]; qhead = (qhead+1)%NB; nq--;
-          }
-          write_out(B[k]);
-          { std::lock_guard<std::mutex> lk(mu); busy[k] = false; }
-          cv.notify_all();
+      // contiguous ranges per device, balanced by bases; batches inside a range
+      std::vector<int64_t> cum(nrec+1,0);
+      for (size_t q = 0; q < nrec; q++) cum[q+1] = cum[q]+w->recs[q].rlen;
+      size_t a = 0;
+      for (int d = 0; d < ndev; d++)
+        { size_t z = nrec;
+          if (d+1 < ndev)
+            { const int64_t target = cum[nrec]*(d+1)/ndev;
+              z = (size_t)(std::lower_bound(cum.begin(),cum.end(),target)-cum.begin());
+              if (z < a) z = a;
+              if (z > nrec) z = nrec;
+            }
+          size_t b0 = a;
+          while (b0 < z)
+            { size_t b1 = b0; int64_t bases = 0, codes = 0; size_t reads = 0;
+              while (b1 < z)
+                { const uint32_t rl = w->recs[b1].rlen;
+                  const int64_t cl = R.P.code_len(w->first_id+(int64_t)b1);
+                  if (b1 > b0 && ((size_t)(bases+rl) > R.batch_bases || reads+1 > R.batch_reads || (size_t)(codes+cl) > R.batch_bases))
+                    break;
+                  bases += rl; codes += cl; reads++; b1++;
+                }
+              D[(size_t)d]->in.push(BatchJob{w,b0,b1});
+              b0 = b1;
+            }
+          a = z;
         }
-    });
-  auto hand_to_writer = [&](int k)
-    { { std::lock_guard<std::mutex> lk(mu); busy[k] = true; to_write[(qhead+nq)%NB] = k; nq++; }
-      cv.notify_all();
-    };
-  auto wait_free = [&](int k)
-    { std::unique_lock<std::mutex> lk(mu);
-      cv.wait(lk,[&] { return !busy[k]; });
-    };
-
-  int cur = 0;
-  bool have = stage(B[cur]);
-  while (have)
-    { submit(B[cur]);
-      const int nxt = (cur+1)%NB;
-      bool have_next = false;
-      if (more)
-        { wait_free(nxt);                                    // its previous contents have been printed
-          have_next = stage(B[nxt]);                         // the host reads the next batch while the device works
-        }
-      wait_device(B[cur]);
-      hand_to_writer(cur);
-      cur = nxt;
-      have = have_next;
+      if (last) break;
     }
-  { std::lock_guard<std::mutex> lk(mu); quit = true; }
-  cv.notify_all();
+  if (next_id != R.P.nreads && !is_db)
+    die("Inconsistent # of reads: .prof (%lld) != input (%lld)\n",(long long)R.P.nreads,(long long)next_id);
+  for (auto &d : D) d->in.close();
+  for (auto &d : D) { d->feeder.join(); d->completer.join(); }
+  R.out_full.close();
   writer.join();
-  fclose(out);
-  class_track.close();
+  if (ftruncate(R.out_fd,(off_t)out_pos) != 0) die("%s: cannot size the output\n",PROG);
+  close(R.out_fd);
+  if (R.trk_fd >= 0) { if (ftruncate(R.trk_fd,(off_t)trk_pos) != 0) die("%s: cannot size the track\n",PROG); close(R.trk_fd); }
 
   if (verbose)
-    { double s = std::chrono::duration<double>(std::chrono::steady_clock::now()-t_start).count();
+    { const double s = secs(t_start,now());
       fprintf(stderr,"\nResources for phase:  %.3f (s) wall, %.1f Mbases classified (%.1f Mbases/s end to end)\n",
-              s,total_bases/1e6,total_bases/1e6/s);
-      fprintf(stderr,"    host: %.3f s set-up, %.3f s reading, %.3f s waiting for the device, %.3f s writing\n",
-              t_setup,t_stage,t_wait,t_write);
+              s,R.total_bases.load()/1e6,R.total_bases.load()/1e6/s);
+      fprintf(stderr,"    host: %d device shard(s), %d host threads; %.3f s set-up, %.3f s indexing the input, %.3f s staging, "
+                     "%.3f s waiting for the device, %.3f s formatting (summed over the pipeline threads), %.3f s in write(2)\n",
+              ndev,nthreads,t_setup,t_index,R.t_stage_us.load()/1e6,R.t_wait_us.load()/1e6,R.t_write_us.load()/1e6,t_pwrite);
     }
-  cp_params_destroy(params);
-  return 0;
+  // the results are on file: leave without tearing down the HIP runtime and 10+ GB of pinned / device buffers
+  fflush(stderr);
+  _exit(0);
 }

@@ -4,6 +4,7 @@
 #pragma once
 #include <zlib.h>
 #include <strings.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdarg>
 #include <cstdlib>
@@ -14,11 +15,14 @@
 
 static const char *PROG = "ClassPro";          // each tool sets its own name first thing in main()
 
+static bool g_die_fast = false;               // multi-threaded tools: _exit, so that no thread meets a destroyed object
+
 [[noreturn]] static void die(const char *fmt, ...)
 { va_list ap;
   va_start(ap,fmt);
   vfprintf(stderr,fmt,ap);
   va_end(ap);
+  if (g_die_fast) { fflush(stderr); _exit(1); }
   exit(1);
 }
 

@@ -1,0 +1,92 @@
+"""The drop-in `ClassPro` binary on a real MI355X (`-m gpu`): one input sharded over several device shards and
+several host threads gives the same bytes as one shard and one thread (the reference's -T invariance,
+SURVEY section 4), for plain FASTA, FASTQ and .gz inputs, FASTK profiles in several parts, windows and batches
+much smaller than the input."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+K = 40
+
+
+@pytest.fixture(scope="module")
+def torch_dev(built):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    return torch
+
+
+@pytest.fixture(scope="module")
+def cli_set(torch_dev, tmp_path_factory):
+    from classpro_amd import synth, fastk, build
+    from classpro_amd.api import hist_covs
+    from oracle.oracle import Oracle
+    d = str(tmp_path_factory.mktemp("cli"))
+    ds = synth.make_dataset(genome_len=300000, cov=40, read_len=9000, seed=21)
+    seqs, profs, names = list(ds["seqs"]), list(ds["profiles"]), list(ds["names"])
+    seqs.insert(7, b"ACGTACGTACGT"); profs.insert(7, np.zeros(0, np.uint16)); names.insert(7, "tiny")
+    seqs.insert(400, b"A" * 39); profs.insert(400, np.zeros(0, np.uint16)); names.insert(400, "km1")
+    comments = [None] * len(seqs)
+    comments[2] = "first comment"
+    comments[300] = "later\tcomment"
+    with open(os.path.join(d, "reads.fasta"), "wb") as f:
+        for n, s, c in zip(names, seqs, comments):
+            f.write(b">" + n.encode() + ((b" " + c.encode()) if c else b"") + b"\n" + s + b"\n")
+    with open(os.path.join(d, "readsq.fastq"), "wb") as f:
+        for i, (n, s, c) in enumerate(zip(names, seqs, comments)):
+            q = b"@" + b"I" * (len(s) - 1) if i % 2 else b"I" * len(s)
+            f.write(b"@" + n.encode() + ((b" " + c.encode()) if c else b"") + b"\n" + s + b"\n+\n" + q + b"\n")
+    fastk.write_fastk(d, "reads", K, profs, ds["hist"], nparts=3)
+    fastk.write_fastk(d, "readsq", K, profs, ds["hist"], nparts=1)
+    low, high, il, ih, h = ds["hist"]
+    hc, dc = hist_covs(h, low, high, il, ih, 0)
+    O = Oracle(K, 20000, hc, dc)
+    exp, last = [], "(null)"
+    for n, s, p, c in zip(names, seqs, profs, comments):
+        if c:
+            last = c
+        lab = O.classify_read(s, p) if len(s) >= K else b"N" * len(s)
+        exp.append(b"@" + n.encode() + b" " + last.encode() + b"\n" + s + b"\n+\n" + lab + b"\n")
+    cli = os.path.join(os.path.dirname(build.OUT), "ClassPro")
+    return d, cli, b"".join(exp)
+
+
+def _run(cli, d, src, threads, devices=None, window_kb=None, batch_kb=None):
+    env = dict(os.environ)
+    if devices:
+        env["CLASSPRO_DEVICES"] = devices
+    if window_kb:
+        env["CLASSPRO_WINDOW_KB"] = str(window_kb)
+    if batch_kb:
+        env["CLASSPRO_BATCH_KBASES"] = str(batch_kb)
+    out = os.path.join(d, os.path.basename(src).split(".")[0] + ".class")
+    if os.path.exists(out):
+        os.remove(out)
+    r = subprocess.run([cli, "-v", "-T%d" % threads, os.path.join(d, src)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    return open(out, "rb").read(), r.stderr
+
+
+def test_one_vs_many_shards_and_threads(cli_set):
+    d, cli, exp = cli_set
+    base, err = _run(cli, d, "reads.fasta", 1, devices="0")
+    assert base == exp
+    assert "1 device shard(s), 1 host threads" in err
+    for threads, devices, win, bat in ((4, "0,0", None, None), (7, "0,0,0", 700, 900), (3, "0", 300, 500), (16, "0,0", 5000, 1500)):
+        got, err = _run(cli, d, "reads.fasta", threads, devices, win, bat)
+        assert got == base, (threads, devices, win, bat)
+        assert "%d device shard(s), %d host threads" % (len(devices.split(",")), threads) in err
+
+
+def test_fastq_and_gz_inputs(cli_set):
+    d, cli, exp = cli_set
+    got, _ = _run(cli, d, "readsq.fastq", 4, "0,0", 400, 600)
+    assert got == exp
+    subprocess.check_call(["gzip", "-kf", os.path.join(d, "readsq.fastq")])
+    os.rename(os.path.join(d, "readsq.fastq"), os.path.join(d, "readsq.fastq.bak"))
+    got, _ = _run(cli, d, "readsq.fastq.gz", 3, "0,0", 350, 500)
+    assert got == exp
