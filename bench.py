@@ -279,7 +279,7 @@ def cpu_baseline(a, ds, batches, hcov, dcov):
         if name == "Tall" and nt == min(16, ncores):
             legs[name] = dict(legs["T16"], threads=nt)
             continue
-        want_bases = r1 * 1e6 * a.cpu_seconds * nt * 0.8
+        want_bases = r1 * 1e6 * a.cpu_seconds * min(nt, 16) * 0.8       # -T<all> takes the -T16 sample
         parts, got = [], 0
         for rd, b in batches:
             if got >= want_bases:

@@ -113,6 +113,13 @@ void cpo_classify_batch(const cpo_params *p, const char *seq, const int64_t *seq
                         const uint16_t *prof, const int64_t *prof_off, int nreads,
                         char *labels, int nthreads);
 
+/* -s seed path (src/seed.c), oracle/classpro_oracle_seed.c.  cls[plen] = the read's k-mer labels (E/H/D/R);
+ * sasgn[plen] receives 'E' (not a seed) or the seed's class 'H'/'D'/'R' (seed.c:1007-1015); returns the number of
+ * repeat-mask intervals, rep_pairs = (b,e) in read coordinates (seed.c:531-566).  mintvl starts as zeros. */
+int  cpo_find_seeds(const char *seq, const char *cls, const uint16_t *profile, int plen, int K,
+                    int *sasgn, int *rep_pairs, int rep_cap);
+void cpo_kmer_hash(const char *seq, int plen, int K, int *hash);      /* seed.c:28-55 */
+
 #ifdef __cplusplus
 }
 #endif

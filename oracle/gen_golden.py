@@ -11,6 +11,7 @@ Vectors (inputs + the reference's outputs; data only, no reference source):
   classify.npz  classify_rel (fw, bw, reconciled) and classify_unrel outputs for interval sets
                 (the interval sets are produced by the oracle's find_wall/find_rel_intvl on seeded synthetic reads)
   fastk.npz     process_global_hist (H,D) and Fetch_Profile output for FASTK files written by classpro_amd.fastk
+  seeds.npz     find_seeds (seed.c, the -s path): seed labels, repeat-mask intervals and canonical ntHash values
 """
 import os
 import sys
@@ -181,10 +182,55 @@ def dazz_db():
     json.dump(out, open(os.path.join(OUT, "dazz_db.json"), "w"), indent=1)
 
 
+def seed_cases():
+    """Inputs for the -s path: (seq, label string, profile, K).  Labels of synthetic reads come from the oracle's own
+    classification; the crafted ones put every class in odd places (all R, all E, R islands shorter / longer than
+    2.5 K, single-position runs, a last position of its own count, N bases)."""
+    rng = np.random.default_rng(77)
+    AL = np.frombuffer(b"ACGT", np.uint8)
+    cases = []
+    for seed, (g, cov, rl, het) in enumerate([(120000, 40, 6000, 0.002), (90000, 60, 9000, 0.004)]):
+        ds = synth.make_dataset(genome_len=g, cov=cov, read_len=rl, seed=seed + 3, het=het, n_repeats=8)
+        Oc = Oracle(40, 20000, cov // 2, cov)
+        for s, p in list(zip(ds["seqs"], ds["profiles"]))[:14]:
+            cases.append((s, Oc.classify_read(s, p), p, 40))
+    for K, plen in ((40, 1), (40, 2), (40, 150), (40, 3000), (40, 5200), (25, 2600), (63, 2400)):
+        for mode in range(4):
+            seq = bytearray(AL[rng.integers(0, 4, plen + K - 1)].tobytes())
+            if mode == 3 and plen > 100:
+                seq[50] = ord("N"); seq[plen // 2] = ord("n")
+            runs = rng.integers(1, [400, 60, 12, 900][mode], plen)
+            lab = np.repeat(np.frombuffer(b"EHDR", np.uint8)[rng.choice(4, plen, p=[[.1, .2, .5, .2], [.25, .25, .25, .25], [.4, .1, .1, .4], [0, .1, .8, .1]][mode])], runs)[:plen]
+            cruns = rng.integers(1, [9, 3, 30, 5][mode], plen)
+            prof = np.repeat(rng.integers(1, [60, 300, 40, 2000][mode], plen), cruns)[:plen].astype(np.uint16)
+            cases.append((bytes(seq), b"N" * (K - 1) + lab.tobytes(), prof, K))
+    plen = 4000
+    seq = bytes(AL[rng.integers(0, 4, plen + 39)])
+    for lab in (b"R" * plen, b"E" * plen, b"D" * plen, b"H" * 99 + b"R" * 3801 + b"D" * 100, b"D" * 100 + b"R" * 3800 + b"H" * 100):
+        cases.append((seq, b"N" * 39 + lab, rng.integers(20, 60, plen).astype(np.uint16), 40))
+    return cases
+
+
+def seeds():
+    R = Ref()
+    cases = seed_cases()
+    out = {"n": np.array(len(cases))}
+    for i, (s, lab, p, K) in enumerate(cases):
+        sas, rep, hsh = R.find_seeds(s, lab, p, K)
+        out["seq%d" % i] = np.frombuffer(s, np.uint8)
+        out["lab%d" % i] = np.frombuffer(lab, np.uint8)
+        out["prof%d" % i] = p
+        out["K%d" % i] = np.array(K)
+        out["sasgn%d" % i] = sas
+        out["rep%d" % i] = rep
+        out["hash%d" % i] = hsh
+    np.savez_compressed(os.path.join(OUT, "seeds.npz"), **out)
+
+
 if __name__ == "__main__":
     if not ref_available() and not os.path.exists("/root/reference/src/ClassPro.h"):
         sys.exit("oracle/_ref is not built and /root/reference is absent")
     os.makedirs(OUT, exist_ok=True)
-    prims(); context(); classify(); fastk_files(); eval_tools(); dazz_db()
+    prims(); context(); classify(); fastk_files(); eval_tools(); dazz_db(); seeds()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -24,11 +24,12 @@ INTVL_DTYPE = np.dtype({
 def build(force=False):
     """Compile the oracle (and _ref when /root/reference is present).  Building is not using."""
     so = os.path.join(_HERE, "libclasspro_oracle.so")
-    src = os.path.join(_HERE, "classpro_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("classpro_oracle.c", "classpro_oracle_seed.c", "classpro_oracle.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(x) for x in srcs):
         subprocess.check_call(["make", "-C", _HERE, "libclasspro_oracle.so"], stdout=subprocess.DEVNULL)
     ref = os.path.join(_HERE, "_ref", "libclasspro_ref.so")
-    if os.path.exists("/root/reference/src/ClassPro.h") and (force or not os.path.exists(ref)):
+    drv = os.path.join(_HERE, "ref_driver.c")
+    if os.path.exists("/root/reference/src/ClassPro.h") and (force or not os.path.exists(ref) or os.path.getmtime(ref) < os.path.getmtime(drv)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
@@ -184,6 +185,29 @@ class Oracle:
         lab = labels.tobytes()
         return (lab, iv[:n].copy(), M.value) if want_intvl else lab
 
+    def find_seeds(self, seq, labels, profile):
+        """seed.c:966-1032 for one read: labels = the read's label string ('N'*(K-1) + E/H/D/R per k-mer).
+        Returns (sasgn uint8[plen] of 'E'/'H'/'D'/'R', rep int32[n,2] in read coordinates)."""
+        s = np.frombuffer(seq if isinstance(seq, bytes) else seq.encode(), dtype=np.uint8)
+        lab = np.frombuffer(labels if isinstance(labels, bytes) else bytes(labels), dtype=np.uint8)
+        profile = np.ascontiguousarray(profile, np.uint16)
+        plen = len(profile)
+        cls = np.ascontiguousarray(lab[self.K - 1:])
+        sas = np.zeros(max(plen, 1), np.int32)
+        rep = np.zeros((plen + 2, 2), np.int32)
+        self.L.cpo_find_seeds.restype = C.c_int
+        n = self.L.cpo_find_seeds(_p(s, C.c_char), _p(cls, C.c_char), _p(profile, C.c_uint16), C.c_int(plen), C.c_int(self.K),
+                                  _p(sas, C.c_int), _p(rep, C.c_int), C.c_int(plen + 2))
+        return sas[:plen].astype(np.uint8), rep[:n].copy()
+
+    def kmer_hash(self, seq, K=None):
+        K = K or self.K
+        s = np.frombuffer(seq if isinstance(seq, bytes) else seq.encode(), dtype=np.uint8)
+        plen = len(s) - K + 1
+        h = np.zeros(max(plen, 1), np.int32)
+        self.L.cpo_kmer_hash(_p(s, C.c_char), C.c_int(plen), C.c_int(K), _p(h, C.c_int))
+        return h[:plen]
+
     def classify_batch(self, seq, seq_off, prof, prof_off, nthreads=1):
         seq = np.ascontiguousarray(seq, np.uint8)
         prof = np.ascontiguousarray(prof, np.uint16)
@@ -272,6 +296,21 @@ class Ref:
         self.L.ref_classify(rintvl.ctypes.data_as(C.c_void_p), C.c_int(len(rintvl)),
                             intvl.ctypes.data_as(C.c_void_p), C.c_int(len(intvl)), C.c_int(plen), C.c_int(stage))
         return rintvl, intvl
+
+    def find_seeds(self, seq, labels, profile, K=40):
+        """The reference's own find_seeds (seed.c:966) through ref_find_seeds: (sasgn, rep pairs, hashes)."""
+        s = (seq if isinstance(seq, bytes) else seq.encode()) + b"\0"
+        lab = (labels if isinstance(labels, bytes) else bytes(labels))
+        cls = lab[K - 1:] + b"\0"
+        profile = np.ascontiguousarray(profile, np.uint16)
+        plen = len(profile)
+        sas = np.zeros(max(plen, 1) + 1, np.int32)
+        hsh = np.zeros(max(plen, 1) + 1, np.int32)
+        rep = np.zeros((plen + 2, 2), np.int32)
+        self.L.ref_find_seeds.restype = C.c_int
+        n = self.L.ref_find_seeds(C.c_char_p(s), C.c_char_p(cls), _p(profile, C.c_uint16), C.c_int(plen), C.c_int(K),
+                                  _p(sas, C.c_int), _p(hsh, C.c_int), _p(rep, C.c_int), C.c_int(plen + 2))
+        return sas[:plen].astype(np.uint8), rep[:n].copy(), hsh[:plen].copy()
 
     def classify_rel_dir(self, rintvl, plen, forward):
         rintvl = rintvl.copy()

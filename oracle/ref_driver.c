@@ -6,7 +6,7 @@
  * functions are `static inline`, so the only way to call them is to #include the .c files into one
  * translation unit, exactly as ClassPro.c:16-25 does.  This driver includes every hot-path file that
  * compiles from the image's own headers:
- *     const.c  prob.c(+bessel.c)  util.c  hist.c  context.c  class_rel.c  class_unrel.c
+ *     const.c  prob.c(+bessel.c)  util.c  hist.c  context.c  class_rel.c  class_unrel.c  seed.c(+nthash.h, kdq.h)
  * and is linked with libfastk.c (which includes gene_core.c), DB.c and QV.c (DB.c:38 defines Prog_Name),
  * the same objects the reference links into ClassPro (src/Makefile:23-24).
  *
@@ -40,6 +40,7 @@ cnt_t GLOBAL_COV[N_STATE];
 #include "context.c"
 #include "class_rel.c"
 #include "class_unrel.c"
+#include "seed.c"
 
 /* ---- setup (what ClassPro.c:536-548 does, minus calc_init_thres which lives in wall.c) ---- */
 void ref_setup(int read_len, int hcov, int dcov)
@@ -193,3 +194,32 @@ long long ref_db_track(const char *name, int *alen, unsigned char *data, long lo
   return tot;
 }
 void ref_db_close(void) { if (g_db_open) { Close_DB(&g_db); g_db_open = 0; } }
+
+/* ---- seed.c: find_seeds (seed.c:966-1032) for one read, with the buffers of ClassPro.c:120-134.
+ *      `mintvl` is zeroed before the call: the reference searches and sorts one slot past the live part of this
+ *      array (seed.c:141,161-166), i.e. it reads whatever an earlier read of the same thread left there; the
+ *      defined behaviour of this build is "the array is all zeros at the start of every read" (within a read
+ *      the three passes see each other's leftovers exactly as the reference code does).
+ *      Outputs: sasgn[plen] ('E','H','D','R' per k-mer, seed.c:1007-1015), the repeat-mask intervals written to
+ *      the .rep data track (int pairs, read coordinates, seed.c:531-566) and the canonical hashes. ---- */
+int ref_find_seeds(const char *seq, const char *pasgn, const unsigned short *profile, int plen, int K,
+                   int *sasgn, int *hash_out, int *rep_pairs, int rep_cap)
+{ kdq_t(hmer_t) *Q = kdq_init(hmer_t);
+  seg_t   *cprofile = Malloc((plen+1)*sizeof(seg_t),"c");
+  int     *hash     = Malloc((plen+1)*sizeof(int),"h");
+  intvl_t *mintvl   = Malloc((plen+2)*sizeof(intvl_t),"m");
+  memset(mintvl,0,(plen+2)*sizeof(intvl_t));
+  char *abuf = NULL, *dbuf = NULL; size_t alen = 0, dlen = 0;
+  FILE *ranno = open_memstream(&abuf,&alen), *rdata = open_memstream(&dbuf,&dlen);
+  int64 ridx = 0;
+  find_seeds(Q,seq,pasgn,profile,cprofile,hash,sasgn,mintvl,plen,K,ranno,rdata,&ridx);
+  fclose(ranno); fclose(rdata);
+  int npair = (int)(dlen/(2*sizeof(int)));
+  if (rep_pairs)
+    memcpy(rep_pairs,dbuf,sizeof(int)*2*(npair < rep_cap ? npair : rep_cap));
+  if (hash_out) memcpy(hash_out,hash,sizeof(int)*plen);
+  free(abuf); free(dbuf);
+  kdq_destroy(hmer_t,Q);
+  free(cprofile); free(hash); free(mintvl);
+  return npair;
+}
