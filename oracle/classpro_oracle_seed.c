@@ -33,13 +33,12 @@ typedef struct { int b, e; } mintvl_t;                         /* ClassPro.h:255
 static const uint64_t SEED_A = 0x3c8bfbb395c60474ULL, SEED_C = 0x3193c18562a02b4cULL,
                       SEED_G = 0x20323ed082572324ULL, SEED_T = 0x295549f54be24456ULL;
 
-static uint64_t seed_fw(unsigned char c)                       /* seedTab, nthash.h:26-59: ACGT in both cases, else 0 */
+static uint64_t seed_fw(unsigned char c)                       /* seedTab, nthash.h:26-59: every non-zero entry of the table */
 { switch (c)
-    { case 'A': case 'a': return SEED_A;
-      case 'C': case 'c': return SEED_C;
-      case 'G': case 'g': return SEED_G;
-      case 'T': case 't': return SEED_T;
-      case 1: return SEED_T; case 3: return SEED_G; case 4: case 5: return SEED_A; case 7: return SEED_C;
+    { case 'A': case 'a': case 4: case 5: return SEED_A;
+      case 'C': case 'c': case 7:         return SEED_C;
+      case 'G': case 'g': case 3:         return SEED_G;
+      case 'T': case 't': case 'U': case 'u': case 1: return SEED_T;
     }
   return 0;
 }

@@ -199,6 +199,8 @@ def seed_cases():
             seq = bytearray(AL[rng.integers(0, 4, plen + K - 1)].tobytes())
             if mode == 3 and plen > 100:
                 seq[50] = ord("N"); seq[plen // 2] = ord("n")
+                for q, c in zip(rng.integers(0, plen, 12), b"UuRYKMSWacgt"):     # every row of nthash.h's seedTab
+                    seq[int(q)] = c
             runs = rng.integers(1, [400, 60, 12, 900][mode], plen)
             lab = np.repeat(np.frombuffer(b"EHDR", np.uint8)[rng.choice(4, plen, p=[[.1, .2, .5, .2], [.25, .25, .25, .25], [.4, .1, .1, .4], [0, .1, .8, .1]][mode])], runs)[:plen]
             cruns = rng.integers(1, [9, 3, 30, 5][mode], plen)

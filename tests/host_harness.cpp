@@ -10,6 +10,7 @@
 #include "../classpro_amd/csrc/cp_host_setup.h"
 #include "../classpro_amd/csrc/cp_wall.h"
 #include "../classpro_amd/csrc/cp_class.h"
+#include "../classpro_amd/csrc/cp_seed.h"
 
 extern "C" {
 
@@ -124,4 +125,17 @@ int hh_classify_read(void *Pv, const char *seq, int rlen, const uint16_t *prof, 
   return N;
 }
 
+
+// cp_find_seeds_read (cp_seed.h) with host buffers: the routine one lane of k_find_seeds runs
+int hh_find_seeds(const char *seq, const char *cls, const uint16_t *prof, int plen, int K, char *state, int *rep_pairs, int rep_cap,
+                  int cap)
+{ std::vector<int32_t> sb(cap), se(cap), sc(cap), sn(cap), dq(cap), ord(cap), bins(CP_SEED_BINS+1), mb(cap+3), me(cap+3);
+  cp_seed_read R;
+  R.seq = seq; R.cls = cls; R.prof = prof; R.plen = plen; R.K = K; R.state = state;
+  R.seg_b = sb.data(); R.seg_e = se.data(); R.seg_cnt = sc.data(); R.seg_nw = sn.data(); R.dq = dq.data(); R.order = ord.data();
+  R.bins = bins.data(); R.mi_b = mb.data(); R.mi_e = me.data(); R.rep_pairs = rep_pairs; R.rep_cap = rep_cap; R.cap = cap; R.overflow = 0;
+  int n = cp_find_seeds_read(R);
+  return R.overflow ? -1 : n;
+}
+int hh_kmer_hash(const char *seq, int j, int K) { return cp_kmer_hash(seq,j,K); }
 }
