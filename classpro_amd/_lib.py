@@ -15,6 +15,7 @@ SYMBOLS = [
     "cp_workspace_bytes", "cp_classify_batch", "cp_workspace_check", "cp_run_stages", "cp_get_counts",
     "cp_get_intervals", "cp_get_rel_asgn", "cp_get_bitmap", "cp_seq_context", "cp_scan_candidates",
     "cp_encode_profile", "cp_decode_profiles", "cp_params_create_model", "cp_load_error_model", "cp_unpack_bases",
+    "cp_find_seeds_batch", "cp_get_rep_masks", "cp_rep_masks_capacity",
 ]
 
 _lib = None
@@ -64,6 +65,10 @@ def lib():
     L.cp_encode_profile.restype = i64
     L.cp_decode_profiles.argtypes = [vp, vp, vp, vp, i32, vp, vp]
     L.cp_unpack_bases.argtypes = [vp, vp, vp, i32, vp, vp]
+    L.cp_find_seeds_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, vp, vp]
+    L.cp_get_rep_masks.argtypes = [vp, vp, vp, vp, i64]
+    L.cp_rep_masks_capacity.argtypes = [vp]
+    L.cp_rep_masks_capacity.restype = i64
     _lib = L
     return L
 

@@ -156,6 +156,22 @@ class Classifier:
     def check(self):
         check(self.L.cp_workspace_check(self.ws))
 
+    def find_seeds(self, b):
+        """-s (seed.c:966-1032) on a batch already labelled by classify()/run(): returns (seed labels as host bytes
+        in the layout of the labels, list per read of int32[n,2] repeat-mask intervals in read coordinates)."""
+        seeds = torch.zeros(max(b.total_bases, 1), dtype=torch.uint8, device=self.device)
+        check(self.L.cp_find_seeds_batch(self.p, self.ws, b.seq.data_ptr(), b.seq_off.data_ptr(), b.prof.data_ptr(),
+                                         b.prof_off.data_ptr(), b.labels.data_ptr(), b.nreads, b.total_bases, b.total_kmers,
+                                         seeds.data_ptr(), self._stream()))
+        check(self.L.cp_workspace_check(self.ws))
+        cap = int(self.L.cp_rep_masks_capacity(self.ws))
+        cnt = np.zeros(max(b.nreads, 1), np.int32)
+        off = np.zeros(b.nreads + 1, np.int64)
+        pairs = np.zeros((max(cap, 1), 2), np.int32)
+        check(self.L.cp_get_rep_masks(self.ws, cnt.ctypes.data, off.ctypes.data, pairs.ctypes.data, max(cap, 1)))
+        b.seeds = seeds
+        return seeds[:b.total_bases].cpu().numpy(), [pairs[off[r]:off[r] + cnt[r]].copy() for r in range(b.nreads)]
+
     def decode_profiles(self, codes, code_off, prof_off):
         """Fetch_Profile on the device: returns a device tensor of counts (int16 view of uint16)."""
         dev = self.device

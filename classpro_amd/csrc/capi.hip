@@ -117,7 +117,8 @@ struct dbuf { void *p; size_t cap; };
 
 struct cp_workspace
   { dbuf bitmap, ncand, nintvl, nrel, ioff, eoff, hoff, wall, wall_s, hkeys, hvals, eintvl, ointvl, intvl, rintvl,
-         relmap, parent, eff, rpos, asgn, ord, err, memo_val, memo_key, perm, wlist, err2;
+         relmap, parent, eff, rpos, asgn, ord, err, memo_val, memo_key, perm, wlist, err2,
+         s_cap, s_rcap, s_dummy, s_key, s_seg, s_aux, s_mi, s_bins, s_rep, s_repcnt;
     int64_t *h_totals;        // pinned: [totalI, totalE, totalH]
     int32_t *h_err;           // pinned
     // shape of the last run
@@ -125,6 +126,7 @@ struct cp_workspace
     int64_t  total_kmers, total_bases, totalI, totalE, totalH, nwords;
     int      last_stage;
     int      decode_pending;  // a cp_decode_profiles result has not been checked yet
+    int      seed_nreads; int64_t seed_totalR;   // shape of the last cp_find_seeds_batch
     hipStream_t stream;
     hipStream_t aux;          // size classes of one stage run side by side: the rare long reads are latency-bound
     hipEvent_t  ev_fork, ev_join;
@@ -166,7 +168,8 @@ extern "C" void cp_workspace_destroy(cp_workspace *ws)
 { if (!ws) return;
   dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
                   &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
-                  &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist,&ws->err2 };
+                  &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist,&ws->err2,
+                  &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_bins,&ws->s_rep,&ws->s_repcnt };
   for (dbuf *b : all) if (b->p) (void)hipFree(b->p);
   if (ws->aux) (void)hipStreamDestroy(ws->aux);
   if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
@@ -180,7 +183,8 @@ extern "C" size_t cp_workspace_bytes(const cp_workspace *ws)
 { if (!ws) return 0;
   const dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
                         &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
-                        &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist,&ws->err2 };
+                        &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist,&ws->err2,
+                  &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_bins,&ws->s_rep,&ws->s_repcnt };
   size_t s = 0;
   for (const dbuf *b : all) s += b->cap;
   return s;
@@ -378,12 +382,13 @@ extern "C" int cp_workspace_check(cp_workspace *ws)
       if (*ws->h_err)
         return set_err(CP_EINVAL,"cp_decode_profiles: a code string does not expand to its read's profile length (rlen != plen+K-1)");
     }
-  if (ws->nreads == 0) return CP_OK;
+  if (ws->nreads == 0 && ws->seed_nreads == 0) return CP_OK;
   HIPCHK(hipMemcpyAsync(ws->h_err,ws->err.p,4,hipMemcpyDeviceToHost,ws->stream));
   HIPCHK(hipStreamSynchronize(ws->stream));
   if (*ws->h_err)
-    { char m[96];
-      snprintf(m,sizeof(m),"scratch overflow in find_wall (flags=%d): too many E-intervals for a read",*ws->h_err);
+    { char m[128];
+      if (*ws->h_err & 4) snprintf(m,sizeof(m),"scratch overflow in find_seeds (flags=%d)",*ws->h_err);
+      else snprintf(m,sizeof(m),"scratch overflow in find_wall (flags=%d): too many E-intervals for a read",*ws->h_err);
       return set_err(CP_EOVERFLOW,m);
     }
   return CP_OK;
@@ -456,6 +461,65 @@ extern "C" int cp_decode_profiles(cp_workspace *ws, const uint8_t *d_codes, cons
   ws->stream = st;
   return CP_OK;
 }
+
+// -s: find_seeds (seed.c:966-1032) for every read of a classified batch
+extern "C" int cp_find_seeds_batch(const cp_params *p, cp_workspace *ws, const char *d_seq, const int64_t *d_seq_off,
+                                   const uint16_t *d_prof, const int64_t *d_prof_off, const char *d_labels,
+                                   int nreads, int64_t total_bases, int64_t total_kmers, char *d_seeds, void *stream)
+{ if (!p || !ws || nreads < 0 || total_bases < 0 || total_kmers < 0)
+    return set_err(CP_EINVAL,"cp_find_seeds_batch: bad argument");
+  if (nreads > 0 && (!d_seq || !d_seq_off || !d_prof || !d_prof_off || !d_labels || !d_seeds))
+    return set_err(CP_EINVAL,"cp_find_seeds_batch: null device pointer");
+  hipStream_t st = (hipStream_t)stream;
+  ws->stream = st; ws->seed_nreads = nreads; ws->seed_totalR = 0;
+  if (nreads == 0) return CP_OK;
+  const int K = p->host.K;
+  ENSURE(ws->s_cap,((size_t)nreads+1)*8);
+  ENSURE(ws->s_rcap,((size_t)nreads+1)*8);
+  ENSURE(ws->s_dummy,((size_t)nreads+1)*8);
+  ENSURE(ws->s_key,(size_t)nreads*4);
+  ENSURE(ws->perm,(size_t)nreads*4);
+  ENSURE(ws->s_repcnt,(size_t)nreads*4);
+  ENSURE(ws->err,16);
+  if (ws->nreads == 0) HIPCHK(hipMemsetAsync(ws->err.p,0,16,st));      // no classification run shares the flag word
+  HIPCHK(hipMemsetAsync(ws->s_dummy.p,0,((size_t)nreads+1)*8,st));
+  hipLaunchKernelGGL(k_seed_caps,dim3(nreads),dim3(WAVE),0,st,d_prof,d_prof_off,d_labels,d_seq_off,K,nreads,
+                     (int64_t *)ws->s_cap.p,(int64_t *)ws->s_rcap.p,(int32_t *)ws->s_key.p);
+  hipLaunchKernelGGL(k_prefix_caps,dim3(1),dim3(1024),0,st,(int64_t *)ws->s_cap.p,(int64_t *)ws->s_rcap.p,(int64_t *)ws->s_dummy.p,nreads);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(&ws->h_totals[0],(int64_t *)ws->s_cap.p+nreads,8,hipMemcpyDeviceToHost,st));
+  HIPCHK(hipMemcpyAsync(&ws->h_totals[1],(int64_t *)ws->s_rcap.p+nreads,8,hipMemcpyDeviceToHost,st));
+  HIPCHK(hipStreamSynchronize(st));
+  const int64_t totalS = ws->h_totals[0], totalR = ws->h_totals[1];
+  ws->seed_totalR = totalR;
+  ENSURE(ws->s_seg,(size_t)totalS*4*4);
+  ENSURE(ws->s_aux,(size_t)totalS*2*4);
+  ENSURE(ws->s_mi,((size_t)totalS+3*(size_t)nreads)*2*4);
+  ENSURE(ws->s_bins,(size_t)nreads*(CP_SEED_BINS+1)*4);
+  ENSURE(ws->s_rep,(size_t)totalR*2*4+16);
+  // longest reads first, reads of similar length in one wave: key = plen / 64
+  hipLaunchKernelGGL(k_order_by_work,dim3(1),dim3(1024),0,st,(const int32_t *)ws->s_key.p,nreads,6,(int32_t *)ws->perm.p);
+  hipLaunchKernelGGL(k_find_seeds,dim3((nreads+WAVE-1)/WAVE),dim3(WAVE),0,st,d_seq,d_seq_off,d_prof,d_prof_off,d_labels,K,nreads,
+                     (const int64_t *)ws->s_cap.p,(const int64_t *)ws->s_rcap.p,(const int32_t *)ws->perm.p,
+                     (int32_t *)ws->s_seg.p,(int32_t *)ws->s_aux.p,(int32_t *)ws->s_mi.p,(int32_t *)ws->s_bins.p,
+                     (int32_t *)ws->s_rep.p,(int32_t *)ws->s_repcnt.p,d_seeds,(int32_t *)ws->err.p,totalS);
+  HIPCHK(hipGetLastError());
+  return CP_OK;
+}
+
+extern "C" int cp_get_rep_masks(cp_workspace *ws, int32_t *count, int64_t *cap_off, int32_t *pairs, int64_t capacity)
+{ if (!ws) return set_err(CP_EINVAL,"cp_get_rep_masks: null workspace");
+  if (capacity < ws->seed_totalR) return set_err(CP_EINVAL,"cp_get_rep_masks: capacity too small");
+  int rc = cp_workspace_check(ws);
+  if (rc != CP_OK) return rc;
+  const size_t n = (size_t)ws->seed_nreads;
+  if (n == 0) return CP_OK;
+  if (count)   HIPCHK(hipMemcpy(count,ws->s_repcnt.p,n*4,hipMemcpyDeviceToHost));
+  if (cap_off) HIPCHK(hipMemcpy(cap_off,ws->s_rcap.p,(n+1)*8,hipMemcpyDeviceToHost));
+  if (pairs && ws->seed_totalR > 0) HIPCHK(hipMemcpy(pairs,ws->s_rep.p,(size_t)ws->seed_totalR*8,hipMemcpyDeviceToHost));
+  return CP_OK;
+}
+extern "C" int64_t cp_rep_masks_capacity(const cp_workspace *ws) { return ws ? ws->seed_totalR : 0; }
 
 extern "C" int cp_unpack_bases(const uint8_t *d_packed, const int64_t *d_pack_off, const int64_t *d_seq_off,
                                int nreads, char *d_seq, void *stream)

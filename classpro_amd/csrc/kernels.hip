@@ -27,6 +27,7 @@
 #include <stdint.h>
 #include "cp_wall.h"
 #include "cp_class.h"
+#include "cp_seed.h"
 
 #define WAVE 64
 #define REL_MAXM 1024           // reads with more reliable intervals use the sequential kernel
@@ -1767,4 +1768,67 @@ k_seq_context(const char *__restrict__ seq, const int64_t *__restrict__ seq_off,
       { lctx[(so+i)*3+t] = (uint8_t)cp_lctx(s,rlen,i,t);
         rctx[(so+i)*3+t] = (uint8_t)cp_rctx(s,rlen,i,t);
       }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+//  -s seed path (src/seed.c:966-1032), cp_seed.h.
+//  k_seed_caps: per read, the number of count runs and of label runs of its k-mers: the scratch a read's
+//  seed selection needs (segments <= count runs + label runs + 4; .rep intervals <= label runs / 2 + 2).
+//  k_find_seeds: the selection itself is a chain of short sequential steps per read (a monotone deque over
+//  ~10^4 segments, a masked-interval list searched and merged step by step), so a read is ONE lane and a wave
+//  carries 64 reads of similar length (work-ordered launch); its arrays live in HBM, walked sequentially.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WAVE)
+k_seed_caps(const uint16_t *__restrict__ prof, const int64_t *__restrict__ prof_off, const char *__restrict__ labels,
+            const int64_t *__restrict__ seq_off, int K, int nreads, int64_t *__restrict__ scap, int64_t *__restrict__ rcap,
+            int32_t *__restrict__ plen_key)
+{ const int r = blockIdx.x;
+  if (r >= nreads) return;
+  const int lane = lane_id();
+  const int64_t po = prof_off[r];
+  const int plen = (int)(prof_off[r+1]-po);
+  const uint16_t *p = prof+po;
+  const char *c = labels+seq_off[r]+(K-1);
+  int nc = 0, nl = 0;
+  for (int i = 1+lane; i < plen; i += WAVE)
+    { nc += (p[i] != p[i-1]) ? 1 : 0;
+      nl += (c[i] != c[i-1]) ? 1 : 0;
+    }
+  for (int o = 32; o > 0; o >>= 1) { nc += __shfl_xor(nc,o); nl += __shfl_xor(nl,o); }
+  if (lane == 0)
+    { scap[r] = (int64_t)nc+nl+6;
+      rcap[r] = (int64_t)(nl+1)/2+2;
+      plen_key[r] = plen;
+    }
+}
+
+__global__ void __launch_bounds__(WAVE)
+k_find_seeds(const char *__restrict__ seq, const int64_t *__restrict__ seq_off, const uint16_t *__restrict__ prof,
+             const int64_t *__restrict__ prof_off, const char *__restrict__ labels, int K, int nreads,
+             const int64_t *__restrict__ soff, const int64_t *__restrict__ roff, const int32_t *__restrict__ perm,
+             int32_t *__restrict__ seg, int32_t *__restrict__ aux, int32_t *__restrict__ mi, int32_t *__restrict__ bins,
+             int32_t *__restrict__ rep_pairs, int32_t *__restrict__ rep_cnt, char *__restrict__ seeds, int32_t *__restrict__ err,
+             int64_t totalS)
+{ const int t = blockIdx.x*WAVE+threadIdx.x;
+  if (t >= nreads) return;
+  const int r = perm[t];
+  const int64_t so = seq_off[r], po = prof_off[r];
+  const int plen = (int)(prof_off[r+1]-po);
+  char *out = seeds+so;
+  for (int i = 0; i < K-1; i++) out[i] = 'N';
+  cp_seed_read R;
+  R.seq = seq+so; R.cls = labels+so+(K-1); R.prof = prof+po; R.plen = plen; R.K = K;
+  R.state = out+(K-1);
+  const int64_t o = soff[r];
+  R.cap = (int)(soff[r+1]-o);
+  R.seg_b = seg+o; R.seg_e = seg+totalS+o; R.seg_cnt = seg+2*totalS+o; R.seg_nw = seg+3*totalS+o;
+  R.dq = aux+o; R.order = aux+totalS+o;
+  R.mi_b = mi+2*(o+3*(int64_t)r); R.mi_e = R.mi_b+R.cap+3;
+  R.bins = bins+(int64_t)r*(CP_SEED_BINS+1);
+  R.rep_pairs = rep_pairs+2*roff[r]; R.rep_cap = (int)(roff[r+1]-roff[r]);
+  R.overflow = 0;
+  const int n = cp_find_seeds_read(R);
+  rep_cnt[r] = n < R.rep_cap ? n : R.rep_cap;
+  if (R.overflow) atomicOr(err,4);
 }

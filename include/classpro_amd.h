@@ -129,6 +129,22 @@ int cp_decode_profiles(cp_workspace *ws, const uint8_t *d_codes, const int64_t *
 int  cp_unpack_bases(const uint8_t *d_packed, const int64_t *d_pack_off, const int64_t *d_seq_off,
                      int nreads, char *d_seq, void *stream);
 
+/* -s: replaces find_seeds (src/seed.c:966-1032; call site ClassPro.c:281-282) for every read of a batch that
+ * cp_classify_batch has labelled.  d_labels is that call's output; d_seeds[total_bases] receives, in the same layout,
+ * 'N' for the first K-1 bases of a read and per k-mer 'E' (no seed) or the class of the seed, 'H' / 'D' / 'R' (a seed
+ * inside a repetitive stretch) -- the values the .class.data track carries under -s (ClassPro.c:293).  The repeat-mask
+ * intervals of anno_repeat (seed.c:482-566, the .rep.data track) stay in `ws`: cp_get_rep_masks copies, per read, their
+ * number and the (b,e) pairs in read coordinates (read r's pairs start at pairs[2*cap_off[r]]; cp_rep_masks_capacity
+ * gives the pairs' total capacity).  Defined behaviour: the reference's masked-interval array starts as zeros at
+ * every read (it is read one slot past its live part, seed.c:141,161-166). */
+int cp_find_seeds_batch(const cp_params *p, cp_workspace *ws,
+                        const char *d_seq, const int64_t *d_seq_off,
+                        const uint16_t *d_prof, const int64_t *d_prof_off, const char *d_labels,
+                        int nreads, int64_t total_bases, int64_t total_kmers,
+                        char *d_seeds, void *stream);
+int cp_get_rep_masks(cp_workspace *ws, int32_t *count, int64_t *cap_off, int32_t *pairs, int64_t capacity);
+int64_t cp_rep_masks_capacity(const cp_workspace *ws);
+
 /* Waits for the last run on `ws` and returns CP_EOVERFLOW if a read needed more E-interval /
  * interval scratch than its capacity (the reference aborts likewise: "# E-intvls >= plen",
  * src/wall.c:783-788).  Call after cp_classify_batch before trusting the labels. */
