@@ -22,7 +22,8 @@
 //     offset of <root>.class (pwrite) -- the ordered concatenation merge_files produces, without the second copy.
 // FASTK profile code strings are shipped as stored (0.27 B/base) and decoded on the device (cp_decode_profiles);
 // database bases are shipped 2-bit packed (cp_unpack_bases).
-// Not supported yet: -s (seed selection, seed.c; exits with a message).
+// -s (seed.c, Dazzler inputs only, as in the reference): cp_find_seeds_batch after the classification; the .class.data
+// track then carries the seed labels (ClassPro.c:293) and .rep.anno/.data the repeat-mask intervals (seed.c:531-566).
 #include <hip/hip_runtime.h>
 #include <zlib.h>
 #include <dirent.h>
@@ -165,7 +166,7 @@ struct BatchJob { std::shared_ptr<Window> w; size_t r0, r1; };
 
 // ---- one batch slot of a device ------------------------------------------------------------------------------
 struct Slot
-  { char *h_seq = nullptr, *h_lab = nullptr; uint8_t *h_code = nullptr, *h_pack = nullptr;
+  { char *h_seq = nullptr, *h_lab = nullptr, *h_seed = nullptr, *d_seed = nullptr; uint8_t *h_code = nullptr, *h_pack = nullptr;
     int64_t *h_soff = nullptr, *h_poff = nullptr, *h_coff = nullptr, *h_boff = nullptr;
     char *d_seq = nullptr, *d_lab = nullptr; uint8_t *d_code = nullptr, *d_pack = nullptr; uint16_t *d_prof = nullptr;
     int64_t *d_soff = nullptr, *d_poff = nullptr, *d_coff = nullptr, *d_boff = nullptr;
@@ -177,8 +178,9 @@ struct Slot
     int n = 0; int64_t bases = 0, kmers = 0, codes = 0, packed = 0;
     std::vector<int32_t> slot_of;              // record (relative to r0) -> index among classified reads, -1 = short read
     std::vector<uint32_t> rec_of;              // classified read -> record (relative to r0)
-    void alloc(size_t bases_cap, size_t reads_cap, bool with_pack)
-    { cap_bases = bases_cap; cap_reads = reads_cap; cap_code = bases_cap;
+    void alloc(size_t bases_cap, size_t reads_cap, bool with_pack, bool with_seeds)
+    { if (with_seeds) { HIPOK(hipHostMalloc((void **)&h_seed,bases_cap)); HIPOK(hipMalloc((void **)&d_seed,bases_cap)); }
+      cap_bases = bases_cap; cap_reads = reads_cap; cap_code = bases_cap;
       HIPOK(hipHostMalloc((void **)&h_seq,bases_cap)); HIPOK(hipHostMalloc((void **)&h_lab,bases_cap));
       HIPOK(hipHostMalloc((void **)&h_code,cap_code));
       HIPOK(hipHostMalloc((void **)&h_soff,(reads_cap+1)*8)); HIPOK(hipHostMalloc((void **)&h_poff,(reads_cap+1)*8));
@@ -199,7 +201,8 @@ struct Slot
 // ---- everything the pipeline threads share -----------------------------------------------------------------
 struct Run
   { int K = 40, Km1 = 39;
-    bool is_db = false, is_dam = false, verbose = false;
+    bool is_db = false, is_dam = false, verbose = false, seeds = false;
+    std::vector<std::vector<int32_t>> rep;      // -s: repeat-mask intervals of every read (b,e pairs), filled batch by batch
     int rlen_opt = 20000, hcov = 0, dcov = 0;
     std::string model_path;
     ProfileMap P;
@@ -264,7 +267,7 @@ struct Device
       std::thread allocator([this]
         { HIPOK(hipSetDevice(dev));
           for (int k = 0; k < NSLOT; k++)
-            { slot[k].alloc(R->batch_bases+CP_MAX_READ_LEN,R->batch_reads,R->is_db);
+            { slot[k].alloc(R->batch_bases+CP_MAX_READ_LEN,R->batch_reads,R->is_db,R->seeds);
               freeslots.push(k);
             }
         });
@@ -348,6 +351,10 @@ struct Device
       CPOK(cp_decode_profiles(b.ws,b.d_code,b.d_coff,b.d_poff,b.n,b.d_prof,b.st));
       CPOK(cp_classify_batch(params,b.ws,b.d_seq,b.d_soff,b.d_prof,b.d_poff,b.n,b.bases,b.kmers,b.d_lab,b.st));
       HIPOK(hipMemcpyAsync(b.h_lab,b.d_lab,(size_t)b.bases,hipMemcpyDeviceToHost,b.st));
+      if (R->seeds)                                               // ClassPro.c:281-282
+        { CPOK(cp_find_seeds_batch(params,b.ws,b.d_seq,b.d_soff,b.d_prof,b.d_poff,b.d_lab,b.n,b.bases,b.kmers,b.d_seed,b.st));
+          HIPOK(hipMemcpyAsync(b.h_seed,b.d_seed,(size_t)b.bases,hipMemcpyDeviceToHost,b.st));
+        }
     }
 
     void complete()
@@ -368,6 +375,16 @@ struct Device
                         die("Read %lld: rlen (%d) != plen+Km1 (%d)\n",(long long)(b.job.w->first_id+(int64_t)b.job.r0+b.rec_of[(size_t)i])+1,rlen,plen+R->Km1);
                     }
                   die("%s\n",cp_last_error());
+                }
+            }
+          if (R->seeds && b.n > 0)                                // the .rep intervals of the batch's reads
+            { const int64_t cap = cp_rep_masks_capacity(b.ws);
+              std::vector<int32_t> cnt((size_t)b.n), pairs((size_t)(cap > 0 ? cap : 1)*2);
+              std::vector<int64_t> off((size_t)b.n+1);
+              CPOK(cp_get_rep_masks(b.ws,cnt.data(),off.data(),pairs.data(),cap > 0 ? cap : 1));
+              for (int i = 0; i < b.n; i++)
+                { const int64_t id = b.job.w->first_id+(int64_t)b.job.r0+b.rec_of[(size_t)i];
+                  R->rep[(size_t)id].assign(pairs.begin()+2*off[(size_t)i],pairs.begin()+2*(off[(size_t)i]+cnt[(size_t)i]));
                 }
             }
           const tp_t t1 = now();
@@ -415,12 +432,13 @@ struct Device
               *o++ = '\n'; *o++ = '+'; *o++ = '\n';
               if (lab) memcpy(o,lab,r.rlen); else memset(o,'N',r.rlen);
               if (R->is_db)                                       // Compress_Read of the state codes, E=0 R=1 H=2 D=3
-                { unsigned char *d = (unsigned char *)ob->track.data()+(w.trk_off[r0+q]-ob->track_off);
+                { const char *trk = (R->seeds && i >= 0) ? b.h_seed+b.h_soff[i] : o;   // -s: the seed labels (ClassPro.c:293)
+                  unsigned char *d = (unsigned char *)ob->track.data()+(w.trk_off[r0+q]-ob->track_off);
                   const uint32_t nby = (r.rlen+3) >> 2;
                   for (uint32_t y = 0; y < nby; y++)
                     { unsigned v = 0;
                       for (uint32_t k2 = 4*y; k2 < 4*y+4; k2++)
-                        { const char c = k2 < r.rlen ? o[k2] : 'N';
+                        { const char c = k2 < r.rlen ? trk[k2] : 'N';
                           v = (v << 2) | (c == 'R' ? 1u : c == 'H' ? 2u : c == 'D' ? 3u : 0u);
                         }
                       d[y] = (unsigned char)v;
@@ -494,8 +512,8 @@ int main(int argc, char **argv)
   if (pos.size() != 1)
     die(idx <= 1 ? "Only single file is accepted for .db and .dam\n" : "Currently only single file is accepted for FASTX input\n");
   const bool is_db = idx <= 1, is_dam = idx == 1, is_gz = idx >= 6;
-  if (seeds)
-    die("%s: -s (seed selection, seed.c) is not supported by this build\n",PROG);
+  if (seeds && !is_db)
+    die("%s: -s writes DAZZ_DB tracks: it needs a .db or .dam input (the reference's seed path has no FASTX mode)\n",PROG);
   if (fk_root.empty()) fk_root = path+"/"+root;
   source = path+"/"+root+EXT[idx];
   const std::string out_path = path+"/"+root+".class";
@@ -523,7 +541,7 @@ int main(int argc, char **argv)
   }
 
   Run R;
-  R.verbose = verbose; R.is_db = is_db; R.is_dam = is_dam; R.rlen_opt = rlen_opt; R.model_path = model_path;
+  R.seeds = seeds; R.verbose = verbose; R.is_db = is_db; R.is_dam = is_dam; R.rlen_opt = rlen_opt; R.model_path = model_path;
   if (!R.P.open(fk_root))
     die("%s: Cannot open %s.prof\n",PROG,fk_root.c_str());
   R.K = R.P.kmer; R.Km1 = R.K-1;
@@ -611,8 +629,9 @@ int main(int argc, char **argv)
         { t += (db.reads[(size_t)i].rlen+3) >> 2; fwrite(&t,8,1,anno); }
       fclose(anno);
       ClassTrack rep_track;
-      rep_track.open(path,root,"rep",db.nreads,0);                         // repeat mask track: written by -s only
+      rep_track.open(path,root,"rep",db.nreads,0);                         // repeat mask track: header only unless -s (io.c:308-312)
       rep_track.close();
+      if (seeds) R.rep.resize((size_t)db.nreads);
     }
 
   const double t_setup = secs(t_start,now());
@@ -746,6 +765,21 @@ int main(int argc, char **argv)
   if (ftruncate(R.out_fd,(off_t)out_pos) != 0) die("%s: cannot size the output\n",PROG);
   close(R.out_fd);
   if (R.trk_fd >= 0) { if (ftruncate(R.trk_fd,(off_t)trk_pos) != 0) die("%s: cannot size the track\n",PROG); close(R.trk_fd); }
+  if (seeds)
+    { // .rep.anno: cumulative byte ends of every read's intervals (seed.c:567-570 per thread, merge_anno io.c:15-68 across
+      // threads); .rep.data: the (b,e) int pairs.  A read shorter than K has no interval (the reference writes no entry
+      // for it at all, ClassPro.c:209-226, which leaves its track one short; here the offset is repeated).
+      FILE *ra = fopen((path+"/."+root+".rep.anno").c_str(),"r+b"), *rd = fopen((path+"/."+root+".rep.data").c_str(),"wb");
+      if (!ra || !rd) die("Cannot open .*.rep.*\n");
+      fseek(ra,16,SEEK_SET);
+      int64_t ridx = 0;
+      for (const auto &v : R.rep)
+        { if (!v.empty()) fwrite(v.data(),4,v.size(),rd);
+          ridx += (int64_t)v.size()*4;
+          fwrite(&ridx,8,1,ra);
+        }
+      fclose(ra); fclose(rd);
+    }
 
   if (verbose)
     { const double s = secs(t_start,now());

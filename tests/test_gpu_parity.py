@@ -402,8 +402,42 @@ def test_cli_on_dazzler_database(torch_dev, tmp_path, dam):
         assert np.array_equal(got, code[np.frombuffer(lab, np.uint8)])
     nr, sz, roffs, rraw = dazz.read_class_track(d, "reads", "rep")
     assert (nr, sz, len(roffs), len(rraw)) == (n, 0, 1, 0)
-    r = subprocess.run([cli, "-s", os.path.join(d, "reads")], capture_output=True, text=True)
-    assert r.returncode == 1 and "-s" in r.stderr
+    # -s (ClassPro.c:281-304): same .class text, the .class track carries the seed labels, .rep the mask intervals
+    r = subprocess.run([cli, "-s", "-T3", os.path.join(d, "reads")], capture_output=True, text=True,
+                       env=dict(os.environ, CLASSPRO_DEVICES="0,0", CLASSPRO_BATCH_KBASES="300"))
+    assert r.returncode == 0, r.stderr
+    assert open(os.path.join(d, "reads.class"), "rb").read() == exp
+    nreads, size, offs, raw = dazz.read_class_track(d, "reads")
+    nr, sz, roffs, rraw = dazz.read_class_track(d, "reads", "rep")
+    assert (nreads, size, nr, sz) == (n, 8, n, 0) and len(roffs) == n + 1 and roffs[-1] == len(rraw)
+    rints = np.frombuffer(rraw, np.int32)
+    nseeds = 0
+    for i, (s_, p_, lab) in enumerate(zip(seqs, profs, labels)):
+        got = dazz.unpack_2bit(raw[offs[i]:offs[i + 1]], len(lab))
+        if len(s_) < K:
+            assert not got.any() and roffs[i + 1] == roffs[i]
+            continue
+        sas, rep = O.find_seeds(s_, lab, p_)
+        assert np.array_equal(got[K - 1:], code[sas]) and not got[:K - 1].any(), i
+        assert np.array_equal(rints[roffs[i] // 4:roffs[i + 1] // 4], rep.reshape(-1)), i
+        nseeds += int((sas != ord("E")).sum())
+    assert nseeds > n
+    # both tracks load through DAZZ_DB's own Open_Track / Load_All_Track_Data (the reference's DB.c, when oracle/_ref travelled)
+    import ctypes as C
+    refso = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libclasspro_ref.so")
+    if os.path.exists(refso):
+        L = C.CDLL(refso)
+        L.ref_db_track.restype = C.c_longlong
+        L.ref_db_track.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_longlong]
+        assert L.ref_db_open(os.path.join(d, "reads.dam" if dam else "reads.db").encode()) == (1 if dam else 0)
+        alen = (C.c_int * n)()
+        data = C.create_string_buffer(len(raw) + len(rraw) + 16)
+        assert L.ref_db_track(b"class", alen, data, len(data)) == len(raw) and data.raw[:len(raw)] == raw
+        assert L.ref_db_track(b"rep", alen, data, len(data)) == len(rraw) and data.raw[:len(rraw)] == rraw
+        assert [alen[i] for i in range(n)] == [int(roffs[i + 1] - roffs[i]) for i in range(n)]
+        L.ref_db_close()
+    r = subprocess.run([cli, "-s", os.path.join(d, "nothere.fasta")], capture_output=True, text=True)
+    assert r.returncode == 1
 
 
 @pytest.mark.parametrize("k,read_len,cov", [(25, 6000, 30), (63, 12000, 50), (101, 12000, 50)], ids=["k25", "k63", "k101_no_window"])
