@@ -356,6 +356,40 @@ def extra_rates(a, ds, clf, batches, hcov, dcov, dev, stream):
     ex["decode_matches"] = bool(torch.equal(d_prof[:bm.total_kmers], bm.prof[:bm.total_kmers]))
     del m, rdm, bm, d_prof, h_seq, h_code, h_lab
 
+    # BASELINE configs[4] stand-in: 60x, r=25000, with the -s seed path (cp_find_seeds_batch after the classification)
+    try:
+        from classpro_amd.api import Classifier, hist_covs
+        s4 = DeviceSynth(genome_len=20_000_000, cov=60, read_len=25000, K=K, seed=a.seed + 4, device=str(dev))
+        h4, d4 = hist_covs(s4.hist[4], 1, 32767, 0, 0, 0)
+        c4 = Classifier(K=K, read_len=25000, hcov=h4, dcov=d4, device=str(dev))
+        b4 = Batch.from_device(s4.reads(0, s4.n_reads))
+        seeds4 = torch.zeros(b4.total_bases, dtype=torch.uint8, device=dev)
+
+        def both():
+            c4.run(b4)
+            check(L.cp_find_seeds_batch(c4.p, c4.ws, b4.seq.data_ptr(), b4.seq_off.data_ptr(), b4.prof.data_ptr(), b4.prof_off.data_ptr(),
+                                        b4.labels.data_ptr(), b4.nreads, b4.total_bases, b4.total_kmers, seeds4.data_ptr(), stream))
+        both()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            c4.run(b4)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            both()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        c4.check()
+        ex["config4_60x_r25000"] = {"bases": b4.total_bases, "hcov": h4, "dcov": d4,
+                                    "classify_mbases_per_s": round(b4.total_bases * 3 / (t1 - t0) / 1e6, 1),
+                                    "classify_plus_seeds_mbases_per_s": round(b4.total_bases * 3 / (t2 - t1) / 1e6, 1),
+                                    "seed_kmers_fraction": round(float((seeds4 != ord("E")).float().mean()), 5)}
+        c4.close()
+        del s4, b4, seeds4
+    except Exception as e:
+        ex["config4_error"] = repr(e)[:200]
+
     # the drop-in binary end to end: FASTA + FASTK files of the first ~1.6 Gbases of the resident set written to
     # tmpfs, `ClassPro -T16` from process start to exit, .class (2 B/base) written next to them
     try:

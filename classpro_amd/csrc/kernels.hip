@@ -1803,20 +1803,78 @@ k_seed_caps(const uint16_t *__restrict__ prof, const int64_t *__restrict__ prof_
     }
 }
 
+// 'N' over the first K-1 bases of every read (the k-mer part is prefilled with 'E' by a memset)
+__global__ void __launch_bounds__(WAVE)
+k_seed_prefix(const int64_t *__restrict__ seq_off, int K, int nreads, char *__restrict__ seeds)
+{ const int r = blockIdx.x;
+  if (r >= nreads) return;
+  char *out = seeds+seq_off[r];
+  for (int i = lane_id(); i < K-1; i += WAVE) out[i] = 'N';
+}
+
+// on-chip part of the flat form (cp_seed.h): deque ring and radix digit counters of lane `lane`, lane-interleaved
+struct cp_seed_fast_lds
+  { uint32_t *ic, *be; int32_t *bins, *pnd; int lane;
+    __device__ __forceinline__ uint32_t &dq_ic(int s) { return ic[s*WAVE+lane]; }
+    __device__ __forceinline__ uint32_t &dq_be(int s) { return be[s*WAVE+lane]; }
+    __device__ __forceinline__ int32_t  &bin(int k)   { return bins[k*WAVE+lane]; }
+    __device__ __forceinline__ int32_t  &pend(int k)  { return pnd[k*WAVE+lane]; }
+  };
+
+#ifdef CP_SEED_PROF
+__device__ unsigned long long g_seed_prof[8];
+#endif
+// The flat form for every read; a read that asks for the plain form is appended to `todo`.
+__global__ void __launch_bounds__(WAVE)
+k_find_seeds_fast(const char *__restrict__ seq, const int64_t *__restrict__ seq_off, const uint16_t *__restrict__ prof,
+                  const int64_t *__restrict__ prof_off, const char *__restrict__ labels, int K, int nreads,
+                  const int64_t *__restrict__ soff, const int64_t *__restrict__ roff, const int32_t *__restrict__ perm,
+                  int32_t *__restrict__ seg, int32_t *__restrict__ aux, int32_t *__restrict__ mi,
+                  int32_t *__restrict__ rep_pairs, int32_t *__restrict__ rep_cnt, char *__restrict__ seeds,
+                  int32_t *__restrict__ todo, int32_t *__restrict__ ntodo, int64_t totalS)
+{ __shared__ uint32_t s_ic[CP_SEED_DQ*WAVE], s_be[CP_SEED_DQ*WAVE];
+  __shared__ int32_t s_bins[32*WAVE], s_pend[CP_SEED_PEND*WAVE];
+  const int t = blockIdx.x*WAVE+threadIdx.x;
+  if (t >= nreads) return;
+  const int r = perm[t];
+  const int64_t so = seq_off[r], po = prof_off[r];
+  cp_seed_read R;
+  R.seq = seq+so; R.cls = labels+so+(K-1); R.prof = prof+po; R.plen = (int)(prof_off[r+1]-po); R.K = K;
+  R.state = seeds+so+(K-1);
+  const int64_t o = soff[r];
+  R.cap = (int)(soff[r+1]-o);
+  R.seg_b = seg+o; R.seg_e = seg+totalS+o; R.seg_cnt = seg+2*totalS+o; R.seg_nw = seg+3*totalS+o;
+  R.dq = aux+o; R.order = aux+totalS+o;
+  R.mi_b = mi+2*(o+3*(int64_t)r); R.mi_e = R.mi_b+R.cap+3;
+  R.bins = nullptr;
+  R.rep_pairs = rep_pairs+2*roff[r]; R.rep_cap = (int)(roff[r+1]-roff[r]);
+  R.overflow = 0;
+  cp_seed_fast_lds f = { s_ic, s_be, s_bins, s_pend, (int)threadIdx.x };
+#ifdef CP_SEED_PROF
+  for (int k = 0; k < 8; k++) R.prof_t[k] = 0;
+  R.prof_last = wall_clock64();
+#endif
+  const int n = cp_find_seeds_fast(R,f);
+#ifdef CP_SEED_PROF
+  if (threadIdx.x == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_seed_prof[k],R.prof_t[k]);
+#endif
+  if (n < 0) todo[atomicAdd(ntodo,1)] = r;
+  else rep_cnt[r] = n < R.rep_cap ? n : R.rep_cap;
+}
+
 __global__ void __launch_bounds__(WAVE)
 k_find_seeds(const char *__restrict__ seq, const int64_t *__restrict__ seq_off, const uint16_t *__restrict__ prof,
              const int64_t *__restrict__ prof_off, const char *__restrict__ labels, int K, int nreads,
              const int64_t *__restrict__ soff, const int64_t *__restrict__ roff, const int32_t *__restrict__ perm,
              int32_t *__restrict__ seg, int32_t *__restrict__ aux, int32_t *__restrict__ mi, int32_t *__restrict__ bins,
              int32_t *__restrict__ rep_pairs, int32_t *__restrict__ rep_cnt, char *__restrict__ seeds, int32_t *__restrict__ err,
-             int64_t totalS)
+             int64_t totalS, const int32_t *__restrict__ count)
 { const int t = blockIdx.x*WAVE+threadIdx.x;
-  if (t >= nreads) return;
+  if (t >= (count ? *count : nreads)) return;
   const int r = perm[t];
   const int64_t so = seq_off[r], po = prof_off[r];
   const int plen = (int)(prof_off[r+1]-po);
   char *out = seeds+so;
-  for (int i = 0; i < K-1; i++) out[i] = 'N';
   cp_seed_read R;
   R.seq = seq+so; R.cls = labels+so+(K-1); R.prof = prof+po; R.plen = plen; R.K = K;
   R.state = out+(K-1);
