@@ -386,8 +386,9 @@ extern "C" int cp_workspace_check(cp_workspace *ws)
   HIPCHK(hipMemcpyAsync(ws->h_err,ws->err.p,4,hipMemcpyDeviceToHost,ws->stream));
   HIPCHK(hipStreamSynchronize(ws->stream));
   if (*ws->h_err)
-    { char m[128];
-      if (*ws->h_err & 4) snprintf(m,sizeof(m),"scratch overflow in find_seeds (flags=%d)",*ws->h_err);
+    { char m[160];
+      if (*ws->h_err & 8) snprintf(m,sizeof(m),"# E-intvls >= plen: the reference exits on a read of this batch (wall.c:783-788) (flags=%d)",*ws->h_err);
+      else if (*ws->h_err & 4) snprintf(m,sizeof(m),"scratch overflow in find_seeds (flags=%d)",*ws->h_err);
       else snprintf(m,sizeof(m),"scratch overflow in find_wall (flags=%d): too many E-intervals for a read",*ws->h_err);
       return set_err(CP_EOVERFLOW,m);
     }

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #include "cp_types.h"
 
 // hist.c:28-105 over the histogram as Load_Histogram + Modify_Histogram(H,low,high,0) leave it
@@ -22,7 +23,11 @@ static inline int cp_host_hist_covs(const int64_t *disk, int low, int high, int6
     }
   if (low > 1 || high < 4 || high > (1 << 20))
     return CP_EINVAL;
-  std::vector<int64_t> buf((size_t)(high-low)+3+4,0);
+  // The partner-peak windows below reach up to 2*maxcnt + sqrt(2*maxcnt) + 1 with maxcnt < min(1000,high): past the
+  // histogram when `high` is small (FastK always writes 1..32767, where this cannot happen).  Cells past the two hidden
+  // ones read as zero here; the reference reads whatever follows its array.
+  const size_t reach = (size_t)(2*(high < 1000 ? high : 1000)+64+8);
+  std::vector<int64_t> buf(std::max((size_t)(high-low)+3+4,reach-(size_t)low+8),0);
   int64_t *hist = buf.data()-low;
   memcpy(buf.data(),disk,sizeof(int64_t)*((size_t)(high-low)+1));
   for (int i = low+1; i < high; i++)                      // toggle to instance counts

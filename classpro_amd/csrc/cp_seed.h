@@ -732,6 +732,7 @@ template <class F>
 CP_HDM int cp_find_seeds_fast(cp_seed_read &R, F &f)
 { const int plen = R.plen, Km1 = R.K-1;
   if (plen <= 0) return 0;
+  if (plen > 65535) return -1;                             // deque entries hold 16-bit positions: the plain form takes the read
   const int min_uniq = (int)(R.K*2.5);
   // unique / repetitive stretches -> .rep intervals (seed.c:482-566), one pass
   int nrep = 0, rs = -1;                                   // rs: start of the open repetitive run

@@ -553,6 +553,7 @@ CP_HD void cp_wall_mult(RD *R, int i, int NS, int *midx)
                   ev[*midx].b = i; ev[*midx].e = plen; ev[*midx].pe = pe;
                   wall[i] |= CP_W_PAIRED_M;
                   (*midx)++;
+                  if (*midx >= plen) { R->overflow = 8; return; }        // the reference exits here: "# E-intvls >= plen" (wall.c:783-788)
                 }
               if (!((wall[j] & CP_W_WALL_O) | (wall_s[j] & CP_W_WALL_S)))
                 continue;
@@ -564,6 +565,7 @@ CP_HD void cp_wall_mult(RD *R, int i, int NS, int *midx)
                       wall[i] |= CP_W_PAIRED_M;
                       wall[j] |= CP_W_PAIRED_M;
                       (*midx)++;
+                      if (*midx >= plen) { R->overflow = 8; return; }
                     }
                 }
               if (wall[j] & CP_W_WALL_O)
@@ -580,6 +582,7 @@ CP_HD void cp_wall_mult(RD *R, int i, int NS, int *midx)
                   ev[*midx].b = 0; ev[*midx].e = i; ev[*midx].pe = pe;
                   wall[i] |= CP_W_PAIRED_M;
                   (*midx)++;
+                  if (*midx >= plen) { R->overflow = 8; return; }        // the reference exits here: "# E-intvls >= plen" (wall.c:783-788)
                 }
               if (!((wall[j] & CP_W_WALL_O) | (wall_s[j] & CP_W_WALL_S)))
                 continue;
@@ -591,6 +594,7 @@ CP_HD void cp_wall_mult(RD *R, int i, int NS, int *midx)
                       wall[i] |= CP_W_PAIRED_M;
                       wall[j] |= CP_W_PAIRED_M;
                       (*midx)++;
+                      if (*midx >= plen) { R->overflow = 8; return; }
                     }
                 }
               if (wall[j] & CP_W_WALL_O)
@@ -624,6 +628,7 @@ CP_HD int cp_merge_eintvl(RD *R, int NS)
         { if (NS >= R->ecap) { R->overflow = 1; return NS; }
           ev[NS].b = ev[i].b; ev[NS].e = max_e; ev[NS].pe = max_pe;
           NS++;
+          if (NS >= R->plen) { R->overflow = 8; return NS; }      // the reference exits here too ("# E-intvls >= plen", wall.c:900-905)
         }
       i = j+1;
     }

@@ -203,7 +203,7 @@ struct Run
   { int K = 40, Km1 = 39;
     bool is_db = false, is_dam = false, verbose = false, seeds = false;
     std::vector<std::vector<int32_t>> rep;      // -s: repeat-mask intervals of every read (b,e pairs), filled batch by batch
-    int rlen_opt = 20000, hcov = 0, dcov = 0;
+    int rlen_opt = 20000, hcov = 0, dcov = 0, max_rlen = CP_MAX_READ_LEN;
     std::string model_path;
     ProfileMap P;
     ThreadPool *pool = nullptr;
@@ -267,7 +267,7 @@ struct Device
       std::thread allocator([this]
         { HIPOK(hipSetDevice(dev));
           for (int k = 0; k < NSLOT; k++)
-            { slot[k].alloc(R->batch_bases+CP_MAX_READ_LEN,R->batch_reads,R->is_db,R->seeds);
+            { slot[k].alloc(R->batch_bases+(size_t)R->max_rlen,R->batch_reads,R->is_db,R->seeds);
               freeslots.push(k);
             }
         });
@@ -367,10 +367,10 @@ struct Device
             { HIPOK(hipStreamSynchronize(b.st));
               if (cp_workspace_check(b.ws) != CP_OK)
                 { // a failed decode: find the read on the host so the message is the reference's (ClassPro.c:234-237)
-                  std::vector<uint16_t> tmp(CP_MAX_READ_LEN);
+                  std::vector<uint16_t> tmp((size_t)R->max_rlen);
                   for (int i = 0; i < b.n; i++)
                     { int rlen = (int)(b.h_soff[i+1]-b.h_soff[i]);
-                      int plen = cp_decode_profile(b.h_code+b.h_coff[i],b.h_coff[i+1]-b.h_coff[i],tmp.data(),CP_MAX_READ_LEN);
+                      int plen = cp_decode_profile(b.h_code+b.h_coff[i],b.h_coff[i+1]-b.h_coff[i],tmp.data(),R->max_rlen);
                       if (plen >= 0 && rlen != plen+R->Km1)
                         die("Read %lld: rlen (%d) != plen+Km1 (%d)\n",(long long)(b.job.w->first_id+(int64_t)b.job.r0+b.rec_of[(size_t)i])+1,rlen,plen+R->Km1);
                     }
@@ -579,6 +579,18 @@ int main(int argc, char **argv)
   if (const char *e = getenv("CLASSPRO_BATCH_KBASES")) R.batch_bases = (size_t)atoll(e) << 10;   // diagnostic knob (tests)
   ThreadPool pool(nthreads);
   R.pool = &pool;
+  TextSource src;
+  DazzDB db;
+  MapFile bps;
+  if (is_db)                                                               // prepare_db, io.c:123-313
+    { db.open(source,is_dam);
+      if (R.P.nreads != db.nreads)
+        die("Inconsistent # of reads: .prof (%d) != .db (%d)\n",(int)R.P.nreads,db.nreads);
+      if (db.maxlen > R.max_rlen) R.max_rlen = db.maxlen;              // a database is sized by its longest read (ClassPro.c:87,110)
+      if (!bps.open(path+"/."+root+".bps")) die("%s: Cannot open %s for 'r'\n",PROG,(path+"/."+root+".bps").c_str());
+    }
+  else if (!src.open(source,is_gz))
+    die("%s: Cannot open %s\n",PROG,source.c_str());
   std::vector<std::unique_ptr<Device>> D;
   for (int d = 0; d < ndev; d++)
     { D.emplace_back(new Device());
@@ -599,19 +611,6 @@ int main(int argc, char **argv)
         }
     });
 
-  TextSource src;
-  DazzDB db;
-  MapFile bps;
-  if (is_db)                                                               // prepare_db, io.c:123-313
-    { db.open(source,is_dam);
-      if (R.P.nreads != db.nreads)
-        die("Inconsistent # of reads: .prof (%d) != .db (%d)\n",(int)R.P.nreads,db.nreads);
-      if (db.maxlen > CP_MAX_READ_LEN)
-        die("%s: longest read of the DB (%d) > %d, the longest read this build classifies\n",PROG,db.maxlen,CP_MAX_READ_LEN);
-      if (!bps.open(path+"/."+root+".bps")) die("%s: Cannot open %s for 'r'\n",PROG,(path+"/."+root+".bps").c_str());
-    }
-  else if (!src.open(source,is_gz))
-    die("%s: Cannot open %s\n",PROG,source.c_str());
 
   R.out_fd = open(out_path.c_str(),O_RDWR|O_CREAT|O_TRUNC,0644);
   if (R.out_fd < 0) die("Cannot open %s\n",out_path.c_str());

@@ -32,6 +32,8 @@
 #define WAVE 64
 #define REL_MAXM 1024           // reads with more reliable intervals use the sequential kernel
 #define UNREL_MAXN 1024         // reads with more intervals use the sequential kernel
+#define GRP_MAX_PLEN 65535      // the lane-parallel classify kernels keep interval ends as 16-bit LDS fields; a longer read
+                                // (a Dazzler database may hold them: ClassPro.c:87,110 sizes by db->maxlen) takes the sequential kernels
 
 // Make one lane's global stores visible to the other lanes of the same wave (blocks are one wave).
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
@@ -414,6 +416,7 @@ __device__ void wave_wall_mult(RD *R, int i, int NS, int *midx)
                       wall[i] |= CP_W_PAIRED_M;
                     }
                   (*midx)++;
+                  if (*midx >= plen) { R->overflow = 8; return; }      // the reference exits here: "# E-intvls >= plen" (wall.c:783-788)
                 }
               if (!((mw >> b) & 1))
                 continue;
@@ -428,6 +431,7 @@ __device__ void wave_wall_mult(RD *R, int i, int NS, int *midx)
                           wall[jj] |= CP_W_PAIRED_M;
                         }
                       (*midx)++;
+                      if (*midx >= plen) { R->overflow = 8; return; }
                     }
                 }
               if ((ms >> b) & 1) { done = true; break; }
@@ -845,8 +849,8 @@ k_classify_rel(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ 
   if (r >= nreads) return;
   const int lane = lane_id();
   const int M = nrel[r];
-  if (M <= REL_MAXM) return;                               // small reads: k_classify_rel_lds
   const int plen = (int)(prof_off[r+1]-prof_off[r]);
+  if (M == 0 || (M <= REL_MAXM && plen <= GRP_MAX_PLEN)) return;   // other reads: k_classify_rel_grp
   const int64_t o = ioff[r];
   cp_intvl *rintvl = rintvl_all+o;
   int8_t *fw = asgn_all+o, *bw = asgn_all+totalI+o;
@@ -906,8 +910,8 @@ k_classify_unrel(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__re
   if (r >= nreads) return;
   const int lane = lane_id();
   const int N = nintvl[r];
-  if (N <= UNREL_MAXN) return;                             // small reads: k_classify_unrel_lds
   cp_intvl *intvl = intvl_all+ioff[r];
+  if (N == 0 || (N <= UNREL_MAXN && intvl[N-1].e <= GRP_MAX_PLEN)) return;   // other reads: k_classify_unrel_grp (the last interval ends at plen)
   int32_t *ord = ord_all+ioff[r];
   for (int k = lane; k < N; k += WAVE)                   // ord[rank] = index | fixed<<31
     { const cp_intvl I = intvl[k];
@@ -1229,10 +1233,10 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
   const int slot = blockIdx.x*G+g;
   const int r = (slot < nreads) ? perm[slot] : nreads;
   int M = (r < nreads) ? nrel[r] : 0;
-  if (M <= MINM || M > MAXM) M = 0;                        // other size classes / sequential kernel
-  if (__ballot(M > 0) == 0) return;
   const int rr = (r < nreads) ? r : 0;
   const int plen = (int)(prof_off[rr+1]-prof_off[rr]);
+  if (M <= MINM || M > MAXM || plen > GRP_MAX_PLEN) M = 0; // other size classes / sequential kernel
+  if (__ballot(M > 0) == 0) return;
   const int64_t o = ioff[rr];
   cp_intvl *rintvl = rintvl_all+o;
   for (int k = ql; k < M; k += L)
@@ -1356,10 +1360,10 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
   const int slot = blockIdx.x*G+g;
   const int r = (slot < nreads) ? perm[slot] : nreads;
   int N = (r < nreads) ? nintvl[r] : 0;
-  if (N <= MINN || N > MAXN) N = 0;                        // other size classes / sequential kernel
-  if (__ballot(N > 0) == 0) return;
   const int64_t io = ioff[(r < nreads) ? r : 0];
   cp_intvl *intvl = intvl_all+io;
+  if (N <= MINN || N > MAXN || intvl[N-1].e > GRP_MAX_PLEN) N = 0;   // other size classes / sequential kernel
+  if (__ballot(N > 0) == 0) return;
   // memo of the expensive terms between the two sweeps: 8 (key,value) pairs per interval
   double  *mval = memo_val+io*8;
   int32_t *mkey = memo_key+io*8;

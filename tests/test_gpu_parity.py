@@ -150,15 +150,24 @@ def test_edge_reads(torch_dev):
     p = np.full(5000, 32767, np.uint16)                   # maximum count everywhere
     p[100:150] = 3
     cases.append((bytes(AL[rng.integers(0, 4, 5039)]), p))
+    rejected = []
     for s, p in cases:
         try:
             labs.append(O.classify_read(s, p))
         except OverflowError:                             # the reference aborts on this read
+            rejected.append((s, p))
             continue
         seqs.append(s)
         profs.append(p)
     assert len(seqs) >= len(cases) - 6
     clf = Classifier(K, 20000, 20, 40)
+    # the device raises CP_EOVERFLOW on exactly the reads the oracle rejects ("# E-intvls >= plen", wall.c:783-788):
+    # each rejected read alone is flagged, and the accepted ones together (below) are not
+    from classpro_amd._lib import ClassProError
+    for s, p in rejected:
+        with pytest.raises(ClassProError) as ei:
+            clf.classify(Batch.from_reads([s], [p]))
+        assert ei.value.code == -5
     b = Batch.from_reads(seqs, profs)
     got = clf.classify(b).tobytes()
     assert got == b"".join(labs)
@@ -300,6 +309,42 @@ def test_long_and_noisy_reads_all_size_classes(torch_dev):
     nc, ni, nr, off = clf.counts(b)
     assert list(ni) == Ns and list(nr) == Ms
     clf.close()
+
+
+def test_reads_longer_than_65535_kmers(torch_dev, tmp_path):
+    """A Dazzler database may hold reads beyond the FASTX limit (ClassPro.c:87,110 size everything by db->maxlen): they
+    take the sequential classify kernels (the lane-parallel ones keep 16-bit interval ends).  Library and command line."""
+    import os
+    import subprocess
+    from classpro_amd import synth, fastk, dazz, build
+    from classpro_amd.api import Classifier, Batch, hist_covs
+    from oracle.oracle import Oracle
+    ds = synth.make_dataset(genome_len=300000, cov=30, read_len=72000, seed=33, min_len=20000, max_len=110000, het=0.002)
+    seqs, profs = list(ds["seqs"]), list(ds["profiles"])
+    assert max(len(p) for p in profs) > 66000 and min(len(p) for p in profs) < 60000
+    low, high, il, ih, h = ds["hist"]
+    hc, dc = hist_covs(h, low, high, il, ih, 0)
+    O = Oracle(K, 20000, hc, dc)
+    want = [O.classify_read(s, p) for s, p in zip(seqs, profs)]
+    clf = Classifier(K, 20000, hc, dc)
+    b = Batch.from_reads(seqs, profs)
+    assert clf.classify(b).tobytes() == b"".join(want)
+    seeds, reps = clf.find_seeds(b)                          # the seed path too (flat form hands long reads to the plain form)
+    so = b.seq_off_h
+    for j, (s_, p_, lab) in enumerate(zip(seqs, profs, want)):
+        sas, rep = O.find_seeds(s_, lab, p_)
+        assert np.array_equal(seeds[so[j] + K - 1:so[j + 1]], sas) and np.array_equal(reps[j].reshape(-1, 2), rep.reshape(-1, 2))
+    clf.close()
+    d = str(tmp_path)
+    n = len(seqs)
+    recs = dazz.write_db(d, "long", seqs, [(n, "a.fasta", "m1")])
+    heads = dazz.db_headers([(n, "a.fasta", "m1")], recs)
+    fastk.write_fastk(d, "long", K, profs, ds["hist"], nparts=1)
+    cli = os.path.join(os.path.dirname(build.OUT), "ClassPro")
+    r = subprocess.run([cli, "-T4", os.path.join(d, "long.db")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exp = b"".join(hd.encode() + b"\n" + s + b"\n+\n" + lab + b"\n" for hd, s, lab in zip(heads, seqs, want))
+    assert open(os.path.join(d, "long.class"), "rb").read() == exp
 
 
 def test_device_profile_decode(torch_dev, ds_a):
@@ -490,15 +535,21 @@ def test_adversarial_inputs(torch_dev, seed):
     seqs, profs = adversarial_reads(seed)
     hc, dc = [(20, 40), (19, 38), (30, 60), (45, 90)][seed - 1]
     O = Oracle(K, 20000, hc, dc)
-    keep_s, keep_p, want = [], [], []
+    keep_s, keep_p, want, rejected = [], [], [], []
     for s_, p_ in zip(seqs, profs):
         try:
             want.append(O.classify_read(s_, p_))
         except OverflowError:                                             # the reference aborts on this read
+            rejected.append((s_, p_))
             continue
         keep_s.append(s_); keep_p.append(p_)
     assert len(want) > 150
     clf = Classifier(K=K, read_len=20000, hcov=hc, dcov=dc)
+    from classpro_amd._lib import ClassProError
+    for s_, p_ in rejected:                                               # ... and the device flags exactly those reads
+        with pytest.raises(ClassProError) as ei:
+            clf.classify(Batch.from_reads([s_], [p_]))
+        assert ei.value.code == -5
     got = clf.classify(Batch.from_reads(keep_s, keep_p))
     off = 0
     for r, w in enumerate(want):

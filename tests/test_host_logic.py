@@ -83,6 +83,23 @@ def test_host_hist_and_decode(harness):
             assert n2 == n and np.all(out2[10:] == 9999)
 
 
+def test_hist_covs_small_range(harness):
+    """A histogram that ends right after its peak (high = 100, peak at 80): the partner-peak window around 160 lies past
+    the array (the reference reads past its own buffer there); cells past the end read as zero, so the answer is the
+    peak as D and peak/2 as H."""
+    h, d = C.c_int(), C.c_int()
+    hist = np.zeros(100, np.int64)
+    hist[79] = 5000                       # count 80
+    hist[78] = hist[80] = 3000
+    hist[39] = 2000                       # count 40
+    hist[38] = hist[40] = 900
+    rc = harness.hh_hist_covs(hist.ctypes.data_as(C.c_void_p), 1, 100, C.c_int64(0), C.c_int64(0), 0, C.byref(h), C.byref(d))
+    assert rc == 0 and (h.value, d.value) == (40, 80)
+    hist[39] = hist[38] = hist[40] = 0    # no left partner either: the right side is all zero -> H = peak, D = 2 * peak
+    rc = harness.hh_hist_covs(hist.ctypes.data_as(C.c_void_p), 1, 100, C.c_int64(0), C.c_int64(0), 0, C.byref(h), C.byref(d))
+    assert rc == 0 and (h.value, d.value) == (80, 160)
+
+
 def test_fastk_encode_roundtrip():
     rng = np.random.default_rng(3)
     for _ in range(200):
