@@ -142,3 +142,60 @@ def test_config2_full_size(torch_dev):
     for j, i in enumerate(order):
         assert np.array_equal(lr[o2[j]:o2[j + 1]], got[so[i]:so[i + 1]])
     clf.close()
+
+
+def test_interval_invariants_at_bench_scale(torch_dev):
+    """What the later phases of the reference assume about find_wall's output (and assert under `#define DEBUG`,
+    ClassPro.h:17): on every read of a 200-Mbase batch the intervals tile [0,plen) in order, carry the counts at their
+    ends, the reliable ones satisfy find_rel_intvl's filters (wall.c:1016-1051), probabilities are logs of numbers <= 1,
+    N <= 2*candidates+3 (the scratch bound), and the label string is the paint of the classes (ClassPro.c:265-271)."""
+    torch = torch_dev
+    import ctypes as C
+    from classpro_amd.synth_dev import DeviceSynth
+    from classpro_amd.api import Classifier, Batch, hist_covs, INTVL_DTYPE
+    from classpro_amd._lib import check
+    ds = DeviceSynth(genome_len=5_000_000, cov=40, read_len=20000, seed=2)
+    hc, dc = hist_covs(ds.hist[4], 1, 32767, 0, 0, 0)
+    clf = Classifier(K=K, read_len=20000, hcov=hc, dcov=dc)
+    rd = ds.reads(0, ds.n_reads)
+    b = Batch.from_device(rd)
+    lab = clf.classify(b)
+    R = clf.export()["cov"][1]
+    nc, ni, nr, off = clf.counts(b)
+    tot = int(off[-1])
+    iv = np.zeros(tot, INTVL_DTYPE)
+    rv = np.zeros(tot, INTVL_DTYPE)
+    check(clf.L.cp_get_intervals(clf.ws, iv.ctypes.data, rv.ctypes.data, tot))
+    n = b.nreads
+    assert np.all(ni >= 1) and np.all(ni <= 2 * nc + 3)
+    pos = np.arange(tot)
+    rid = np.searchsorted(off, pos, side="right") - 1
+    k = pos - off[rid]                                    # interval number inside its read
+    live = k < ni[rid]
+    I, rid, k = iv[live], rid[live], k[live]
+    plen = np.diff(b.prof_off_h)[rid]
+    first, last = k == 0, k == ni[rid] - 1
+    assert np.all(I["b"] < I["e"])
+    assert np.all(I["b"][first] == 0) and np.all(I["e"][last] == plen[last])
+    assert np.all(I["b"][~first] == I["e"][np.nonzero(~first)[0] - 1])          # consecutive intervals touch
+    prof = rd["prof"][:rd["total_kmers"]].cpu().numpy().view(np.uint16)
+    po, so = b.prof_off_h[rid], b.seq_off_h[rid]
+    assert np.array_equal(I["cb"], prof[po + I["b"]]) and np.array_equal(I["ce"], prof[po + I["e"] - 1])
+    assert np.all((I["asgn"] >= 0) & (I["asgn"] <= 3))
+    stoc = np.frombuffer(b"ERHD", np.uint8)
+    for where in (I["b"], I["e"] - 1, (I["b"] + I["e"]) // 2):
+        assert np.array_equal(lab[so + K - 1 + where], stoc[I["asgn"]])
+    for f in ("pe", "peo_b", "peo_e"):
+        v = I[f]
+        assert np.all((v <= 1e-12) | np.isneginf(v))
+    rel = I["is_rel"] == 1
+    assert rel.sum() == nr.sum() and rel.any()
+    assert np.all((I["e"] - I["b"])[rel] >= K)
+    assert np.all(np.maximum(I["cb"], I["ce"])[rel] < R)
+    assert np.all(I["pe"][rel] < np.log(1e-5))
+    assert np.all(np.maximum(I["ccb"], I["cce"])[rel] != 32767)
+    # labels change only at interval boundaries
+    flat_change = np.nonzero(lab[1:] != lab[:-1])[0] + 1
+    bounds = set((so + K - 1 + I["b"]).tolist()) | set(b.seq_off_h.tolist()) | set((b.seq_off_h[:-1] + K - 1).tolist())
+    assert set(flat_change.tolist()) <= bounds
+    clf.close()
