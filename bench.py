@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="target CPU time of each cpu_baseline leg (-T1, -T16, -T<all>)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of the barrier / max-over-ranks reduction; gloo = rehearsal of N ranks on a box with "
+                         "fewer GPUs (ranks beyond the device count share device 0)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the MHC-like / PCIe / CLI extras (profiling runs)")
     return ap.parse_args()
@@ -97,7 +100,10 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(a.backend, rank=rank, world_size=world)
+    if a.backend == "gloo" and local >= torch.cuda.device_count():
+        local = 0                                           # rehearsal: more ranks than GPUs
+    rdev = None if a.backend == "nccl" else "cpu"           # where the two scalars of the reduction live
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     L = lib()
@@ -157,10 +163,10 @@ def main():
     for w in wss:
         check(L.cp_workspace_check(w))
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=rdev or dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        nb = torch.tensor([my_bases], dtype=torch.int64, device=dev)
+        nb = torch.tensor([my_bases], dtype=torch.int64, device=rdev or dev)
         dist.all_reduce(nb, op=dist.ReduceOp.SUM)
         total_bases_all = int(nb.item())
     else:

@@ -34,3 +34,26 @@ def gather_fragments(fragment, rank, world, group=None):
     if rank == 0:
         return np.concatenate(out)
     return None
+
+
+def shard_slice(seq, seq_off, prof, prof_off, lo, hi):
+    """Reads [lo,hi) of a flat read set as a flat read set of their own (offsets rebased to 0)."""
+    seq_off = np.asarray(seq_off, dtype=np.int64)
+    prof_off = np.asarray(prof_off, dtype=np.int64)
+    return (seq[seq_off[lo]:seq_off[hi]], seq_off[lo:hi + 1] - seq_off[lo],
+            prof[prof_off[lo]:prof_off[hi]], prof_off[lo:hi + 1] - prof_off[lo])
+
+
+def classify_sharded(classify_fn, seq, seq_off, prof, prof_off, rank, world, group=None):
+    """The N>1 path for a host-resident read set: this rank takes its contiguous read range (plan_shards: balanced by
+    bases), classifies it with `classify_fn(seq, seq_off, prof, prof_off) -> label bytes` (on a GPU box:
+    `lambda *a: clf.classify(Batch(*a))`), and the fragments are concatenated in rank order on rank 0 -- the ordered
+    merge of the reference's per-thread files (io.c:70-112).  No collective touches the data path.
+    Returns (labels on rank 0 / None elsewhere, the shard boundaries)."""
+    bounds = plan_shards(seq_off, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    if hi > lo:
+        frag = np.asarray(classify_fn(*shard_slice(seq, seq_off, prof, prof_off, lo, hi)), dtype=np.uint8)
+    else:
+        frag = np.zeros(0, np.uint8)
+    return gather_fragments(frag, rank, world, group), bounds

@@ -1,6 +1,8 @@
 """N>1 path: reads shard across ranks by bases with no data-path collective; the only exchange is the
 ordered host-side gather of per-shard label fragments (the reference's merge_files, io.c:70-112).
-Runs world_size 2 over gloo on CPU; the per-shard classifier here is the oracle (tests may use it)."""
+World size 2 over gloo on CPU through the PRODUCT's shard driver (classpro_amd.shard.classify_sharded: plan, slice,
+rebase, gather).  There is no GPU in this container, so the per-shard classifier plugged into the driver here is the
+oracle; tests/test_gpu_sharded.py runs the same driver with the HIP Classifier on two ranks that share one MI355X."""
 import os
 import sys
 
@@ -17,18 +19,24 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from classpro_amd import synth
-    from classpro_amd.shard import plan_shards, gather_fragments
+    from classpro_amd.shard import classify_sharded
     from oracle.oracle import Oracle
     ds = synth.make_dataset(genome_len=60000, cov=30, read_len=5000, seed=3)
     seq, so, prof, po = synth.pack_batch(ds["seqs"], ds["profiles"])
-    bounds = plan_shards(so, world)
-    lo, hi = bounds[rank], bounds[rank + 1]
     O = Oracle(40, 20000, 15, 30)
-    frag = O.classify_batch(seq[so[lo]:so[hi]], so[lo:hi + 1] - so[lo], prof[po[lo]:po[hi]], po[lo:hi + 1] - po[lo], nthreads=1)
-    merged = gather_fragments(frag, rank, world)
+    calls = []
+
+    def classify_fn(s, so_, p, po_):
+        calls.append((len(so_) - 1, int(so_[0]), int(po_[0])))
+        return O.classify_batch(s, so_, p, po_, nthreads=1)
+    merged, bounds = classify_sharded(classify_fn, seq, so, prof, po, rank, world)
+    assert len(calls) == 1 and calls[0][1] == 0 and calls[0][2] == 0          # one shard per rank, offsets rebased
+    assert calls[0][0] == bounds[rank + 1] - bounds[rank]
     if rank == 0:
         whole = O.classify_batch(seq, so, prof, po, nthreads=2)
         q.put((bool(np.array_equal(merged, whole)), [int(b) for b in bounds], int(so[-1])))
+    else:
+        assert merged is None
     dist.barrier()
     dist.destroy_process_group()
 
