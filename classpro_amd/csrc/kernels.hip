@@ -235,22 +235,21 @@ __device__ __forceinline__ T block_scan_excl_1024(T x, T *tmp, T *total)
 __global__ void __launch_bounds__(1024)
 k_prefix_caps(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__restrict__ c, int n)
 { __shared__ int64_t tmp[16], tot;
-  const int t = threadIdx.x, T = blockDim.x;
-  const int per = (n+T-1)/T;
-  const int lo = t*per, hi = (lo+per < n) ? lo+per : n;
+  const int t = threadIdx.x;
   int64_t *arr[3] = { a, b, c };
 #pragma unroll
-  for (int q = 0; q < 3; q++)
+  for (int q = 0; q < 3; q++)                             // tiles of 1024 consecutive values: coalesced loads and stores
     { int64_t *v = arr[q];
-      int64_t x = 0;
-      for (int i = lo; i < hi; i++) x += v[i];
-      int64_t off = block_scan_excl_1024<int64_t>(x,tmp,&tot);
-      for (int i = lo; i < hi; i++)
-        { int64_t y = v[i];
-          v[i] = off;
-          off += y;
+      int64_t carry = 0;
+      for (int base = 0; base < n; base += 1024)
+        { const int i = base+t;
+          const int64_t x = (i < n) ? v[i] : 0;
+          const int64_t off = block_scan_excl_1024<int64_t>(x,tmp,&tot);
+          if (i < n) v[i] = carry+off;
+          carry += tot;
+          __syncthreads();
         }
-      if (t == 0) v[n] = tot;
+      if (t == 0) v[n] = carry;
       __syncthreads();
     }
 }
@@ -845,12 +844,12 @@ k_classify_rel(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ 
                const int64_t *__restrict__ ioff, const int32_t *__restrict__ nrel,
                int8_t *__restrict__ parent_all, int32_t *__restrict__ eff_all, uint8_t *__restrict__ rpos_all,
                int8_t *__restrict__ asgn_all, int64_t totalI)
-{ const int r = blockIdx.x;
-  if (r >= nreads) return;
-  const int lane = lane_id();
+{ const int lane = lane_id();
+  for (int r = blockIdx.x; r < nreads; r += gridDim.x)     // few reads need this kernel: a small grid strides over the batch
+  {
   const int M = nrel[r];
   const int plen = (int)(prof_off[r+1]-prof_off[r]);
-  if (M == 0 || (M <= REL_MAXM && plen <= GRP_MAX_PLEN)) return;   // other reads: k_classify_rel_grp
+  if (M == 0 || (M <= REL_MAXM && plen <= GRP_MAX_PLEN)) continue;   // other reads: k_classify_rel_grp
   const int64_t o = ioff[r];
   cp_intvl *rintvl = rintvl_all+o;
   int8_t *fw = asgn_all+o, *bw = asgn_all+totalI+o;
@@ -896,6 +895,8 @@ k_classify_rel(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ 
       rintvl[i].asgn = a;
       intvl[relmap[i]].asgn = a;
     }
+  wave_sync();
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -906,12 +907,12 @@ __global__ void __launch_bounds__(WAVE)
 k_classify_unrel(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__restrict__ intvl_all,
                  const int64_t *__restrict__ ioff, const int32_t *__restrict__ nintvl,
                  int32_t *__restrict__ ord_all)
-{ const int r = blockIdx.x;
-  if (r >= nreads) return;
-  const int lane = lane_id();
+{ const int lane = lane_id();
+  for (int r = blockIdx.x; r < nreads; r += gridDim.x)     // few reads need this kernel: a small grid strides over the batch
+  {
   const int N = nintvl[r];
   cp_intvl *intvl = intvl_all+ioff[r];
-  if (N == 0 || (N <= UNREL_MAXN && intvl[N-1].e <= GRP_MAX_PLEN)) return;   // other reads: k_classify_unrel_grp (the last interval ends at plen)
+  if (N == 0 || (N <= UNREL_MAXN && intvl[N-1].e <= GRP_MAX_PLEN)) continue;   // other reads: k_classify_unrel_grp (the last interval ends at plen)
   int32_t *ord = ord_all+ioff[r];
   for (int k = lane; k < N; k += WAVE)                   // ord[rank] = index | fixed<<31
     { const cp_intvl I = intvl[k];
@@ -933,6 +934,8 @@ k_classify_unrel(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__re
         if (!(ord[i] >> 30))
           cp_update_state(P,ord[i] & 0x3fffffff,intvl,N);
     }
+  wave_sync();
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1230,13 +1233,20 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
   constexpr int L = WAVE/G;
   const int lane = lane_id();
   const int g = lane/L, ql = lane%L;
-  const int slot = blockIdx.x*G+g;
+  // A block takes the read groups blockIdx.x, blockIdx.x+gridDim.x, ...  `perm` lists the reads by decreasing M, so
+  // the reads of a class with MINM > 0 are a prefix of it: such a class is launched with a small grid and a block
+  // stops at its first group below the class (an empty class costs a few hundred blocks, not one block with this
+  // kernel's LDS per read of the batch).
+  for (int blk = blockIdx.x; blk*G < nreads; blk += gridDim.x)
+  {
+  const int slot = blk*G+g;
   const int r = (slot < nreads) ? perm[slot] : nreads;
   int M = (r < nreads) ? nrel[r] : 0;
+  if (MINM > 0 && __ballot(M > MINM) == 0) break;
   const int rr = (r < nreads) ? r : 0;
   const int plen = (int)(prof_off[rr+1]-prof_off[rr]);
   if (M <= MINM || M > MAXM || plen > GRP_MAX_PLEN) M = 0; // other size classes / sequential kernel
-  if (__ballot(M > 0) == 0) return;
+  if (__ballot(M > 0) == 0) continue;
   const int64_t o = ioff[rr];
   cp_intvl *rintvl = rintvl_all+o;
   for (int k = ql; k < M; k += L)
@@ -1304,6 +1314,8 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
       rintvl[i].asgn = a;
       intvl[relmap[i]].asgn = a;
     }
+  wave_sync();                                             // the LDS record is reused by the block's next group
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1357,13 +1369,16 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
   static_assert(L >= 8 && (L % 8) == 0, "8 role lanes per read");
   const int lane = lane_id();
   const int g = lane/L, ql = lane%L, gbase = g*L;
-  const int slot = blockIdx.x*G+g;
+  for (int blk = blockIdx.x; blk*G < nreads; blk += gridDim.x)     // groups of a block, as in k_classify_rel_grp
+  {
+  const int slot = blk*G+g;
   const int r = (slot < nreads) ? perm[slot] : nreads;
   int N = (r < nreads) ? nintvl[r] : 0;
+  if (MINN > 0 && __ballot(N > MINN) == 0) break;
   const int64_t io = ioff[(r < nreads) ? r : 0];
   cp_intvl *intvl = intvl_all+io;
   if (N <= MINN || N > MAXN || intvl[N-1].e > GRP_MAX_PLEN) N = 0;   // other size classes / sequential kernel
-  if (__ballot(N > 0) == 0) return;
+  if (__ballot(N > 0) == 0) continue;
   // memo of the expensive terms between the two sweeps: 8 (key,value) pairs per interval
   double  *mval = memo_val+io*8;
   int32_t *mkey = memo_key+io*8;
@@ -1588,6 +1603,8 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
       }
   for (int k = ql; k < N; k += L)
     intvl[k].asgn = S.asgn[g][k];
+  wave_sync();                                             // the LDS record is reused by the block's next group
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
