@@ -26,6 +26,9 @@ shutil.copy(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0],
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
 json.dump(bench, open(os.path.join(dst, name + "_bench.json"), "w"), indent=1)
 kmers = bench["roofline"]["algorithmic_bytes_per_launch"] / 2.0
+sys.path.insert(0, ROOT)
+import bench as _bench_mod
+kernel_id = _bench_mod.scan_kernel_id()
 
 agg = collections.defaultdict(list)
 grid = {}
@@ -33,7 +36,7 @@ for kind in ("fetch", "write"):
     for r in csv.DictReader(open(glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv"))[0])):
         agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
 with open(os.path.join(dst, name + "_pmc.txt"), "w") as f:
-    f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 1 --warmup 1 --no-cpu`\n")
+    f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 1 --warmup 1 --no-cpu --no-extras`\n")
     f.write("# values in KiB per dispatch as reported; gfx950 correction for streaming reads: bytes = 2*FETCH_SIZE*1024\n")
     f.write("%-28s %-11s %6s %14s %14s %14s\n" % ("kernel", "counter", "n", "avg_KiB", "min_KiB", "max_KiB"))
     for (k, c), v in sorted(agg.items()):
@@ -43,7 +46,8 @@ fs = agg[("k_scan_candidates", "FETCH_SIZE")]
 wsz = agg[("k_scan_candidates", "WRITE_SIZE")]
 fetch = 2.0 * 1024 * sum(fs) / len(fs)
 write = 1024.0 * sum(wsz) / len(wsz)
-json.dump({"kernel": "k_scan_candidates", "positions_per_launch": kmers,
+json.dump({"kernel": "k_scan_candidates", "kernel_id": kernel_id, "positions_per_launch": kmers,
+           "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 1 --warmup 1 --no-cpu --no-extras (scripts/profile_round.sh)",
            "fetch_bytes_per_launch_corrected": fetch, "write_bytes_per_launch": write,
            "hbm_bytes_per_position": (fetch + write) / kmers,
            "source": "profiles/%s_pmc.txt (FETCH_SIZE x2 per MI355X_MICROARCH.md HBM section)" % name},
