@@ -543,11 +543,11 @@ CP_HDN bool cp_seed_select_fast(cp_seed_read &R, F &f, int C, int nrep, int &hw)
   int qf = 0, qn = 0;                                      // deque = ring slots (qf+j) % CP_SEED_DQ
   bool last_oor = false; int last_oor_pos = 0;
   int ri = 0;                                              // next .rep interval (repeat selection)
-  auto valid = [&](int i) -> bool
-    { if (!rep) return R.cls[i] == C;
+  auto valid = [&](int i, unsigned char cl, unsigned char stc) -> bool      // cl = label, stc = letter written so far at k-mer i
+    { if (!rep) return cl == (unsigned char)C;
       while (ri < nrep && R.rep_pairs[2*ri+1]-Km1 <= i) ri++;
       const bool in_rep = ri < nrep && R.rep_pairs[2*ri]-Km1 <= i;
-      return in_rep && R.state[i] == 'E' && R.cls[i] != 'E';
+      return in_rep && stc == 'E' && cl != 'E';
     };
   bool ok = true;
   // The deque's entries are addressed by their running number p (qf .. qf+qn-1).  They live in the on-chip ring
@@ -559,7 +559,8 @@ CP_HDN bool cp_seed_select_fast(cp_seed_read &R, F &f, int C, int nrep, int &hw)
   auto feed = [&](int sb, int se, int sc)                  // segment n = [sb,se) with count sc (-1: skipped stretch)
     { if (n >= R.cap) { R.overflow = 1; ok = false; return; }
       if (n >= 65535) { ok = false; return; }              // deque entries hold 16-bit segment numbers
-      R.seg_b[n] = sb; R.seg_e[n] = se; R.seg_nw[n] = (sc < 0) ? -10 : 0;
+      R.seg_b[n] = (int32_t)(((uint32_t)sb << 16) | (uint32_t)se);     // begin and end in one word (both < 65536 here)
+      R.seg_nw[n] = (sc < 0) ? -10 : 0;
       if (sc >= 0)
         { if (qn > 0)
             { const int fc = (int)(q_ic(qf) >> 16);
@@ -610,14 +611,31 @@ CP_HDN bool cp_seed_select_fast(cp_seed_read &R, F &f, int C, int nrep, int &hw)
     };
   if (plen >= 2)
     { int b = 0;
-      bool run = valid(0);                                 // inside a run of equal counts (else: skipping to a valid k-mer)
+      bool run = valid(0,(unsigned char)R.cls[0],(unsigned char)R.state[0]);   // inside a run of equal counts (else: skipping to a valid k-mer)
       int prev = R.prof[0];
-      for (int e = 1; e < plen && ok; e++)
-        { const int cur = R.prof[e];
-          if (run)
-            { if (cur != prev) { feed(b,e,prev); b = e; run = valid(e); } }
-          else if (valid(e)) { feed(b,e,-1); b = e; run = true; }
-          prev = cur;
+      // eight positions per step: one 16-byte load of counts, one 8-byte load of labels (and of the letters written so
+      // far, for the repeat selection) per lane instead of two or three strided 1-2 byte loads per position
+      for (int e0 = 1; e0 < plen && ok; e0 += 8)
+        { uint16_t c8[8]; unsigned char l8[8], s8[8];
+          const int nn = plen-e0 < 8 ? plen-e0 : 8;
+          if (nn == 8)
+            { __builtin_memcpy(c8,R.prof+e0,16);
+              __builtin_memcpy(l8,R.cls+e0,8);
+              if (rep) __builtin_memcpy(s8,R.state+e0,8);
+            }
+          else
+            for (int k = 0; k < nn; k++) { c8[k] = R.prof[e0+k]; l8[k] = (unsigned char)R.cls[e0+k]; s8[k] = (unsigned char)R.state[e0+k]; }
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+          for (int k = 0; k < 8; k++)
+            if (k < nn && ok)
+              { const int e = e0+k, cur = c8[k];
+                if (run)
+                  { if (cur != prev) { feed(b,e,prev); b = e; run = valid(e,l8[k],s8[k]); } }
+                else if (valid(e,l8[k],s8[k])) { feed(b,e,-1); b = e; run = true; }
+                prev = cur;
+              }
         }
       if (ok && b < plen-1) feed(b,plen,run ? prev : -1);
     }
@@ -638,7 +656,8 @@ CP_HDN bool cp_seed_select_fast(cp_seed_read &R, F &f, int C, int nrep, int &hw)
     { const int nw = R.seg_nw[i];
       if (nw == -10)
         { cp_seed_mi_touch(R,hw,M);
-          R.mi_b[M] = R.seg_b[i]; R.mi_e[M] = R.seg_e[i]; M++;
+          const uint32_t be = (uint32_t)R.seg_b[i];
+          R.mi_b[M] = (int)(be >> 16); R.mi_e[M] = (int)(be & 0xffffu); M++;
         }
       else if (nw < 0) return false;                       // cannot happen (a window count is a distance or a count)
       else if (nw > 1000) nbig++;
@@ -647,76 +666,78 @@ CP_HDN bool cp_seed_select_fast(cp_seed_read &R, F &f, int C, int nrep, int &hw)
   SEED_STAMP(1);
   if (M > 0 && R.mi_b[0] == 0 && R.mi_e[0] == plen) return true;
   // ---- stable order by decreasing window count: two 5-bit radix passes on 1000 - count (the skipped stretches,
-  //      -10, come last), digit counters on chip -------------------------------------------------------------------
+  //      -10, come last), digit counters on chip.  The second pass also writes the records in their new order
+  //      (obe[] = begin/end, onw[] = window count), so the selection below reads them front to back.
+  int32_t *obe = R.seg_e, *onw = R.seg_cnt;
   for (int pass = 0; pass < 2; pass++)
-    { const int32_t *src = pass ? R.dq : nullptr;
-      int32_t *dst = pass ? R.order : R.dq;
-      for (int k = 0; k < 32; k++) f.bin(k) = 0;
+    { for (int k = 0; k < 32; k++) f.bin(k) = 0;
       for (int q = 0; q < n; q++)
-        { const int i = src ? src[q] : q;
-          const int nw = R.seg_nw[i];
+        { const int nw = R.seg_nw[pass ? R.dq[q] : q];
           f.bin(((nw > 1000 ? 0 : 1000-nw) >> (5*pass)) & 31)++;
         }
       int acc = 0;
       for (int k = 0; k < 32; k++) { const int c = f.bin(k); f.bin(k) = acc; acc += c; }
       for (int q = 0; q < n; q++)
-        { const int i = src ? src[q] : q;
+        { const int i = pass ? R.dq[q] : q;
           const int nw = R.seg_nw[i];
-          dst[f.bin(((nw > 1000 ? 0 : 1000-nw) >> (5*pass)) & 31)++] = i;
+          const int d = f.bin(((nw > 1000 ? 0 : 1000-nw) >> (5*pass)) & 31)++;
+          if (pass == 0) R.dq[d] = i;
+          else { R.order[d] = i; obe[d] = R.seg_b[i]; onw[d] = nw; }
         }
     }
   if (nbig > 0)                                            // counts above 1000 share the first radix key with 1000: put that
     { int m = 0;                                           // head group in order by insertion (rare, short)
-      while (m < n && R.seg_nw[R.order[m]] >= 1000) m++;
+      while (m < n && onw[m] >= 1000) m++;
       for (int a = 1; a < m; a++)
-        { const int x = R.order[a], xn = R.seg_nw[x];
+        { const int x = R.order[a], xb = obe[a], xn = onw[a];
           int j = a-1;
-          while (j >= 0 && R.seg_nw[R.order[j]] < xn) { R.order[j+1] = R.order[j]; j--; }
-          R.order[j+1] = x;
+          while (j >= 0 && onw[j] < xn) { R.order[j+1] = R.order[j]; obe[j+1] = obe[j]; onw[j+1] = onw[j]; j--; }
+          R.order[j+1] = x; obe[j+1] = xb; onw[j+1] = xn;
         }
     }
   SEED_STAMP(2);
-  auto take = [&](int s)
-    { const int b = R.seg_b[s], e = R.seg_e[s];
+  auto take = [&](uint32_t be)
+    { const int b = (int)(be >> 16), e = (int)(be & 0xffffu);
       M = cp_seed_mi_add_hw(R,M,b-W > 0 ? b-W : 0,e+W < plen ? e+W : plen,hw);
       cp_seed_mark_minimizers(R,b,e,rep);
     };
   int i = 0;
   for (; i < n; i++)                                       // extreme over a whole window
-    { const int sg = R.order[i];
-      if (R.seg_nw[sg] < W) break;
-      take(sg);
+    { if (onw[i] < W) break;
+      take((uint32_t)obe[i]);
     }
   SEED_STAMP(3);
-  // then groups of equal window count, while uncovered.  One flat loop over the remaining segments (the lanes of a wave
+  // then groups of equal window count, while uncovered.  One flat loop over the remaining records (the lanes of a wave
   // stay in step): a segment is tested against the list as it was before its group began; the members that are not
   // inside wait in a short pending list (LDS) and are taken when the group ends.
   { int g = 0x7fffffff, npend = 0, gstart = i;
     bool over = false, done = false;                         // over: more members pending than the list holds
     auto flush = [&](int gend)
       { if (over)
-          { for (int q = gstart; q < gend; q++) if (R.order[q] & 0x40000000) take(R.order[q] & 0x3fffffff); }
+          { for (int q = gstart; q < gend; q++) if (R.order[q] & 0x40000000) take((uint32_t)obe[q]); }
         else
-          for (int q = 0; q < npend; q++) take(f.pend(q));
+          for (int q = 0; q < npend; q++) take((uint32_t)f.pend(q));
         npend = 0; over = false;
       };
     for (int ii = i; ii < n && !done; ii++)
-      { const int sg = R.order[ii];
-        const int nw = R.seg_nw[sg];
+      { const int nw = onw[ii];
         if (nw != g)
           { if (ii > i)
-              { flush(ii);
+              { SEED_STAMP(4);
+                flush(ii);
+                SEED_STAMP(6);
                 if (M > 0 && R.mi_b[0] == 0 && R.mi_e[0] == plen) { done = true; break; }
               }
             g = nw; gstart = ii;
           }
         cp_seed_mi_touch(R,hw,M);
-        const int sb = R.seg_b[sg], se = R.seg_e[sg];
+        const uint32_t be = (uint32_t)obe[ii];
+        const int sb = (int)(be >> 16), se = (int)(be & 0xffffu);
         const int idx = cp_seed_mi_find(R,M,sb,se);
         const bool inside = idx >= 0 && R.mi_b[idx] <= sb && se <= R.mi_e[idx];
         if (!inside)
-          { R.order[ii] = sg | 0x40000000;
-            if (npend < CP_SEED_PEND) f.pend(npend++) = sg; else over = true;
+          { R.order[ii] |= 0x40000000;
+            if (npend < CP_SEED_PEND) f.pend(npend++) = (int32_t)be; else over = true;
           }
       }
     if (!done) flush(n);

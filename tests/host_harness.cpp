@@ -140,10 +140,10 @@ int hh_find_seeds(const char *seq, const char *cls, const uint16_t *prof, int pl
 // the flat form (cp_find_seeds_fast); returns -1 when the read asks for the plain form, -2 on scratch overflow
 int hh_find_seeds_fast(const char *seq, const char *cls, const uint16_t *prof, int plen, int K, char *state, int *rep_pairs, int rep_cap,
                        int cap)
-{ std::vector<int32_t> sb(cap), se(cap), sn(cap), dq(cap), ord(cap), mb(cap+3,-7), me(cap+3,-7);     // mi_*: garbage on purpose, zeroed on demand
+{ std::vector<int32_t> sb(cap), se(cap), sc(cap), sn(cap), dq(cap), ord(cap), mb(cap+3,-7), me(cap+3,-7);     // mi_*: garbage on purpose, zeroed on demand
   cp_seed_read R;
   R.seq = seq; R.cls = cls; R.prof = prof; R.plen = plen; R.K = K; R.state = state;
-  R.seg_b = sb.data(); R.seg_e = se.data(); R.seg_cnt = nullptr; R.seg_nw = sn.data(); R.dq = dq.data(); R.order = ord.data();
+  R.seg_b = sb.data(); R.seg_e = se.data(); R.seg_cnt = sc.data(); R.seg_nw = sn.data(); R.dq = dq.data(); R.order = ord.data();
   R.bins = nullptr; R.mi_b = mb.data(); R.mi_e = me.data(); R.rep_pairs = rep_pairs; R.rep_cap = rep_cap; R.cap = cap; R.overflow = 0;
   for (int i = 0; i < plen; i++) state[i] = 'E';
   cp_seed_fast_host f;
