@@ -120,7 +120,13 @@ def main():
         first, last = bounds[rank], bounds[rank + 1]
     else:
         first, last = 0, ds.n_reads
-    plan = ds.plan_batches(int(a.batch_mbases * 1e6), first, last)
+    # sub-batches of at most --batch-mbases, their number a multiple of the stream count (so that consecutive
+    # sub-batches, also across steps, alternate over the streams); a rank's share is never a single sub-batch
+    share = int(ds.seq_off_all[last] - ds.seq_off_all[first])
+    nst_ = max(1, a.streams)
+    nb_ = max(nst_, -(-share // int(a.batch_mbases * 1e6)))
+    nb_ = -(-nb_ // nst_) * nst_
+    plan = ds.plan_batches(-(-share // nb_) + 1, first, last)
     batches = []
     for i, (r0, n) in enumerate(plan):
         rd = ds.reads(r0, n, truth=(i == 0 and rank == 0))

@@ -54,3 +54,19 @@ json.dump({"kernel": "k_scan_candidates", "kernel_id": kernel_id, "positions_per
           open(os.path.join(dst, "scan_pmc.json"), "w"), indent=1)
 print(open(os.path.join(dst, name + "_pmc.txt")).read())
 print(open(os.path.join(dst, "scan_pmc.json")).read())
+
+# The default bench keeps two sub-batches in flight, so the scan launches of the pipeline overlap with other kernels; the
+# launches of bench.py's roofline loop (the last ones, back-to-back on one stream) are the ones its HIP events time.
+tr = glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))[0]
+rows = [r for r in csv.DictReader(open(tr)) if r["Kernel_Name"].startswith("k_scan_candidates")]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+nloop = bench["roofline"].get("launches_timed", 200)
+loop = d[-nloop:]
+with open(os.path.join(dst, name + "_scan_durations.txt"), "w") as f:
+    f.write("# k_scan_candidates launch durations in the rocprofv3 --kernel-trace of the stats run; the last %d launches are bench.py's\n" % nloop)
+    f.write("# roofline loop (back-to-back on one stream), the earlier ones belong to the pipeline and overlap with the other stream's kernels\n")
+    f.write("all %d launches: average %.1f us (the figure in %s_kernel_stats.csv)\n" % (len(d), sum(d) / len(d), name))
+    f.write("roofline-loop launches (%d): average %.1f us, min %.1f, max %.1f\n" % (len(loop), sum(loop) / len(loop), min(loop), max(loop)))
+    f.write("bench.py HIP events (%s_bench.json): %.1f us per launch, %.0f GB/s\n" % (name, bench["roofline"]["ms_per_launch"] * 1e3, bench["roofline"]["achieved"]))
+print(open(os.path.join(dst, name + "_scan_durations.txt")).read())
