@@ -17,9 +17,9 @@
 //   * -T host threads (a pool) do every data-parallel host loop: indexing the input text (fastx_index.h: plain
 //     FASTA in parallel chunks, FASTQ by one thread, .gz inflated by one thread = the .gz ceiling), staging copies
 //     into pinned memory, formatting the records;
-//   * no temp files and no merge pass: the size of every record is known once its window is indexed, so a batch's
-//     records are formatted by the pool into a memory buffer and one writer thread puts the buffer at its final
-//     offset of <root>.class (pwrite) -- the ordered concatenation merge_files produces, without the second copy.
+//   * no temp files and no merge pass: the size of every record is known once its window is indexed, so the window's
+//     stretch of <root>.class is fallocated and mapped at once and the pool formats every record at its final offset
+//     -- the ordered concatenation merge_files produces, without the second copy.
 // FASTK profile code strings are shipped as stored (0.27 B/base) and decoded on the device (cp_decode_profiles);
 // database bases are shipped 2-bit packed (cp_unpack_bases).
 // -s (seed.c, Dazzler inputs only, as in the reference): cp_find_seeds_batch after the classification; the .class.data
@@ -160,6 +160,30 @@ struct Window
     int64_t first_id = 0;                      // input index of recs[0]
     std::vector<int64_t> out_off;              // offset of every record in <root>.class (+ end)
     std::vector<int64_t> trk_off;              // database: offset of every read in .class.data (+ end)
+    // The window's stretch of the output files, mapped shared.  The output's pages are what the host pays most for:
+    // a fresh page-cache / tmpfs page costs the kernel an allocation, a clear and a memcg charge, and ONE file takes
+    // them no faster from many writers than from one (write(2) serialises on the inode lock: 5-8 GB/s; first-touch
+    // faults of a shared mapping: 3.6-5.6 GB/s).  fallocate() hands a file its pages at 14.8 GB/s from one thread, and
+    // pages that exist are filled through a mapping at 130 GB/s by 16 threads (scripts/microbench/tmpfs_write.cpp,
+    // tmpfs_falloc.cpp; profiles/r02_tmpfs_write.txt).  So: an allocator thread fallocates a window's stretch as soon
+    // as the window is indexed -- while HIP starts and the device works -- and the formatter threads write the
+    // records in place.
+    char *omap = nullptr, *tmap = nullptr; size_t omap_len = 0, tmap_len = 0; int64_t omap_base = 0, tmap_base = 0;
+    int64_t out_lo = 0, out_hi = 0, trk_lo = 0, trk_hi = 0;
+    bool allocated = false;                    // set by the allocator thread (under Run::am); formatters wait for it
+    char *out_at(int64_t off) const { return omap+(off-omap_base); }
+    char *trk_at(int64_t off) const { return tmap+(off-tmap_base); }
+    void map_out(int fd, int64_t lo, int64_t hi, bool track)
+    { if (hi <= lo) return;
+      const int64_t base = lo & ~(int64_t)4095;
+      if (ftruncate(fd,(off_t)hi) != 0) die("%s: cannot size the output\n",PROG);
+      void *m = mmap(nullptr,(size_t)(hi-base),PROT_READ|PROT_WRITE,MAP_SHARED,fd,(off_t)base);
+      if (m == MAP_FAILED) die("%s: cannot map the output file\n",PROG);
+      if (track) { tmap = (char *)m; tmap_len = (size_t)(hi-base); tmap_base = base; trk_lo = lo; trk_hi = hi; }
+      else       { omap = (char *)m; omap_len = (size_t)(hi-base); omap_base = base; out_lo = lo; out_hi = hi; }
+    }
+    // (the mappings are left to process exit: munmap of a gigabyte holds the address-space lock against every
+    //  thread's page faults, and the process leaves through _exit right after the last window)
   };
 
 struct BatchJob { std::shared_ptr<Window> w; size_t r0, r1; };
@@ -211,17 +235,14 @@ struct Run
     std::atomic<int64_t> total_bases{0};
     std::atomic<int64_t> t_stage_us{0}, t_wait_us{0}, t_write_us{0};
     size_t batch_bases = (size_t)256 << 20, batch_reads = 1 << 17;
-    // Output: records are formatted by the pool into reusable memory buffers and written by ONE thread with large
-    // pwrite calls.  A page-cache / tmpfs file takes fresh pages fastest from a single writer (the inode lock
-    // serialises writers, and first-touch faults of a shared mapping serialise too: scripts/microbench/tmpfs_write.cpp,
-    // profiles/r02_tmpfs_write.txt: 8.1 GB/s from one thread, 3.5-7.4 GB/s from sixteen).
-    struct OutBuf { std::vector<char> text, track; int64_t text_off = 0, track_off = 0; };
-    Chan<OutBuf *> out_free, out_full;
+    std::mutex am; std::condition_variable acv;   // a window's pages are there before anyone formats into them: a formatter
+                                                  // that runs ahead of the allocator would take pages one fault at a time and
+                                                  // slow the allocator down on the same file
     // window throttle
     std::mutex wm; std::condition_variable wcv; int windows_alive = 0;
   };
 
-static void pwrite_all(int fd, const char *buf, size_t n, int64_t off)
+[[maybe_unused]] static void pwrite_all(int fd, const char *buf, size_t n, int64_t off)
 { while (n > 0)
     { ssize_t w = pwrite(fd,buf,n,(off_t)off);
       if (w <= 0) die("%s: write to the output failed\n",PROG);
@@ -397,23 +418,17 @@ struct Device
         }
     }
 
-    // records of the batch (ClassPro.c:215,289; tracks: ClassPro.c:217-223,290-304) formatted into an output
-    // buffer that the writer thread puts at its final offset
+    // records of the batch at their final offsets (ClassPro.c:215,289; tracks: ClassPro.c:217-223,290-304)
     void write_out(Slot &b)
     { const Window &w = *b.job.w;
       const size_t r0 = b.job.r0, nrec = b.job.r1-r0;
-      Run::OutBuf *ob;
-      if (!R->out_free.pop(ob)) return;
-      ob->text_off = w.out_off[r0];
-      ob->text.resize((size_t)(w.out_off[r0+nrec]-w.out_off[r0]));
-      if (R->is_db)
-        { ob->track_off = w.trk_off[r0];
-          ob->track.resize((size_t)(w.trk_off[r0+nrec]-w.trk_off[r0]));
-        }
+      { std::unique_lock<std::mutex> lk(R->am);
+        R->acv.wait(lk,[&] { return w.allocated; });
+      }
       const int64_t blk = 64;
       R->pool->parallel_for(((int64_t)nrec+blk-1)/blk,[&](int64_t t)
         { const size_t a = (size_t)(t*blk), z = std::min(nrec,(size_t)((t+1)*blk));
-          char *o = ob->text.data()+(w.out_off[r0+a]-ob->text_off);
+          char *o = w.out_at(w.out_off[r0+a]);
           for (size_t q = a; q < z; q++)
             { const FxRec &r = w.recs[r0+q];
               *o++ = '@';
@@ -433,7 +448,7 @@ struct Device
               if (lab) memcpy(o,lab,r.rlen); else memset(o,'N',r.rlen);
               if (R->is_db)                                       // Compress_Read of the state codes, E=0 R=1 H=2 D=3
                 { const char *trk = (R->seeds && i >= 0) ? b.h_seed+b.h_soff[i] : o;   // -s: the seed labels (ClassPro.c:293)
-                  unsigned char *d = (unsigned char *)ob->track.data()+(w.trk_off[r0+q]-ob->track_off);
+                  unsigned char *d = (unsigned char *)w.trk_at(w.trk_off[r0+q]);
                   const uint32_t nby = (r.rlen+3) >> 2;
                   for (uint32_t y = 0; y < nby; y++)
                     { unsigned v = 0;
@@ -448,7 +463,6 @@ struct Device
               *o++ = '\n';
             }
         });
-      R->out_full.push(ob);
     }
   };
 
@@ -597,20 +611,21 @@ int main(int argc, char **argv)
       D.back()->start(&R,devs[(size_t)d],d);        // HIP start-up, tables and buffers come up while the input is indexed
     }
 
-  Run::OutBuf outbufs[3];
-  for (auto &o : outbufs) R.out_free.push(&o);
-  double t_pwrite = 0.;
-  std::thread writer([&]
-    { Run::OutBuf *ob;
-      while (R.out_full.pop(ob))
-        { const tp_t t0 = now();
-          pwrite_all(R.out_fd,ob->text.data(),ob->text.size(),ob->text_off);
-          if (R.trk_fd >= 0 && !ob->track.empty()) pwrite_all(R.trk_fd,ob->track.data(),ob->track.size(),ob->track_off);
-          t_pwrite += secs(t0,now());
-          R.out_free.push(ob);
+  // the allocator thread: gives every window's stretch of the output its pages, in order, as soon as it is indexed
+  Chan<std::shared_ptr<Window>> to_allocate;
+  double t_alloc = 0.;
+  std::thread allocator([&]
+    { std::shared_ptr<Window> w;
+      while (to_allocate.pop(w))
+        { const tp_t t0 = now();                      // (a file system without fallocate: the pages come at first touch)
+          if (w->out_hi > w->out_lo) (void)fallocate(R.out_fd,0,(off_t)w->out_lo,(off_t)(w->out_hi-w->out_lo));
+          if (w->trk_hi > w->trk_lo) (void)fallocate(R.trk_fd,0,(off_t)w->trk_lo,(off_t)(w->trk_hi-w->trk_lo));
+          t_alloc += secs(t0,now());
+          { std::lock_guard<std::mutex> lk(R.am); w->allocated = true; }
+          R.acv.notify_all();
+          w.reset();
         }
     });
-
 
   R.out_fd = open(out_path.c_str(),O_RDWR|O_CREAT|O_TRUNC,0644);
   if (R.out_fd < 0) die("Cannot open %s\n",out_path.c_str());
@@ -724,6 +739,11 @@ int main(int argc, char **argv)
         }
       w->out_off[nrec] = out_pos;
       if (is_db) w->trk_off[nrec] = trk_pos;
+      if (nrec > 0)
+        { w->map_out(R.out_fd,w->out_off[0],out_pos,false);
+          if (is_db) w->map_out(R.trk_fd,w->trk_off[0],trk_pos,true);
+          to_allocate.push(w);
+        }
       t_index += secs(ti,now());
 
       // contiguous ranges per device, balanced by bases; batches inside a range
@@ -758,9 +778,9 @@ int main(int argc, char **argv)
   if (next_id != R.P.nreads && !is_db)
     die("Inconsistent # of reads: .prof (%lld) != input (%lld)\n",(long long)R.P.nreads,(long long)next_id);
   for (auto &d : D) d->in.close();
+  to_allocate.close();
+  allocator.join();
   for (auto &d : D) { d->feeder.join(); d->completer.join(); }
-  R.out_full.close();
-  writer.join();
   if (ftruncate(R.out_fd,(off_t)out_pos) != 0) die("%s: cannot size the output\n",PROG);
   close(R.out_fd);
   if (R.trk_fd >= 0) { if (ftruncate(R.trk_fd,(off_t)trk_pos) != 0) die("%s: cannot size the track\n",PROG); close(R.trk_fd); }
@@ -785,8 +805,8 @@ int main(int argc, char **argv)
       fprintf(stderr,"\nResources for phase:  %.3f (s) wall, %.1f Mbases classified (%.1f Mbases/s end to end)\n",
               s,R.total_bases.load()/1e6,R.total_bases.load()/1e6/s);
       fprintf(stderr,"    host: %d device shard(s), %d host threads; %.3f s set-up, %.3f s indexing the input, %.3f s staging, "
-                     "%.3f s waiting for the device, %.3f s formatting (summed over the pipeline threads), %.3f s in write(2)\n",
-              ndev,nthreads,t_setup,t_index,R.t_stage_us.load()/1e6,R.t_wait_us.load()/1e6,R.t_write_us.load()/1e6,t_pwrite);
+                     "%.3f s waiting for the device, %.3f s formatting in place (summed over the pipeline threads); %.3f s in fallocate (its own thread)\n",
+              ndev,nthreads,t_setup,t_index,R.t_stage_us.load()/1e6,R.t_wait_us.load()/1e6,R.t_write_us.load()/1e6,t_alloc);
     }
   // the results are on file: leave without tearing down the HIP runtime and 10+ GB of pinned / device buffers
   fflush(stderr);
