@@ -90,3 +90,36 @@ def test_fastq_and_gz_inputs(cli_set):
     os.rename(os.path.join(d, "readsq.fastq"), os.path.join(d, "readsq.fastq.bak"))
     got, _ = _run(cli, d, "readsq.fastq.gz", 3, "0,0", 350, 500)
     assert got == exp
+
+
+def test_tiny_inputs(torch_dev, tmp_path):
+    """One read; only reads shorter than K (printed with N labels, nothing goes to the device); more threads and shards
+    than reads."""
+    from classpro_amd import synth, fastk, build
+    from classpro_amd.api import hist_covs
+    from oracle.oracle import Oracle
+    d = str(tmp_path)
+    ds = synth.make_dataset(genome_len=60000, cov=30, read_len=5000, seed=5)
+    cli = os.path.join(os.path.dirname(build.OUT), "ClassPro")
+    low, high, il, ih, h = ds["hist"]
+    hc, dc = hist_covs(h, low, high, il, ih, 0)
+    O = Oracle(K, 20000, hc, dc)
+    # one read
+    s0, p0 = ds["seqs"][0], ds["profiles"][0]
+    open(os.path.join(d, "one.fa"), "wb").write(b">solo\n" + s0 + b"\n")
+    fastk.write_fastk(d, "one", K, [p0], ds["hist"], nparts=1)
+    got, _ = _run(cli, d, "one.fa", 8, "0,0,0")
+    assert got == b"@solo (null)\n" + s0 + b"\n+\n" + O.classify_read(s0, p0) + b"\n"
+    # only short reads
+    shorts = [b"ACGT", b"A" * 39, b"C"]
+    with open(os.path.join(d, "short.fa"), "wb") as f:
+        for i, s in enumerate(shorts):
+            f.write(b">s%d x\n" % i + s + b"\n")
+    fastk.write_fastk(d, "short", K, [np.zeros(0, np.uint16)] * 3, ds["hist"], nparts=2)
+    got, _ = _run(cli, d, "short.fa", 4, "0,0")
+    assert got == b"".join(b"@s%d x\n" % i + s + b"\n+\n" + b"N" * len(s) + b"\n" for i, s in enumerate(shorts))
+    # read count mismatch between FASTA and profiles: message + exit 1 (ClassPro.c:148-154's consistency)
+    open(os.path.join(d, "two.fa"), "wb").write(b">a\n" + s0 + b"\n>b\n" + s0 + b"\n")
+    fastk.write_fastk(d, "two", K, [p0], ds["hist"], nparts=1)
+    r = subprocess.run([cli, os.path.join(d, "two.fa")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "Inconsistent # of reads" in r.stderr
