@@ -269,15 +269,20 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
 
   // ---- stage 2: find_wall ----------------------------------------------------------------------
   const int64_t ncell = total_kmers+nreads;
-  ENSURE(ws->wall,ncell);
-  ENSURE(ws->wall_s,ncell);
+  // The two flag arrays are all zero between batches: k_find_wall clears, before it ends, the few cells a read's walk
+  // touched (its candidates and the ends of its E-/O-intervals), so only a newly allocated array is filled here --
+  // not 2 x (one byte per k-mer) per batch.
+  { const size_t c0 = ws->wall.cap, c1 = ws->wall_s.cap;
+    ENSURE(ws->wall,ncell);
+    ENSURE(ws->wall_s,ncell);
+    if (ws->wall.cap != c0)   HIPCHK(hipMemsetAsync(ws->wall.p,0,ws->wall.cap,st));
+    if (ws->wall_s.cap != c1) HIPCHK(hipMemsetAsync(ws->wall_s.p,0,ws->wall_s.cap,st));
+  }
   ENSURE(ws->hkeys,(size_t)totalH*4);
   ENSURE(ws->hvals,(size_t)totalH*4*8);
   ENSURE(ws->eintvl,(size_t)totalE*sizeof(cp_eintvl));
   ENSURE(ws->ointvl,(size_t)totalE*sizeof(cp_eintvl));
   ENSURE(ws->intvl,(size_t)totalI*sizeof(cp_intvl));
-  HIPCHK(hipMemsetAsync(ws->wall.p,0,(size_t)ncell,st));
-  HIPCHK(hipMemsetAsync(ws->wall_s.p,0,(size_t)ncell,st));
   HIPCHK(hipMemsetAsync(ws->hkeys.p,0xff,(size_t)totalH*4,st));       // every slot empty (key -1)
   ENSURE(ws->perm,(size_t)nreads*4);
   ENSURE(ws->wlist,(size_t)totalI*4*4);

@@ -637,10 +637,12 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   // wl); s_res is reused as an int buffer for short lists.
   int *sbuf = reinterpret_cast<int *>(s_res);
   constexpr int SBUF = (int)(sizeof(task_res)*WAVE/sizeof(int));      // 512 ints
+  // (the "paired by OTHERS" bit goes too: nothing reads it after the walk, and an O-pair partner that is no candidate
+  //  must be left clean for the next batch -- the O-interval list is reused as sort scratch below)
   if (lane == 0)
     for (int k = 0; k < NO; k++)
-      { wall[R.ointvl[k].b] &= ~CP_W_WALL_O;
-        wall[R.ointvl[k].e] &= ~CP_W_WALL_O;
+      { wall[R.ointvl[k].b] &= ~(CP_W_WALL_O|CP_W_PAIRED_O);
+        wall[R.ointvl[k].e] &= ~(CP_W_WALL_O|CP_W_PAIRED_O);
       }
   wave_sync();
   wave_unwall_inside(wall,clist,n_c,R.eintvl,0,NS,sbuf,SBUF/2);
@@ -786,6 +788,20 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   for (int k = lane; k < N && k < icap; k += WAVE)     // wall.c:928-946, one lane per interval
     cp_make_interval(&R,NS,k ? bnd[k-1] : 0,bnd[k],&intvl[k]);
   PH_STAMP(5);
+  // Leave the flag arrays all zero (capi.hip fills them only when they are allocated): every cell the walk and the
+  // multi-error phase wrote is a candidate position or an end of an E-interval of the final list (the ends of O-pairs
+  // were cleaned above).  A read whose lists overflowed may have unrecorded cells: its whole range is cleared.
+  wave_sync();
+  if (overflow)
+    { for (int j = lane; j <= plen; j += WAVE) { wall[j] = 0; R.wall_s[j] = 0; } }
+  else
+    { for (int q = lane; q < n_c; q += WAVE)
+        { const int i = clist[q]; wall[i] = 0; R.wall_s[i] = 0; }
+      for (int k = lane; k < NS; k += WAVE)
+        { const int b = R.eintvl[k].b, e = R.eintvl[k].e;
+          wall[b] = 0; wall[e] = 0; R.wall_s[b] = 0; R.wall_s[e] = 0;
+        }
+    }
   if (lane == 0)
     { nintvl[r] = (N > icap) ? icap : N;
       if (overflow) atomicOr(err,overflow);
