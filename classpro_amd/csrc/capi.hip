@@ -283,7 +283,6 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   ENSURE(ws->eintvl,(size_t)totalE*sizeof(cp_eintvl));
   ENSURE(ws->ointvl,(size_t)totalE*sizeof(cp_eintvl));
   ENSURE(ws->intvl,(size_t)totalI*sizeof(cp_intvl));
-  HIPCHK(hipMemsetAsync(ws->hkeys.p,0xff,(size_t)totalH*4,st));       // every slot empty (key -1)
   ENSURE(ws->perm,(size_t)nreads*4);
   ENSURE(ws->wlist,(size_t)totalI*4*4);
   // longest reads first: key = wall candidates / 4 (bins of 4 up to 4096 candidates)

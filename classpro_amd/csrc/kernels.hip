@@ -574,6 +574,13 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   if (n_t > icap) { R.overflow = 1; n_t = 0; n_c = 0; }   // cannot happen: 2*n_c <= icap
   // a pass memoises at most two entries per live candidate (its own and its low-complexity partner's)
   R.perror.use_lds = ((8*n_live0 <= 3*LCAP0) ? 1 : 0) | ((8*(n_t-n_live0) <= 3*LCAP1) ? 2 : 0);
+  // a pass whose memo does not fit on chip uses its table in HBM: empty it here (the few reads that need one), instead
+  // of a memset over every read's tables per batch
+  { const int hc = (int)R.perror.g.mask+1;
+    for (int e = 0; e < 2; e++)
+      if (!((R.perror.use_lds >> e) & 1))
+        for (int k = lane; k < hc; k += WAVE) R.perror.g.keys[(size_t)e*hc+k] = -1;
+  }
   wave_sync();
   // 1b + 2, 64 tasks at a time: lane k evaluates task k and leaves the result in LDS; then the chunk is
   //    replayed in order, lane 0 taking the SELF tasks and lane 1 the OTHERS tasks (one lane active per task;
