@@ -366,6 +366,45 @@ def extra_rates(a, ds, clf, batches, hcov, dcov, dev, stream):
     ex["pcie_inclusive_pinned_codes_mbases_per_s"] = round(bm.total_bases / min(ts) / 1e6, 1)
     ex["code_bytes_per_base"] = round(len(codes) / bm.total_bases, 4)
     ex["decode_matches"] = bool(torch.equal(d_prof[:bm.total_kmers], bm.prof[:bm.total_kmers]))
+    # the same transfers with three batches in flight (own stream, workspace and buffers each), as the command line
+    # keeps them: H2D of batch k+1 and D2H of batch k-1 overlap the kernels of batch k.  Sustained rate over 12 batches.
+    try:
+        NS = 3
+        sl = []
+        for _ in range(NS):
+            w = C.c_void_p()
+            check(L.cp_workspace_create(C.byref(w)))
+            sl.append(dict(st=torch.cuda.Stream(dev), ws=w, d_seq=torch.empty_like(bm.seq), d_code=torch.empty(len(codes), dtype=torch.uint8, device=dev),
+                           d_prof=torch.empty_like(bm.prof), d_lab=torch.empty_like(bm.labels),
+                           h_lab=torch.empty(bm.total_bases, dtype=torch.uint8).pin_memory()))
+
+        def run(nb):
+            for i in range(nb):
+                q = sl[i % NS]
+                q["st"].synchronize()                       # the slot's previous batch has left
+                with torch.cuda.stream(q["st"]):
+                    sp = C.c_void_p(q["st"].cuda_stream)
+                    q["d_seq"].copy_(h_seq, non_blocking=True)
+                    q["d_code"].copy_(h_code, non_blocking=True)
+                    check(L.cp_decode_profiles(q["ws"], q["d_code"].data_ptr(), d_coff.data_ptr(), bm.prof_off.data_ptr(), bm.nreads,
+                                               q["d_prof"].data_ptr(), sp))
+                    check(L.cp_classify_batch(clf.p, q["ws"], q["d_seq"].data_ptr(), bm.seq_off.data_ptr(), q["d_prof"].data_ptr(),
+                                              bm.prof_off.data_ptr(), bm.nreads, bm.total_bases, bm.total_kmers, q["d_lab"].data_ptr(), sp))
+                    q["h_lab"].copy_(q["d_lab"][:bm.total_bases], non_blocking=True)
+            torch.cuda.synchronize()
+        run(NS)
+        t0 = time.perf_counter()
+        run(12)
+        dt3 = time.perf_counter() - t0
+        for q in sl:
+            check(L.cp_workspace_check(q["ws"]))
+        ex["pcie_inclusive_3_in_flight_mbases_per_s"] = round(12 * bm.total_bases / dt3 / 1e6, 1)
+        ex["pcie_3_in_flight_labels_match"] = bool(all(np.array_equal(q["h_lab"].numpy(), h_lab.numpy()) for q in sl))
+        for q in sl:
+            L.cp_workspace_destroy(q["ws"])
+        del sl
+    except Exception as e:
+        ex["pcie_3_in_flight_error"] = repr(e)[:200]
     del m, rdm, bm, d_prof, h_seq, h_code, h_lab
 
     # BASELINE configs[4] stand-in: 60x, r=25000, with the -s seed path (cp_find_seeds_batch after the classification)
