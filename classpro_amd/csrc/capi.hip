@@ -118,7 +118,7 @@ struct dbuf { void *p; size_t cap; };
 struct cp_workspace
   { dbuf bitmap, ncand, nintvl, nrel, ioff, eoff, hoff, wall, wall_s, hkeys, hvals, eintvl, ointvl, intvl, rintvl,
          relmap, parent, eff, rpos, asgn, ord, err, memo_val, memo_key, perm, wlist, err2,
-         s_cap, s_rcap, s_dummy, s_key, s_seg, s_aux, s_mi, s_bins, s_rep, s_repcnt, s_todo;
+         s_cap, s_rcap, s_dummy, s_key, s_seg, s_aux, s_mi, s_rep, s_repcnt;
     int64_t *h_totals;        // pinned: [totalI, totalE, totalH]
     int32_t *h_err;           // pinned
     // shape of the last run
@@ -169,7 +169,7 @@ extern "C" void cp_workspace_destroy(cp_workspace *ws)
   dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
                   &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
                   &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist,&ws->err2,
-                  &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_bins,&ws->s_rep,&ws->s_repcnt,&ws->s_todo };
+                  &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_rep,&ws->s_repcnt };
   for (dbuf *b : all) if (b->p) (void)hipFree(b->p);
   if (ws->aux) (void)hipStreamDestroy(ws->aux);
   if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
@@ -184,7 +184,7 @@ extern "C" size_t cp_workspace_bytes(const cp_workspace *ws)
   const dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
                         &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
                         &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist,&ws->err2,
-                  &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_bins,&ws->s_rep,&ws->s_repcnt,&ws->s_todo };
+                  &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_rep,&ws->s_repcnt };
   size_t s = 0;
   for (const dbuf *b : all) s += b->cap;
   return s;
@@ -497,26 +497,18 @@ extern "C" int cp_find_seeds_batch(const cp_params *p, cp_workspace *ws, const c
   HIPCHK(hipStreamSynchronize(st));
   const int64_t totalS = ws->h_totals[0], totalR = ws->h_totals[1];
   ws->seed_totalR = totalR;
-  ENSURE(ws->s_seg,(size_t)totalS*4*4);
+  ENSURE(ws->s_seg,(size_t)totalS*6*4);
   ENSURE(ws->s_aux,(size_t)totalS*2*4);
   ENSURE(ws->s_mi,((size_t)totalS+3*(size_t)nreads)*2*4);
-  ENSURE(ws->s_bins,(size_t)nreads*(CP_SEED_BINS+1)*4);
   ENSURE(ws->s_rep,(size_t)totalR*2*4+16);
-  ENSURE(ws->s_todo,((size_t)nreads+1)*4);
   HIPCHK(hipMemsetAsync(d_seeds,'E',(size_t)total_bases,st));
-  HIPCHK(hipMemsetAsync(ws->s_todo.p,0,4,st));
   hipLaunchKernelGGL(k_seed_prefix,dim3(nreads),dim3(WAVE),0,st,d_seq_off,K,nreads,d_seeds);
-  // longest reads first, reads of similar length in one wave: key = plen / 64
+  // longest reads first: key = plen / 64
   hipLaunchKernelGGL(k_order_by_work,dim3(1),dim3(1024),0,st,(const int32_t *)ws->s_key.p,nreads,6,(int32_t *)ws->perm.p);
-  // the flat form for every read (cp_seed.h), then the plain form for the reads it handed back (s_todo[0] = how many)
-  hipLaunchKernelGGL(k_find_seeds_fast,dim3((nreads+WAVE-1)/WAVE),dim3(WAVE),0,st,d_seq,d_seq_off,d_prof,d_prof_off,d_labels,K,nreads,
+  hipLaunchKernelGGL(k_find_seeds,dim3(nreads),dim3(WAVE),0,st,d_seq,d_seq_off,d_prof,d_prof_off,d_labels,K,nreads,
                      (const int64_t *)ws->s_cap.p,(const int64_t *)ws->s_rcap.p,(const int32_t *)ws->perm.p,
                      (int32_t *)ws->s_seg.p,(int32_t *)ws->s_aux.p,(int32_t *)ws->s_mi.p,
-                     (int32_t *)ws->s_rep.p,(int32_t *)ws->s_repcnt.p,d_seeds,(int32_t *)ws->s_todo.p+1,(int32_t *)ws->s_todo.p,totalS);
-  hipLaunchKernelGGL(k_find_seeds,dim3((nreads+WAVE-1)/WAVE),dim3(WAVE),0,st,d_seq,d_seq_off,d_prof,d_prof_off,d_labels,K,nreads,
-                     (const int64_t *)ws->s_cap.p,(const int64_t *)ws->s_rcap.p,(const int32_t *)ws->s_todo.p+1,
-                     (int32_t *)ws->s_seg.p,(int32_t *)ws->s_aux.p,(int32_t *)ws->s_mi.p,(int32_t *)ws->s_bins.p,
-                     (int32_t *)ws->s_rep.p,(int32_t *)ws->s_repcnt.p,d_seeds,(int32_t *)ws->err.p,totalS,(const int32_t *)ws->s_todo.p);
+                     (int32_t *)ws->s_rep.p,(int32_t *)ws->s_repcnt.p,d_seeds,(int32_t *)ws->err.p,totalS);
   HIPCHK(hipGetLastError());
   return CP_OK;
 }

@@ -1,0 +1,578 @@
+// cp_seed_wave.h -- the `-s` seed path of the reference (src/seed.c:966-1032, find_seeds) on the device, ONE WAVE PER
+// READ (device only; included by kernels.hip).
+//
+// What the reference computes per read, from the label string, the count profile and the bases:
+//   * anno_repeat (seed.c:482-592): a k-mer position is "unique" when it lies in a maximal stretch of non-R labels
+//     that holds at least 2.5 K H/D positions, otherwise "repetitive"; the repetitive stretches, in read coordinates,
+//     are the intervals of the .rep mask track;
+//   * three seed selections that share one masked-interval list: count MAXimizers among the H-labelled and among the
+//     D-labelled k-mers (_find_seeds, seed.c:190-476, window 1000), count MINimizers among the non-E k-mers of the
+//     repetitive stretches (_find_seeds_rep, seed.c:667-951, window 200).  A selection compresses the profile into
+//     segments of equal count (compress_profile, seed.c:61-110 / :599-665), gives every segment the number of windows
+//     in which it is the extreme one (a monotone deque), visits the segments by decreasing window count and marks the
+//     sequence minimizers (canonical ntHash, src/nthash.h) of the segments it takes as seeds;
+//   * the result per k-mer: 'E' (no seed) or the class of the seed ('H', 'D', or 'R' for a repeat seed),
+//     seed.c:1007-1015 -- what the .class.data track carries under -s (ClassPro.c:293).
+//
+// Who does what in the wave:
+//   * all 64 lanes: the per-position work.  256 k-mer positions are loaded coalesced per step; run boundaries, the
+//     selection's valid flags and from them the SEGMENT STARTS come out of three ballots per 64 positions in closed
+//     form (a position starts a segment iff it is the first valid k-mer of its run of equal counts, or it begins a run
+//     whose predecessor run held a valid k-mer, or it is position 0): no walk over the positions.  Label runs for
+//     anno_repeat, the stable radix sort by window count (ballot ranks), the group tests against the masked-interval
+//     list (64 sorted segments at once) and the ntHash of a taken segment's k-mers (a lane per k-mer over a table of
+//     pre-rotated seeds in LDS, wave minimum) are wave-parallel too.
+//   * lane 0: the one inherently sequential chain -- the monotone deque that gives every segment its window count --
+//     with its state on chip: the deque's two ends in registers, the ring in LDS.
+//   * the masked-interval list is restated slot for slot: the reference searches and sorts one slot past the live part
+//     of that array (seed.c:141,161-166), so its leftovers matter; the defined behaviour is that the array
+//     is all zeros when a read starts.
+// Nothing is bounded by the on-chip sizes: a deque deeper than the ring, a list longer than SW_MI, more than SW_REP
+// repetitive stretches, a group with more than SW_PEND members to take move to (or are flagged in) the read's HBM
+// scratch and the same code goes on there.
+#pragma once
+#include "cp_seed.h"
+
+#define SW_DQ    128
+#define SW_MI    512
+#define SW_PEND  64
+#define SW_REP   64
+#define SW_KMAX  64                              // k-mer lengths served by the rotated-seed table (longer: byte-wise fold)
+#define SW_STEP  4                               // chunks of 64 positions per load step
+
+struct cp_seedw_lds
+  { int4     dq[SW_DQ];                          // deque ring: (segment, count, begin, end)
+    int32_t  mi_b[SW_MI], mi_e[SW_MI];           // masked-interval list while it fits
+    int32_t  cval[SW_STEP*WAVE];                 // per position: the count if the k-mer is valid, else -1; base classes for the hash
+    int32_t  bins[32];
+    int32_t  pend_b[SW_PEND], pend_e[SW_PEND];
+    int32_t  rep[2*SW_REP];                      // repetitive stretches in k-mer coordinates while they fit
+    uint64_t rot[5*SW_KMAX];                     // rot[c*SW_KMAX+k] = seed of base class c rotated k times (c = 4: zero)
+  };
+
+__shared__ cp_seedw_lds sw_S;                    // the wave's LDS block (one wave per workgroup)
+
+struct cp_seedw_read
+  { const char *seq, *cls; const uint16_t *prof; char *state;
+    int plen, K, cap, rep_cap;
+    int32_t *seg_b, *seg_e, *seg_nw, *ob, *oe, *onw, *tmp, *order;      // cap slots each
+    int32_t *gmi_b, *gmi_e;                                             // cap+3 slots each
+    int32_t *rep_pairs;
+    int32_t *err;                                                       // bit 4: a read needed more segments than its scratch holds
+  };
+
+#ifdef CP_SEED_PROF
+#define SW_STAMP(k) do { if (lane == 0) { unsigned long long t_ = wall_clock64(); sw_t[k] += t_-sw_last; sw_last = t_; } } while (0)
+#define SW_PROF_ARGS , unsigned long long *sw_t, unsigned long long &sw_last
+#define SW_PROF_PASS , sw_t, sw_last
+#else
+#define SW_STAMP(k) ((void)0)
+#define SW_PROF_ARGS
+#define SW_PROF_PASS
+#endif
+
+__device__ __forceinline__ int sw_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// k applications of cp_nt_srol (nthash.h:181-207: rol1, then bits 0 and 33 swapped) = the low 33 bits and the high 31
+// bits each rotated left by k within themselves
+__device__ __forceinline__ uint64_t sw_srol_k(uint64_t v, int k)
+{ const uint64_t lo = v & 0x1ffffffffull, hi = v >> 33;
+  const int a = k % 33, b = k % 31;
+  const uint64_t l2 = a ? (((lo << a) | (lo >> (33-a))) & 0x1ffffffffull) : lo;
+  const uint64_t h2 = b ? (((hi << b) | (hi >> (31-b))) & 0x7fffffffull) : hi;
+  return l2 | (h2 << 33);
+}
+
+// ---- the masked-interval list (seed.c:120-188), in LDS or (big) in the read's HBM scratch ------------------------
+struct sw_list
+  { int32_t *gb, *ge; bool big;
+    __device__ __forceinline__ int  b(int i) const { return big ? gb[i] : sw_S.mi_b[i]; }
+    __device__ __forceinline__ int  e(int i) const { return big ? ge[i] : sw_S.mi_e[i]; }
+    __device__ __forceinline__ void set(int i, int vb, int ve) { if (big) { gb[i] = vb; ge[i] = ve; } else { sw_S.mi_b[i] = vb; sw_S.mi_e[i] = ve; } }
+    __device__ __forceinline__ void set_b(int i, int vb) { if (big) gb[i] = vb; else sw_S.mi_b[i] = vb; }
+    __device__ __forceinline__ void set_e(int i, int ve) { if (big) ge[i] = ve; else sw_S.mi_e[i] = ve; }
+  };
+// slots 0..M, M included (the reference searches one slot past the live part)
+__device__ __forceinline__ int sw_mi_find(const sw_list &Lm, int M, int b, int e)
+{ int l = 0, r = M;
+  while (l <= r)
+    { const int m = (l+r) >> 1;
+      const int mb = Lm.b(m), me = Lm.e(m);
+      if (cp_seed_ovlp(mb,me,b,e)) return m;
+      if (mb < b) l = m+1; else r = m-1;
+    }
+  return -1;
+}
+// the list outgrows LDS: all SW_MI slots move to HBM, the slots above them are zero (wave-uniform call)
+__device__ __forceinline__ void sw_mi_grow(sw_list &Lm, int cap3, int lane)
+{ __syncthreads();
+  for (int q = lane; q < cap3; q += WAVE)
+    { Lm.gb[q] = q < SW_MI ? sw_S.mi_b[q] : 0; Lm.ge[q] = q < SW_MI ? sw_S.mi_e[q] : 0; }
+  Lm.big = true;
+  __syncthreads();
+}
+// wave-uniform: every lane walks the same search (broadcast reads); slots are shifted 64 at a time
+__device__ __forceinline__ int sw_mi_add(sw_list &Lm, int M, int b, int e, int lane)
+{ const int idx = sw_mi_find(Lm,M,b,e);
+  if (idx < 0)
+    { M++;
+      __syncthreads();
+      if (lane == 0) Lm.set(M,b,e);                            // waits one slot past the sorted part
+      __syncthreads();
+      if (M >= 2)                                              // the reference's sort of slots [0,M) moves one element: slot M-1
+        { const int xb = Lm.b(M-1), xe = Lm.e(M-1);
+          int lo = 0, hi = M-1;                                // first slot whose begin is > xb (stable)
+          while (lo < hi) { const int m = (lo+hi) >> 1; if (Lm.b(m) > xb) hi = m; else lo = m+1; }
+          for (int top = M-1; top > lo; top -= WAVE)           // slots (lo,M-1] <- their left neighbours, from the top down
+            { const int i = top-lane;
+              int tb = 0, te = 0;
+              if (i > lo) { tb = Lm.b(i-1); te = Lm.e(i-1); }
+              __syncthreads();
+              if (i > lo) Lm.set(i,tb,te);
+              __syncthreads();
+            }
+          if (lane == 0) Lm.set(lo,xb,xe);
+          __syncthreads();
+        }
+      return M;
+    }
+  int l = idx-1;
+  while (l >= 0 && cp_seed_ovlp(Lm.b(l),Lm.e(l),b,e)) l--;
+  l++;
+  int r = idx+1;
+  while (r < M && cp_seed_ovlp(Lm.b(r),Lm.e(r),b,e)) r++;
+  r--;
+  const int lb = Lm.b(l), re = Lm.e(r);
+  __syncthreads();
+  if (lane == 0) { if (b < lb) Lm.set_b(l,b); Lm.set_e(l,re > e ? re : e); }
+  __syncthreads();
+  if (l == r) return M;
+  const int d = r-l;
+  M -= d;
+  for (int base = l+1; base < M; base += WAVE)                 // close the gap, from the bottom up
+    { const int i = base+lane;
+      int tb = 0, te = 0;
+      if (i < M) { tb = Lm.b(i+d); te = Lm.e(i+d); }
+      __syncthreads();
+      if (i < M) Lm.set(i,tb,te);
+      __syncthreads();
+    }
+  return M;
+}
+
+// ---- minimum canonical hash over the k-mers [b,e) and a mark on every k-mer that attains it (seed.c:392-397) -------
+// 64 k-mers at a time, a lane each: the bases' seed classes go to LDS once, then K steps of two table look-ups
+// (the forward strand's seed rotated K-1-t times, the reverse strand's rotated t times: nthash.h:215-235 unrolled)
+__device__ __attribute__((noinline)) void sw_mark(const cp_seedw_read &R, int b, int e, bool rep, int lane)
+{ const int K = R.K;
+  if (e-b == 1) { if (lane == 0) R.state[b] = rep ? 'R' : R.cls[b]; return; }
+  const bool table = K <= SW_KMAX;
+  int mh = CP_SEED_MOD, h = CP_SEED_MOD;
+  for (int pass = 0; pass < 2; pass++)                        // minimum first, marks second
+    { for (int base = b; base < e; base += WAVE)
+        { const int j = base+lane;
+          h = CP_SEED_MOD;
+          if (table)
+            { __syncthreads();
+              for (int q = lane; q < WAVE+K-1; q += WAVE)      // seed classes of the bases base .. base+63+K-1
+                { int code = 4 | (4 << 3);
+                  if (base+q < R.plen+K-1)
+                    { const unsigned c = (unsigned char)R.seq[base+q];
+                      int f = 4, r = 4;
+                      switch (c)                               // seedTab, nthash.h:26-59
+                        { case 'A': case 'a': case 4: case 5: f = 0; break;
+                          case 'C': case 'c': case 7: f = 1; break;
+                          case 'G': case 'g': case 3: f = 2; break;
+                          case 'T': case 't': case 'U': case 'u': case 1: f = 3; break;
+                        }
+                      switch (c & 7u)                          // seedTab[c & cpOff], nthash.h:17,226-235: the complement's seed
+                        { case 1: r = 3; break;
+                          case 3: r = 2; break;
+                          case 4: case 5: r = 0; break;
+                          case 7: r = 1; break;
+                        }
+                      code = f | (r << 3);
+                    }
+                  sw_S.cval[q] = code;
+                }
+              __syncthreads();
+              if (j < e)
+                { uint64_t fh = 0, rh = 0;
+                  for (int t = 0; t < K; t++)
+                    { const int code = sw_S.cval[lane+t];
+                      fh ^= sw_S.rot[(code & 7)*SW_KMAX+(K-1-t)];
+                      rh ^= sw_S.rot[(code >> 3)*SW_KMAX+t];
+                    }
+                  h = (int)((rh < fh ? rh : fh) % CP_SEED_MOD);
+                }
+            }
+          else if (j < e) h = cp_kmer_hash(R.seq,j,K);
+          if (pass == 0) mh = h < mh ? h : mh;
+          else if (j < e && h == mh) R.state[j] = rep ? 'R' : R.cls[j];
+        }
+      if (pass == 0)
+        { for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(mh,o); mh = x < mh ? x : mh; }
+          if (e-b <= WAVE)                                     // one chunk: its hashes are still in hand
+            { if (b+lane < e && h == mh) R.state[b+lane] = rep ? 'R' : R.cls[b+lane];
+              break;
+            }
+        }
+    }
+}
+
+// ---- one selection (seed.c:190-476 with C = 'H'/'D'; seed.c:667-951 with C = 0) --------------------------------------
+__device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, int C, int nrep, bool rep_big, int lane
+                                          SW_PROF_ARGS)
+{ const bool rep = (C == 0);
+  const int W = rep ? CP_SEED_W_REP : CP_SEED_W;
+  const int plen = R.plen, Km1 = R.K-1;
+  const uint64_t lt = (1ull << lane)-1;
+  // ---- lane 0's chain: the monotone deque over the segments (seed.c:218-324 / :694-810) ----
+  // entries are addressed by their running number p (qf .. qf+qn-1): ring slot p % SW_DQ, or, once the deque got deeper
+  // than the ring, slot p of four idle HBM arrays.  The front entry and the back entry's (segment, count) sit in registers.
+  int n = 0, M = 0, nbig = 0;
+  int qf = 0, qn = 0; bool last_oor = false; int last_oor_pos = 0;
+  bool spilled = false, grow = false, full = false;
+  int4 F = make_int4(0,0,0,0); int Bn = 0, Bc = 0;
+  auto dq_get = [&](int p) -> int4 { return spilled ? make_int4(R.tmp[p],R.order[p],R.ob[p],R.oe[p]) : sw_S.dq[p & (SW_DQ-1)]; };
+  auto dq_put = [&](int p, int4 v)
+    { if (spilled) { R.tmp[p] = v.x; R.order[p] = v.y; R.ob[p] = v.z; R.oe[p] = v.w; } else sw_S.dq[p & (SW_DQ-1)] = v; };
+  auto beats = [&](int a, int c) -> bool { return rep ? (a < c) : (a > c); };
+  // a displaced segment that was not the front gets its count (H/D) or W_REP - count (repeats) as a stand-in
+  auto standin = [&](int c) -> int { const int v = rep ? (CP_SEED_W_REP-c > 0 ? CP_SEED_W_REP-c : 0) : c; nbig += v > 1000; return v; };
+  auto expire = [&]() -> int4                                // the front leaves the window (or the read ends): its count of windows
+    { int v = W;
+      if (last_oor) { v = F.z-last_oor_pos+1; if (v > W) v = W; }
+      R.seg_nw[F.x] = v;
+      return qn > 1 ? dq_get(qf+1) : F;
+    };
+  auto feed = [&](int sb, int se, int sc)                    // segment n = [sb,se), count sc (-1: a skipped stretch)
+    { if (n >= R.cap) { full = true; return; }             // (k_seed_caps sizes the scratch; reported, never written past)
+      R.seg_b[n] = sb; R.seg_e[n] = se; R.seg_nw[n] = (sc < 0) ? -10 : 0;
+      if (sc < 0)                                            // skipped stretches are masked from the start
+        { if (!Lm.big && M+4 >= SW_MI) grow = true;          // no room on chip: they are listed again, in HBM, after the pass
+          if (!grow) Lm.set(M,sb,se);
+          M++;
+        }
+      else
+        { if (qn > 0 && beats(sc,F.y))                       // the whole deque goes
+            { last_oor = false;
+              for (int j = 0; j < qn; j++)
+                { const int4 t = dq_get(qf+j);
+                  int v;
+                  if (t.y == F.y) { v = sb-t.z; if (v > W) v = W; }
+                  else v = standin(t.y);
+                  R.seg_nw[t.x] = v;
+                }
+              qn = 0;
+            }
+          else
+            while (qn > 0 && beats(sc,Bc))
+              { R.seg_nw[Bn] = standin(Bc);
+                qn--;
+                if (qn > 0) { const int4 t = dq_get(qf+qn-1); Bn = t.x; Bc = t.y; }
+              }
+          if (!spilled && qn >= SW_DQ)                       // deeper than the ring: the deque moves to HBM
+            { for (int j = 0; j < qn; j++)
+                { const int4 t = sw_S.dq[(qf+j) & (SW_DQ-1)]; R.tmp[qf+j] = t.x; R.order[qf+j] = t.y; R.ob[qf+j] = t.z; R.oe[qf+j] = t.w; }
+              spilled = true;
+            }
+          const int4 t = make_int4(n,sc,sb,se);
+          dq_put(qf+qn,t);
+          if (qn == 0) F = t;
+          Bn = n; Bc = sc;
+          qn++;
+        }
+      while (qn > 0 && F.z <= sb-W)
+        { const int4 nx = expire();
+          if (qn > 1 && beats(F.y,nx.y)) last_oor_pos = F.w;
+          F = nx; qf++; qn--;
+          last_oor = true;
+        }
+      n++;
+    };
+  // ---- segments (all lanes; seed.c:61-110 / :599-665 in closed form) handed to the deque (lane 0) ----
+  // valid(i): the k-mer takes part in this selection.  A valid segment is a run of equal counts from its first valid
+  // k-mer on (it may run on over k-mers of other classes); the k-mers skipped between segments form invalid ones.
+  // A segment that would start at the last k-mer is never made (the reference's loop ends first).
+  { bool carry = false;                                      // the run entering the chunk already holds a valid k-mer
+    int ob = 0, oc = 0; bool open = false;                   // lane 0: the segment whose end is not known yet
+    for (int e0 = 0; e0 < plen; e0 += SW_STEP*WAVE)
+      { int cnt[SW_STEP], cpv[SW_STEP]; char cl[SW_STEP], st[SW_STEP];
+#pragma unroll
+        for (int u = 0; u < SW_STEP; u++)                    // all loads of the step first
+          { const int p = e0+u*WAVE+lane;
+            const bool in = p < plen;
+            cnt[u] = in ? (int)R.prof[p] : 0;
+            cpv[u] = (in && p > 0) ? (int)R.prof[p-1] : -1;
+            cl[u] = in ? R.cls[p] : (char)0;
+            st[u] = (in && rep) ? R.state[p] : (char)'E';
+          }
+        uint64_t sm[SW_STEP];
+#pragma unroll
+        for (int u = 0; u < SW_STEP; u++)
+          { const int p = e0+u*WAVE+lane;
+            const bool in = p < plen;
+            const bool bnd = in && cnt[u] != cpv[u];
+            bool v = false;
+            if (in)
+              { if (!rep) v = cl[u] == (char)C;
+                else if (cl[u] != 'E' && st[u] == 'E')       // a non-E k-mer without a seed yet, inside a repetitive stretch
+                  { int lo = 0, hi = nrep;                   // first stretch that ends beyond p
+                    while (lo < hi)
+                      { const int m = (lo+hi) >> 1;
+                        const int re = rep_big ? R.rep_pairs[2*m+1]-Km1 : sw_S.rep[2*m+1];
+                        if (re <= p) lo = m+1; else hi = m;
+                      }
+                    v = lo < nrep && (rep_big ? R.rep_pairs[2*lo]-Km1 : sw_S.rep[2*lo]) <= p;
+                  }
+              }
+            const uint64_t bm = __ballot(bnd), vm = __ballot(v);
+            const uint64_t le = lt | (1ull << lane);
+            bool first_valid = false, prev_has = false;
+            if (v)
+              { const uint64_t bb = bm & le;                 // my run starts at the highest boundary at or below me
+                if (bb) { const int rb = 63-__clzll((long long)bb); first_valid = (vm & lt & ~((1ull << rb)-1)) == 0; }
+                else first_valid = !carry && (vm & lt) == 0;
+              }
+            if (bnd)
+              { const uint64_t bb = bm & lt;                 // the run before mine
+                if (bb) { const int rb = 63-__clzll((long long)bb); prev_has = (vm & lt & ~((1ull << rb)-1)) != 0; }
+                else prev_has = carry || (vm & lt) != 0;
+              }
+            sm[u] = __ballot(in && (p == 0 || first_valid || (bnd && prev_has)));
+            if (bm) { const int top = 63-__clzll((long long)bm); carry = (vm & ~((1ull << top)-1)) != 0; }
+            else carry = carry || vm != 0;
+            sw_S.cval[u*WAVE+lane] = v ? cnt[u] : -1;
+          }
+        __syncthreads();
+        if (lane == 0)
+#pragma unroll
+          for (int u = 0; u < SW_STEP; u++)
+            { uint64_t m = sm[u];
+              while (m)
+                { const int j = __ffsll((long long)m)-1;
+                  m &= m-1;
+                  const int s = e0+u*WAVE+j;
+                  if (open) feed(ob,s,oc);
+                  ob = s; oc = sw_S.cval[u*WAVE+j]; open = true;
+                }
+            }
+        __syncthreads();
+      }
+    if (lane == 0)
+      { if (open && ob < plen-1) feed(ob,plen,oc);
+        while (qn > 0)                                       // end of the read; both selections compare with `>` here
+          { const int4 nx = expire();
+            if (qn > 1 && F.y > nx.y) last_oor_pos = F.w;
+            F = nx; qf++; qn--;
+            last_oor = true;
+          }
+      }
+  }
+  __syncthreads();                                           // lane 0's segment records are visible to the wave
+  if (sw_first(full ? 1 : 0)) { if (lane == 0) atomicOr(R.err,4); return; }
+  n = sw_first(n); nbig = sw_first(nbig); M = sw_first(M);   // wave-uniform from here on
+  if (sw_first(grow ? 1 : 0))                                // the skipped stretches did not fit on chip: the list moves to HBM
+    { sw_mi_grow(Lm,R.cap+3,lane);                           // (slots not yet rewritten keep the earlier selections' leftovers)
+      int k = 0;
+      for (int base = 0; base < n; base += WAVE)             // and every skipped stretch is listed again, in order
+        { const int q = base+lane;
+          const bool inv = q < n && R.seg_nw[q] == -10;
+          const uint64_t im = __ballot(inv);
+          if (inv) { const int s = k+__popcll(im & lt); Lm.gb[s] = R.seg_b[q]; Lm.ge[s] = R.seg_e[q]; }
+          k += __popcll(im);
+        }
+      __syncthreads();
+    }
+  SW_STAMP(1);
+  if (M > 0 && Lm.b(0) == 0 && Lm.e(0) == plen) return;
+  // ---- stable order by decreasing window count (the reference's qsort is glibc's stable merge sort): two 5-bit radix
+  //      passes on 1000 - count (the skipped stretches, -10, come last), ranks from ballots ----
+  for (int pass = 0; pass < 2; pass++)
+    { if (lane < 32) sw_S.bins[lane] = 0;
+      __syncthreads();
+      for (int q = lane; q < n; q += WAVE)
+        { const int nw = R.seg_nw[pass ? R.tmp[q] : q];
+          atomicAdd(&sw_S.bins[((nw > 1000 ? 0 : 1000-nw) >> (5*pass)) & 31],1);
+        }
+      __syncthreads();
+      { int c = lane < 32 ? sw_S.bins[lane] : 0, incl = c;
+        for (int o = 1; o < 32; o <<= 1) { const int x = __shfl_up(incl,o); if (lane >= o) incl += x; }
+        __syncthreads();
+        if (lane < 32) sw_S.bins[lane] = incl-c;
+      }
+      __syncthreads();
+      for (int base = 0; base < n; base += WAVE)
+        { const int q = base+lane;
+          const bool act = q < n;
+          int i = 0, nw = 0, dg = 0;
+          if (act) { i = pass ? R.tmp[q] : q; nw = R.seg_nw[i]; dg = ((nw > 1000 ? 0 : 1000-nw) >> (5*pass)) & 31; }
+          uint64_t peers = __ballot(act);
+          for (int bit = 0; bit < 5; bit++)
+            { const uint64_t bmk = __ballot(act && ((dg >> bit) & 1));
+              peers &= ((dg >> bit) & 1) ? bmk : ~bmk;
+            }
+          const int rank = __popcll(peers & lt);
+          int d = 0;
+          if (act) d = sw_S.bins[dg]+rank;
+          __syncthreads();
+          if (act && rank == 0) sw_S.bins[dg] += __popcll(peers);
+          __syncthreads();
+          if (act)
+            { if (pass == 0) R.order[d] = i;
+              else { R.ob[d] = R.seg_b[i]; R.oe[d] = R.seg_e[i]; R.onw[d] = nw; }
+            }
+        }
+      __syncthreads();
+      if (pass == 0)
+        { for (int q = lane; q < n; q += WAVE) R.tmp[q] = R.order[q];
+          __syncthreads();
+        }
+    }
+  if (nbig > 0)                                              // counts above 1000 share the first key with 1000: that head is put
+    { if (lane == 0)                                         // in order by insertion (rare, short)
+        { int m = 0;
+          while (m < n && R.onw[m] >= 1000) m++;
+          for (int a = 1; a < m; a++)
+            { const int xb = R.ob[a], xe = R.oe[a], xn = R.onw[a];
+              int j = a-1;
+              while (j >= 0 && R.onw[j] < xn) { R.ob[j+1] = R.ob[j]; R.oe[j+1] = R.oe[j]; R.onw[j+1] = R.onw[j]; j--; }
+              R.ob[j+1] = xb; R.oe[j+1] = xe; R.onw[j+1] = xn;
+            }
+        }
+      __syncthreads();
+    }
+  SW_STAMP(2);
+  // ---- selection (wave-uniform control flow) ----
+  auto take = [&](int b, int e)                              // mask the segment with a margin of W, mark its hash minimizers
+    { if (!Lm.big && M+4 >= SW_MI) sw_mi_grow(Lm,R.cap+3,lane);
+      M = sw_mi_add(Lm,M,b-W > 0 ? b-W : 0,e+W < plen ? e+W : plen,lane);
+      sw_mark(R,b,e,rep,lane);
+    };
+  int pos = 0;
+  for (; pos < n; pos++)                                     // every segment that is extreme over a whole window
+    { if (R.onw[pos] < W) break;
+      take(R.ob[pos],R.oe[pos]);
+    }
+  SW_STAMP(3);
+  // Then groups of equal window count, while uncovered.  The members of a group are tested against the list as it was
+  // before the group, and the list changes only when a group with members outside it ends: so 64 records are tested
+  // at once (a lane each) against the current list; everything up to the first record found outside is settled, that
+  // record's group is tested to its end, its outside members are taken in order, and the walk resumes behind the group.
+  // (The reference looks for full coverage after every group; coverage changes only with a take, so it is looked for
+  // after the whole-window takes and after every group that took something.)
+  int npend = 0, g = 0, ovpos = -1;                          // ovpos: from this record on the group's outside members are flagged in HBM
+  bool ingroup = false, covered = M > 0 && Lm.b(0) == 0 && Lm.e(0) == plen;
+  auto flush = [&](int gend)
+    { for (int q = 0; q < npend; q++) take(sw_S.pend_b[q],sw_S.pend_e[q]);
+      if (ovpos >= 0)
+        { __syncthreads();
+          for (int q = ovpos; q < gend; q++) if (R.order[q] < 0) take(R.ob[q],R.oe[q]);
+        }
+      npend = 0; ovpos = -1; ingroup = false;
+      covered = M > 0 && Lm.b(0) == 0 && Lm.e(0) == plen;
+    };
+  while (pos < n && !covered)
+    { const int q = pos+lane;
+      const bool act = q < n;
+      const int sb = act ? R.ob[q] : 0, se = act ? R.oe[q] : 0;
+      const int nw = act ? R.onw[q] : -0x7fffffff;
+      bool outside = false;
+      if (act)
+        { const int idx = sw_mi_find(Lm,M,sb,se);
+          outside = !(idx >= 0 && Lm.b(idx) <= sb && se <= Lm.e(idx));
+        }
+      const int len = n-pos < WAVE ? n-pos : WAVE;
+      int k0 = 0;
+      if (!ingroup)
+        { const uint64_t om = __ballot(outside);
+          if (om == 0) { pos += len; continue; }
+          k0 = __ffsll((long long)om)-1;
+          g = __shfl(nw,k0);
+        }
+      // members of group g from lane k0 on: a contiguous run (the records are sorted)
+      const uint64_t notg = __ballot(!(act && nw == g)) & ~((1ull << k0)-1);
+      const int endl = notg ? __ffsll((long long)notg)-1 : WAVE;
+      const bool mine = outside && lane >= k0 && lane < endl;
+      const uint64_t pm = __ballot(mine);
+      if (ovpos < 0 && npend+__popcll(pm) > SW_PEND) ovpos = pos;
+      __syncthreads();
+      if (ovpos >= 0) { if (act) R.order[q] = mine ? -1 : 0; }      // (the order array is idle by now: flags)
+      else if (mine) { const int s = npend+__popcll(pm & lt); sw_S.pend_b[s] = sb; sw_S.pend_e[s] = se; }
+      __syncthreads();
+      if (ovpos < 0) npend += __popcll(pm);
+      if (endl == WAVE && pos+WAVE < n) { ingroup = true; pos += WAVE; continue; }      // the group runs on into the next chunk
+      pos += endl < len ? endl : len;
+      flush(pos);
+    }
+  SW_STAMP(4);
+  __syncthreads();                                           // the marks are visible to the next selection
+}
+
+// ---- the whole path for one read.  R.state holds 'E' at every k-mer on entry.  Returns the number of .rep intervals
+//      (wave-uniform); the first rep_cap of them are in R.rep_pairs. ----
+__device__ __forceinline__ int sw_find_seeds(const cp_seedw_read &R, int lane SW_PROF_ARGS)
+{ const int plen = R.plen, K = R.K, Km1 = K-1;
+  if (plen <= 0) return 0;
+  for (int q = lane; q < SW_MI; q += WAVE) { sw_S.mi_b[q] = 0; sw_S.mi_e[q] = 0; }     // defined start state of the list
+  if (K <= SW_KMAX)                                          // seeds of A C G T rotated 0..63 times (msTab of nthash.h, made on the spot)
+    for (int q = lane; q < 5*SW_KMAX; q += WAVE)
+      { const int c = q/SW_KMAX, k = q % SW_KMAX;
+        const uint64_t sd = c == 0 ? 0x3c8bfbb395c60474ull : c == 1 ? 0x3193c18562a02b4cull : c == 2 ? 0x20323ed082572324ull
+                          : c == 3 ? 0x295549f54be24456ull : 0ull;
+        sw_S.rot[q] = sw_srol_k(sd,k);
+      }
+  sw_list Lm; Lm.gb = R.gmi_b; Lm.ge = R.gmi_e; Lm.big = false;
+  // ---- unique / repetitive stretches -> .rep intervals (seed.c:482-566): label runs from a ballot, lane 0 over the runs ----
+  const int min_uniq = (int)(K*2.5);
+  int nrep = 0, rs = -1, i0 = 0, normal = 0, lrun_s = 0; bool inR = false; char lrun_c = 0;
+  auto emit = [&](int b, int e)                              // a repetitive stretch, k-mer coordinates
+    { if (nrep < R.rep_cap) { R.rep_pairs[2*nrep] = b+Km1; R.rep_pairs[2*nrep+1] = e+Km1; }      // read coordinates: the first K-1 bases belong to the first k-mer
+      if (nrep < SW_REP) { sw_S.rep[2*nrep] = b; sw_S.rep[2*nrep+1] = e; }
+      nrep++;
+    };
+  auto close_stretch = [&](int e)                            // the non-R stretch [i0,e) ends: unique if it holds >= 2.5 K H/D positions
+    { if (normal >= min_uniq) { if (rs >= 0 && rs < i0) emit(rs,i0); rs = e; }
+      else if (rs < 0) rs = i0;
+    };
+  auto label_run = [&](int s, char c, int len, bool first)   // lane 0: the label run [s,s+len) of class c
+    { if (c == 'R') { if (first) rs = 0; else if (!inR) close_stretch(s); inR = true; }
+      else
+        { if (inR || first) { i0 = s; normal = 0; inR = false; }
+          if (c == 'H' || c == 'D') normal += len;
+        }
+    };
+  for (int e0 = 0; e0 < plen; e0 += WAVE)
+    { const int p = e0+lane;
+      const bool in = p < plen;
+      const char c = in ? R.cls[p] : (char)0, cp = (in && p > 0) ? R.cls[p-1] : (char)0;
+      const uint64_t sm = __ballot(in && (p == 0 || c != cp));
+      if (sm == 0) continue;
+      __syncthreads();
+      sw_S.cval[lane] = c;
+      __syncthreads();
+      if (lane == 0)
+        { uint64_t m = sm;
+          while (m)
+            { const int j = __ffsll((long long)m)-1;
+              m &= m-1;
+              const int s = e0+j;
+              if (s > 0) label_run(lrun_s,lrun_c,s-lrun_s,lrun_s == 0);
+              lrun_s = s; lrun_c = (char)sw_S.cval[j];
+            }
+        }
+    }
+  if (lane == 0)
+    { label_run(lrun_s,lrun_c,plen-lrun_s,lrun_s == 0);
+      if (!inR) close_stretch(plen);
+      if (rs >= 0 && rs < plen) emit(rs,plen);
+    }
+  __syncthreads();
+  SW_STAMP(0);
+  nrep = sw_first(nrep);
+  const bool rep_big = nrep > SW_REP;                        // then the HBM list is searched (complete: rep_cap bounds the label runs)
+  for (int sel = 0; sel < 3; sel++)                          // H, D, then the repeats: one copy of the code
+    sw_select(R,Lm,sel == 0 ? 'H' : sel == 1 ? 'D' : 0,nrep > R.rep_cap ? R.rep_cap : nrep,rep_big,lane SW_PROF_PASS);
+  return nrep;
+}

@@ -1816,12 +1816,13 @@ k_seq_context(const char *__restrict__ seq, const int64_t *__restrict__ seq_off,
 
 
 // ---------------------------------------------------------------------------------------------
-//  -s seed path (src/seed.c:966-1032), cp_seed.h.
+//  -s seed path (src/seed.c:966-1032): cp_seed_wave.h, one wave per read.
 //  k_seed_caps: per read, the number of count runs and of label runs of its k-mers: the scratch a read's
-//  seed selection needs (segments <= count runs + label runs + 4; .rep intervals <= label runs / 2 + 2).
-//  k_find_seeds: the selection itself is a chain of short sequential steps per read (a monotone deque over
-//  ~10^4 segments, a masked-interval list searched and merged step by step), so a read is ONE lane and a wave
-//  carries 64 reads of similar length (work-ordered launch); its arrays live in HBM, walked sequentially.
+//  seed selection needs.  Segments of a selection: every count run starts at most one, every change of the valid
+//  flag inside a count run one more; the flag changes with the label and, for the repeat selection, at k-mers that
+//  already carry an H/D seed (a handful per 1000 k-mers: a taken segment masks 1000 k-mers either side of it), so
+//  count runs + label runs + plen/64 + 6 holds them with a wide margin; a read that still needs more is reported
+//  (error bit 4), never written past.  .rep intervals <= label runs / 2 + 2.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WAVE)
 k_seed_caps(const uint16_t *__restrict__ prof, const int64_t *__restrict__ prof_off, const char *__restrict__ labels,
@@ -1841,7 +1842,7 @@ k_seed_caps(const uint16_t *__restrict__ prof, const int64_t *__restrict__ prof_
     }
   for (int o = 32; o > 0; o >>= 1) { nc += __shfl_xor(nc,o); nl += __shfl_xor(nl,o); }
   if (lane == 0)
-    { scap[r] = (int64_t)nc+nl+6;
+    { scap[r] = (int64_t)nc+nl+6+plen/64;
       rcap[r] = (int64_t)(nl+1)/2+2;
       plen_key[r] = plen;
     }
@@ -1856,81 +1857,35 @@ k_seed_prefix(const int64_t *__restrict__ seq_off, int K, int nreads, char *__re
   for (int i = lane_id(); i < K-1; i += WAVE) out[i] = 'N';
 }
 
-// on-chip part of the flat form (cp_seed.h): deque ring and radix digit counters of lane `lane`, lane-interleaved
-struct cp_seed_fast_lds
-  { uint32_t *ic, *be; int32_t *bins, *pnd; int lane;
-    __device__ __forceinline__ uint32_t &dq_ic(int s) { return ic[s*WAVE+lane]; }
-    __device__ __forceinline__ uint32_t &dq_be(int s) { return be[s*WAVE+lane]; }
-    __device__ __forceinline__ int32_t  &bin(int k)   { return bins[k*WAVE+lane]; }
-    __device__ __forceinline__ int32_t  &pend(int k)  { return pnd[k*WAVE+lane]; }
-  };
-
 #ifdef CP_SEED_PROF
 __device__ unsigned long long g_seed_prof[8];
 #endif
-// The flat form for every read; a read that asks for the plain form is appended to `todo`.
-__global__ void __launch_bounds__(WAVE)
-k_find_seeds_fast(const char *__restrict__ seq, const int64_t *__restrict__ seq_off, const uint16_t *__restrict__ prof,
-                  const int64_t *__restrict__ prof_off, const char *__restrict__ labels, int K, int nreads,
-                  const int64_t *__restrict__ soff, const int64_t *__restrict__ roff, const int32_t *__restrict__ perm,
-                  int32_t *__restrict__ seg, int32_t *__restrict__ aux, int32_t *__restrict__ mi,
-                  int32_t *__restrict__ rep_pairs, int32_t *__restrict__ rep_cnt, char *__restrict__ seeds,
-                  int32_t *__restrict__ todo, int32_t *__restrict__ ntodo, int64_t totalS)
-{ __shared__ uint32_t s_ic[CP_SEED_DQ*WAVE], s_be[CP_SEED_DQ*WAVE];
-  __shared__ int32_t s_bins[32*WAVE], s_pend[CP_SEED_PEND*WAVE];
-  const int t = blockIdx.x*WAVE+threadIdx.x;
-  if (t >= nreads) return;
-  const int r = perm[t];
-  const int64_t so = seq_off[r], po = prof_off[r];
-  cp_seed_read R;
-  R.seq = seq+so; R.cls = labels+so+(K-1); R.prof = prof+po; R.plen = (int)(prof_off[r+1]-po); R.K = K;
-  R.state = seeds+so+(K-1);
-  const int64_t o = soff[r];
-  R.cap = (int)(soff[r+1]-o);
-  R.seg_b = seg+o; R.seg_e = seg+totalS+o; R.seg_cnt = seg+2*totalS+o; R.seg_nw = seg+3*totalS+o;
-  R.dq = aux+o; R.order = aux+totalS+o;
-  R.mi_b = mi+2*(o+3*(int64_t)r); R.mi_e = R.mi_b+R.cap+3;
-  R.bins = nullptr;
-  R.rep_pairs = rep_pairs+2*roff[r]; R.rep_cap = (int)(roff[r+1]-roff[r]);
-  R.overflow = 0;
-  cp_seed_fast_lds f = { s_ic, s_be, s_bins, s_pend, (int)threadIdx.x };
-#ifdef CP_SEED_PROF
-  for (int k = 0; k < 8; k++) R.prof_t[k] = 0;
-  R.prof_last = wall_clock64();
-#endif
-  const int n = cp_find_seeds_fast(R,f);
-#ifdef CP_SEED_PROF
-  if (threadIdx.x == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_seed_prof[k],R.prof_t[k]);
-#endif
-  if (n < 0) todo[atomicAdd(ntodo,1)] = r;
-  else rep_cnt[r] = n < R.rep_cap ? n : R.rep_cap;
-}
-
+#include "cp_seed_wave.h"
+// One wave per read (cp_seed_wave.h).
 __global__ void __launch_bounds__(WAVE)
 k_find_seeds(const char *__restrict__ seq, const int64_t *__restrict__ seq_off, const uint16_t *__restrict__ prof,
              const int64_t *__restrict__ prof_off, const char *__restrict__ labels, int K, int nreads,
              const int64_t *__restrict__ soff, const int64_t *__restrict__ roff, const int32_t *__restrict__ perm,
-             int32_t *__restrict__ seg, int32_t *__restrict__ aux, int32_t *__restrict__ mi, int32_t *__restrict__ bins,
+             int32_t *__restrict__ seg, int32_t *__restrict__ aux, int32_t *__restrict__ mi,
              int32_t *__restrict__ rep_pairs, int32_t *__restrict__ rep_cnt, char *__restrict__ seeds, int32_t *__restrict__ err,
-             int64_t totalS, const int32_t *__restrict__ count)
-{ const int t = blockIdx.x*WAVE+threadIdx.x;
-  if (t >= (count ? *count : nreads)) return;
-  const int r = perm[t];
-  const int64_t so = seq_off[r], po = prof_off[r];
-  const int plen = (int)(prof_off[r+1]-po);
-  char *out = seeds+so;
-  cp_seed_read R;
-  R.seq = seq+so; R.cls = labels+so+(K-1); R.prof = prof+po; R.plen = plen; R.K = K;
-  R.state = out+(K-1);
-  const int64_t o = soff[r];
-  R.cap = (int)(soff[r+1]-o);
-  R.seg_b = seg+o; R.seg_e = seg+totalS+o; R.seg_cnt = seg+2*totalS+o; R.seg_nw = seg+3*totalS+o;
-  R.dq = aux+o; R.order = aux+totalS+o;
-  R.mi_b = mi+2*(o+3*(int64_t)r); R.mi_e = R.mi_b+R.cap+3;
-  R.bins = bins+(int64_t)r*(CP_SEED_BINS+1);
-  R.rep_pairs = rep_pairs+2*roff[r]; R.rep_cap = (int)(roff[r+1]-roff[r]);
-  R.overflow = 0;
-  const int n = cp_find_seeds_read(R);
-  rep_cnt[r] = n < R.rep_cap ? n : R.rep_cap;
-  if (R.overflow) atomicOr(err,4);
+             int64_t totalS)
+{ if ((int)blockIdx.x >= nreads) return;
+  const int r = perm[blockIdx.x], lane = (int)threadIdx.x;
+  const int64_t so = seq_off[r], po = prof_off[r], o = soff[r];
+  cp_seedw_read R;
+  R.seq = seq+so; R.cls = labels+so+(K-1); R.prof = prof+po; R.state = seeds+so+(K-1);
+  R.plen = (int)(prof_off[r+1]-po); R.K = K; R.cap = (int)(soff[r+1]-o);
+  R.seg_b = seg+o; R.seg_e = seg+totalS+o; R.seg_nw = seg+2*totalS+o;
+  R.ob = seg+3*totalS+o; R.oe = seg+4*totalS+o; R.onw = seg+5*totalS+o;
+  R.tmp = aux+o; R.order = aux+totalS+o;
+  R.gmi_b = mi+2*(o+3*(int64_t)r); R.gmi_e = R.gmi_b+R.cap+3;
+  R.rep_pairs = rep_pairs+2*roff[r]; R.rep_cap = (int)(roff[r+1]-roff[r]); R.err = err;
+#ifdef CP_SEED_PROF
+  unsigned long long sw_t[8] = {0,0,0,0,0,0,0,0}, sw_last = wall_clock64();
+  const int n = sw_find_seeds(R,lane,sw_t,sw_last);
+  if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_seed_prof[k],sw_t[k]);
+#else
+  const int n = sw_find_seeds(R,lane);
+#endif
+  if (lane == 0) rep_cnt[r] = n < R.rep_cap ? n : R.rep_cap;
 }

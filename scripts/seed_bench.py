@@ -27,8 +27,7 @@ for it in range(3):
     if hasattr(L, "cp_debug_seed_prof"):
         out = (C.c_ulonglong * 8)()
         L.cp_debug_seed_prof(out)
-        nw = (b4.nreads + 63) // 64
-        print("   lane-0 ms per wave (100 MHz ticks): stream %.1f  mask-init %.1f  radix %.1f  whole-window %.1f  group tests %.1f  anno %.1f  group takes %.1f" %
-              tuple(out[k] / nw / 1e5 for k in range(7)), flush=True)
+        print("   lane-0 ms per read (100 MHz ticks): anno %.3f  segments+deque %.3f  sort %.3f  whole-window takes %.3f  group walk %.3f" %
+              tuple(out[k] / b4.nreads / 1e5 for k in range(5)), flush=True)
     print("seeds pass %d: %.1f ms, %.1f Gbases/s (%d reads, %d bases); seeds %.4f" % (it, dt * 1e3, b4.total_bases / dt / 1e9, b4.nreads, b4.total_bases,
           float((seeds != ord("E")).float().mean())), flush=True)

@@ -126,36 +126,5 @@ int hh_classify_read(void *Pv, const char *seq, int rlen, const uint16_t *prof, 
 }
 
 
-// cp_find_seeds_read (cp_seed.h) with host buffers: the routine one lane of k_find_seeds runs
-int hh_find_seeds(const char *seq, const char *cls, const uint16_t *prof, int plen, int K, char *state, int *rep_pairs, int rep_cap,
-                  int cap)
-{ std::vector<int32_t> sb(cap), se(cap), sc(cap), sn(cap), dq(cap), ord(cap), bins(CP_SEED_BINS+1), mb(cap+3), me(cap+3);
-  cp_seed_read R;
-  R.seq = seq; R.cls = cls; R.prof = prof; R.plen = plen; R.K = K; R.state = state;
-  R.seg_b = sb.data(); R.seg_e = se.data(); R.seg_cnt = sc.data(); R.seg_nw = sn.data(); R.dq = dq.data(); R.order = ord.data();
-  R.bins = bins.data(); R.mi_b = mb.data(); R.mi_e = me.data(); R.rep_pairs = rep_pairs; R.rep_cap = rep_cap; R.cap = cap; R.overflow = 0;
-  int n = cp_find_seeds_read(R);
-  return R.overflow ? -1 : n;
-}
-// the flat form (cp_find_seeds_fast); returns -1 when the read asks for the plain form, -2 on scratch overflow
-int hh_find_seeds_fast(const char *seq, const char *cls, const uint16_t *prof, int plen, int K, char *state, int *rep_pairs, int rep_cap,
-                       int cap)
-{ std::vector<int32_t> sb(cap), se(cap), sc(cap), sn(cap), dq(cap), ord(cap), mb(cap+3,-7), me(cap+3,-7);     // mi_*: garbage on purpose, zeroed on demand
-  cp_seed_read R;
-  R.seq = seq; R.cls = cls; R.prof = prof; R.plen = plen; R.K = K; R.state = state;
-  R.seg_b = sb.data(); R.seg_e = se.data(); R.seg_cnt = sc.data(); R.seg_nw = sn.data(); R.dq = dq.data(); R.order = ord.data();
-  R.bins = nullptr; R.mi_b = mb.data(); R.mi_e = me.data(); R.rep_pairs = rep_pairs; R.rep_cap = rep_cap; R.cap = cap; R.overflow = 0;
-  for (int i = 0; i < plen; i++) state[i] = 'E';
-  cp_seed_fast_host f;
-  int n = cp_find_seeds_fast(R,f);
-  return R.overflow ? -2 : n;
-}
 int hh_kmer_hash(const char *seq, int j, int K) { return cp_kmer_hash(seq,j,K); }
-}
-extern "C" int hh_hashes_win(const char *seq, int j0, int avail, int K, int cnt, int *out8)
-{ cp_seed_win w;
-  cp_seed_win_load(w,seq,j0,avail);
-  if (!cp_seed_win_plain(w)) return 0;
-  cp_kmer_hashes_win(w,K,cnt,out8);
-  return 1;
 }
