@@ -497,8 +497,8 @@ extern "C" int cp_find_seeds_batch(const cp_params *p, cp_workspace *ws, const c
   HIPCHK(hipStreamSynchronize(st));
   const int64_t totalS = ws->h_totals[0], totalR = ws->h_totals[1];
   ws->seed_totalR = totalR;
-  ENSURE(ws->s_seg,(size_t)totalS*6*4);
-  ENSURE(ws->s_aux,(size_t)totalS*2*4);
+  ENSURE(ws->s_seg,(size_t)totalS*2*16);
+  ENSURE(ws->s_aux,(size_t)totalS*4);
   ENSURE(ws->s_mi,((size_t)totalS+3*(size_t)nreads)*2*4);
   ENSURE(ws->s_rep,(size_t)totalR*2*4+16);
   HIPCHK(hipMemsetAsync(d_seeds,'E',(size_t)total_bases,st));

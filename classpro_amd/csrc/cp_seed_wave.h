@@ -55,7 +55,9 @@ __shared__ cp_seedw_lds sw_S;                    // the wave's LDS block (one wa
 struct cp_seedw_read
   { const char *seq, *cls; const uint16_t *prof; char *state;
     int plen, K, cap, rep_cap;
-    int32_t *seg_b, *seg_e, *seg_nw, *ob, *oe, *onw, *tmp, *order;      // cap slots each
+    int4 *rec;                                                          // cap segments in position order: (begin, end, window count, -)
+    int4 *orec;                                                         // cap segments by window count: (begin, end, window count, take flag)
+    int32_t *tmp;                                                       // cap slots
     int32_t *gmi_b, *gmi_e;                                             // cap+3 slots each
     int32_t *rep_pairs;
     int32_t *err;                                                       // bit 4: a read needed more segments than its scratch holds
@@ -163,9 +165,9 @@ __device__ __forceinline__ int sw_mi_add(sw_list &Lm, int M, int b, int e, int l
 // ---- minimum canonical hash over the k-mers [b,e) and a mark on every k-mer that attains it (seed.c:392-397) -------
 // 64 k-mers at a time, a lane each: the bases' seed classes go to LDS once, then K steps of two table look-ups
 // (the forward strand's seed rotated K-1-t times, the reverse strand's rotated t times: nthash.h:215-235 unrolled)
-__device__ __attribute__((noinline)) void sw_mark(const cp_seedw_read &R, int b, int e, bool rep, int lane)
-{ const int K = R.K;
-  if (e-b == 1) { if (lane == 0) R.state[b] = rep ? 'R' : R.cls[b]; return; }
+__device__ __attribute__((noinline)) void sw_mark(const char *seq, const char *cls, char *state, int rlen, int K,
+                                                  int b, int e, bool rep, int lane)
+{ if (e-b == 1) { if (lane == 0) state[b] = rep ? 'R' : cls[b]; return; }
   const bool table = K <= SW_KMAX;
   int mh = CP_SEED_MOD, h = CP_SEED_MOD;
   for (int pass = 0; pass < 2; pass++)                        // minimum first, marks second
@@ -176,8 +178,8 @@ __device__ __attribute__((noinline)) void sw_mark(const cp_seedw_read &R, int b,
             { __syncthreads();
               for (int q = lane; q < WAVE+K-1; q += WAVE)      // seed classes of the bases base .. base+63+K-1
                 { int code = 4 | (4 << 3);
-                  if (base+q < R.plen+K-1)
-                    { const unsigned c = (unsigned char)R.seq[base+q];
+                  if (base+q < rlen)
+                    { const unsigned c = (unsigned char)seq[base+q];
                       int f = 4, r = 4;
                       switch (c)                               // seedTab, nthash.h:26-59
                         { case 'A': case 'a': case 4: case 5: f = 0; break;
@@ -206,49 +208,58 @@ __device__ __attribute__((noinline)) void sw_mark(const cp_seedw_read &R, int b,
                   h = (int)((rh < fh ? rh : fh) % CP_SEED_MOD);
                 }
             }
-          else if (j < e) h = cp_kmer_hash(R.seq,j,K);
+          else if (j < e) h = cp_kmer_hash(seq,j,K);
           if (pass == 0) mh = h < mh ? h : mh;
-          else if (j < e && h == mh) R.state[j] = rep ? 'R' : R.cls[j];
+          else if (j < e && h == mh) state[j] = rep ? 'R' : cls[j];
         }
       if (pass == 0)
         { for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(mh,o); mh = x < mh ? x : mh; }
           if (e-b <= WAVE)                                     // one chunk: its hashes are still in hand
-            { if (b+lane < e && h == mh) R.state[b+lane] = rep ? 'R' : R.cls[b+lane];
+            { if (b+lane < e && h == mh) state[b+lane] = rep ? 'R' : cls[b+lane];
               break;
             }
         }
     }
 }
 
+// an entry of a deque that moved to HBM.  Out of line on purpose: the chain's own code then holds no HBM load, so the
+// compiler puts no wait for memory into it, and the chain's stores (window counts, segment records) stay in flight
+__device__ __attribute__((noinline)) int4 sw_dq_far(const int4 *a, int p) { return a[p]; }
+
 // ---- one selection (seed.c:190-476 with C = 'H'/'D'; seed.c:667-951 with C = 0) --------------------------------------
+template <bool rep>
 __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, int C, int nrep, bool rep_big, int lane
                                           SW_PROF_ARGS)
-{ const bool rep = (C == 0);
-  const int W = rep ? CP_SEED_W_REP : CP_SEED_W;
+{ const int W = rep ? CP_SEED_W_REP : CP_SEED_W;
   const int plen = R.plen, Km1 = R.K-1;
   const uint64_t lt = (1ull << lane)-1;
-  // ---- lane 0's chain: the monotone deque over the segments (seed.c:218-324 / :694-810) ----
-  // entries are addressed by their running number p (qf .. qf+qn-1): ring slot p % SW_DQ, or, once the deque got deeper
-  // than the ring, slot p of four idle HBM arrays.  The front entry and the back entry's (segment, count) sit in registers.
+  // ---- the sequential chain: the monotone deque over the segments (seed.c:218-324 / :694-810) ----
+  // Run by lane 0 on wave-uniform values (scalar registers, scalar branches).  Entries are addressed by their
+  // running number p (qf .. qf+qn-1): ring slot p % SW_DQ, or, once the deque got deeper than the ring, slot p of an
+  // idle HBM array.  The front entry and the back entry's (segment, count) sit in registers.
   int n = 0, M = 0, nbig = 0;
   int qf = 0, qn = 0; bool last_oor = false; int last_oor_pos = 0;
   bool spilled = false, grow = false, full = false;
   int4 F = make_int4(0,0,0,0); int Bn = 0, Bc = 0;
-  auto dq_get = [&](int p) -> int4 { return spilled ? make_int4(R.tmp[p],R.order[p],R.ob[p],R.oe[p]) : sw_S.dq[p & (SW_DQ-1)]; };
+  auto dq_get = [&](int p) -> int4
+    { const int4 t = spilled ? sw_dq_far(R.orec,p) : sw_S.dq[p & (SW_DQ-1)];
+      return make_int4(sw_first(t.x),sw_first(t.y),sw_first(t.z),sw_first(t.w));
+    };
   auto dq_put = [&](int p, int4 v)
-    { if (spilled) { R.tmp[p] = v.x; R.order[p] = v.y; R.ob[p] = v.z; R.oe[p] = v.w; } else sw_S.dq[p & (SW_DQ-1)] = v; };
+    { if (spilled) R.orec[p] = v; else sw_S.dq[p & (SW_DQ-1)] = v; };
+  auto set_nw = [&](int seg, int v) { ((int32_t *)(R.rec+seg))[2] = v; };
   auto beats = [&](int a, int c) -> bool { return rep ? (a < c) : (a > c); };
   // a displaced segment that was not the front gets its count (H/D) or W_REP - count (repeats) as a stand-in
   auto standin = [&](int c) -> int { const int v = rep ? (CP_SEED_W_REP-c > 0 ? CP_SEED_W_REP-c : 0) : c; nbig += v > 1000; return v; };
   auto expire = [&]() -> int4                                // the front leaves the window (or the read ends): its count of windows
     { int v = W;
       if (last_oor) { v = F.z-last_oor_pos+1; if (v > W) v = W; }
-      R.seg_nw[F.x] = v;
+      set_nw(F.x,v);
       return qn > 1 ? dq_get(qf+1) : F;
     };
   auto feed = [&](int sb, int se, int sc)                    // segment n = [sb,se), count sc (-1: a skipped stretch)
     { if (n >= R.cap) { full = true; return; }             // (k_seed_caps sizes the scratch; reported, never written past)
-      R.seg_b[n] = sb; R.seg_e[n] = se; R.seg_nw[n] = (sc < 0) ? -10 : 0;
+      R.rec[n] = make_int4(sb,se,(sc < 0) ? -10 : 0,0);
       if (sc < 0)                                            // skipped stretches are masked from the start
         { if (!Lm.big && M+4 >= SW_MI) grow = true;          // no room on chip: they are listed again, in HBM, after the pass
           if (!grow) Lm.set(M,sb,se);
@@ -262,19 +273,18 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
                   int v;
                   if (t.y == F.y) { v = sb-t.z; if (v > W) v = W; }
                   else v = standin(t.y);
-                  R.seg_nw[t.x] = v;
+                  set_nw(t.x,v);
                 }
               qn = 0;
             }
           else
             while (qn > 0 && beats(sc,Bc))
-              { R.seg_nw[Bn] = standin(Bc);
+              { set_nw(Bn,standin(Bc));
                 qn--;
                 if (qn > 0) { const int4 t = dq_get(qf+qn-1); Bn = t.x; Bc = t.y; }
               }
           if (!spilled && qn >= SW_DQ)                       // deeper than the ring: the deque moves to HBM
-            { for (int j = 0; j < qn; j++)
-                { const int4 t = sw_S.dq[(qf+j) & (SW_DQ-1)]; R.tmp[qf+j] = t.x; R.order[qf+j] = t.y; R.ob[qf+j] = t.z; R.oe[qf+j] = t.w; }
+            { for (int j = 0; j < qn; j++) R.orec[qf+j] = sw_S.dq[(qf+j) & (SW_DQ-1)];
               spilled = true;
             }
           const int4 t = make_int4(n,sc,sb,se);
@@ -296,7 +306,7 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
   // k-mer on (it may run on over k-mers of other classes); the k-mers skipped between segments form invalid ones.
   // A segment that would start at the last k-mer is never made (the reference's loop ends first).
   { bool carry = false;                                      // the run entering the chunk already holds a valid k-mer
-    int ob = 0, oc = 0; bool open = false;                   // lane 0: the segment whose end is not known yet
+    int ob = 0, oc = 0; bool open = false;                   // the segment whose end is not known yet
     for (int e0 = 0; e0 < plen; e0 += SW_STEP*WAVE)
       { int cnt[SW_STEP], cpv[SW_STEP]; char cl[SW_STEP], st[SW_STEP];
 #pragma unroll
@@ -347,15 +357,16 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
           }
         __syncthreads();
         if (lane == 0)
+          for (int u = 0; u < SW_STEP; u++)                  // (one copy of the chain's code: the masks are picked, not unrolled)
+            { uint64_t m = sm[0];
 #pragma unroll
-          for (int u = 0; u < SW_STEP; u++)
-            { uint64_t m = sm[u];
+              for (int w = 1; w < SW_STEP; w++) if (u == w) m = sm[w];
               while (m)
                 { const int j = __ffsll((long long)m)-1;
                   m &= m-1;
                   const int s = e0+u*WAVE+j;
                   if (open) feed(ob,s,oc);
-                  ob = s; oc = sw_S.cval[u*WAVE+j]; open = true;
+                  ob = s; oc = sw_first(sw_S.cval[u*WAVE+j]); open = true;
                 }
             }
         __syncthreads();
@@ -371,21 +382,26 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
       }
   }
   __syncthreads();                                           // lane 0's segment records are visible to the wave
-  if (sw_first(full ? 1 : 0)) { if (lane == 0) atomicOr(R.err,4); return; }
   n = sw_first(n); nbig = sw_first(nbig); M = sw_first(M);   // wave-uniform from here on
+  if (sw_first(full ? 1 : 0)) { if (lane == 0) atomicOr(R.err,4); return; }
   if (sw_first(grow ? 1 : 0))                                // the skipped stretches did not fit on chip: the list moves to HBM
     { sw_mi_grow(Lm,R.cap+3,lane);                           // (slots not yet rewritten keep the earlier selections' leftovers)
       int k = 0;
       for (int base = 0; base < n; base += WAVE)             // and every skipped stretch is listed again, in order
         { const int q = base+lane;
-          const bool inv = q < n && R.seg_nw[q] == -10;
+          int4 t = make_int4(0,0,0,0);
+          if (q < n) t = R.rec[q];
+          const bool inv = q < n && t.z == -10;
           const uint64_t im = __ballot(inv);
-          if (inv) { const int s = k+__popcll(im & lt); Lm.gb[s] = R.seg_b[q]; Lm.ge[s] = R.seg_e[q]; }
+          if (inv) { const int s = k+__popcll(im & lt); Lm.gb[s] = t.x; Lm.ge[s] = t.y; }
           k += __popcll(im);
         }
       __syncthreads();
     }
   SW_STAMP(1);
+#ifdef CP_SEED_PROF
+  if (lane == 0) { sw_t[5] += n; sw_t[6] += M; sw_t[7] += (plen+SW_STEP*WAVE-1)/(SW_STEP*WAVE); }
+#endif
   if (M > 0 && Lm.b(0) == 0 && Lm.e(0) == plen) return;
   // ---- stable order by decreasing window count (the reference's qsort is glibc's stable merge sort): two 5-bit radix
   //      passes on 1000 - count (the skipped stretches, -10, come last), ranks from ballots ----
@@ -393,7 +409,7 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
     { if (lane < 32) sw_S.bins[lane] = 0;
       __syncthreads();
       for (int q = lane; q < n; q += WAVE)
-        { const int nw = R.seg_nw[pass ? R.tmp[q] : q];
+        { const int nw = R.rec[pass ? R.tmp[q] : q].z;
           atomicAdd(&sw_S.bins[((nw > 1000 ? 0 : 1000-nw) >> (5*pass)) & 31],1);
         }
       __syncthreads();
@@ -406,8 +422,9 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
       for (int base = 0; base < n; base += WAVE)
         { const int q = base+lane;
           const bool act = q < n;
-          int i = 0, nw = 0, dg = 0;
-          if (act) { i = pass ? R.tmp[q] : q; nw = R.seg_nw[i]; dg = ((nw > 1000 ? 0 : 1000-nw) >> (5*pass)) & 31; }
+          int i = 0, dg = 0;
+          int4 t = make_int4(0,0,0,0);
+          if (act) { i = pass ? R.tmp[q] : q; t = R.rec[i]; dg = ((t.z > 1000 ? 0 : 1000-t.z) >> (5*pass)) & 31; }
           uint64_t peers = __ballot(act);
           for (int bit = 0; bit < 5; bit++)
             { const uint64_t bmk = __ballot(act && ((dg >> bit) & 1));
@@ -420,25 +437,21 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
           if (act && rank == 0) sw_S.bins[dg] += __popcll(peers);
           __syncthreads();
           if (act)
-            { if (pass == 0) R.order[d] = i;
-              else { R.ob[d] = R.seg_b[i]; R.oe[d] = R.seg_e[i]; R.onw[d] = nw; }
+            { if (pass == 0) R.tmp[d] = i;
+              else R.orec[d] = t;
             }
         }
       __syncthreads();
-      if (pass == 0)
-        { for (int q = lane; q < n; q += WAVE) R.tmp[q] = R.order[q];
-          __syncthreads();
-        }
     }
   if (nbig > 0)                                              // counts above 1000 share the first key with 1000: that head is put
     { if (lane == 0)                                         // in order by insertion (rare, short)
         { int m = 0;
-          while (m < n && R.onw[m] >= 1000) m++;
+          while (m < n && R.orec[m].z >= 1000) m++;
           for (int a = 1; a < m; a++)
-            { const int xb = R.ob[a], xe = R.oe[a], xn = R.onw[a];
+            { const int4 x = R.orec[a];
               int j = a-1;
-              while (j >= 0 && R.onw[j] < xn) { R.ob[j+1] = R.ob[j]; R.oe[j+1] = R.oe[j]; R.onw[j+1] = R.onw[j]; j--; }
-              R.ob[j+1] = xb; R.oe[j+1] = xe; R.onw[j+1] = xn;
+              while (j >= 0 && R.orec[j].z < x.z) { R.orec[j+1] = R.orec[j]; j--; }
+              R.orec[j+1] = x;
             }
         }
       __syncthreads();
@@ -448,12 +461,13 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
   auto take = [&](int b, int e)                              // mask the segment with a margin of W, mark its hash minimizers
     { if (!Lm.big && M+4 >= SW_MI) sw_mi_grow(Lm,R.cap+3,lane);
       M = sw_mi_add(Lm,M,b-W > 0 ? b-W : 0,e+W < plen ? e+W : plen,lane);
-      sw_mark(R,b,e,rep,lane);
+      sw_mark(R.seq,R.cls,R.state,plen+Km1,R.K,b,e,rep,lane);
     };
   int pos = 0;
   for (; pos < n; pos++)                                     // every segment that is extreme over a whole window
-    { if (R.onw[pos] < W) break;
-      take(R.ob[pos],R.oe[pos]);
+    { const int4 t = R.orec[pos];
+      if (t.z < W) break;
+      take(t.x,t.y);
     }
   SW_STAMP(3);
   // Then groups of equal window count, while uncovered.  The members of a group are tested against the list as it was
@@ -468,7 +482,7 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
     { for (int q = 0; q < npend; q++) take(sw_S.pend_b[q],sw_S.pend_e[q]);
       if (ovpos >= 0)
         { __syncthreads();
-          for (int q = ovpos; q < gend; q++) if (R.order[q] < 0) take(R.ob[q],R.oe[q]);
+          for (int q = ovpos; q < gend; q++) { const int4 t = R.orec[q]; if (t.w < 0) take(t.x,t.y); }
         }
       npend = 0; ovpos = -1; ingroup = false;
       covered = M > 0 && Lm.b(0) == 0 && Lm.e(0) == plen;
@@ -476,8 +490,9 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
   while (pos < n && !covered)
     { const int q = pos+lane;
       const bool act = q < n;
-      const int sb = act ? R.ob[q] : 0, se = act ? R.oe[q] : 0;
-      const int nw = act ? R.onw[q] : -0x7fffffff;
+      int4 rc = make_int4(0,0,-0x7fffffff,0);
+      if (act) rc = R.orec[q];
+      const int sb = rc.x, se = rc.y, nw = rc.z;
       bool outside = false;
       if (act)
         { const int idx = sw_mi_find(Lm,M,sb,se);
@@ -498,7 +513,7 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
       const uint64_t pm = __ballot(mine);
       if (ovpos < 0 && npend+__popcll(pm) > SW_PEND) ovpos = pos;
       __syncthreads();
-      if (ovpos >= 0) { if (act) R.order[q] = mine ? -1 : 0; }      // (the order array is idle by now: flags)
+      if (ovpos >= 0) { if (act) R.orec[q].w = mine ? -1 : 0; }
       else if (mine) { const int s = npend+__popcll(pm & lt); sw_S.pend_b[s] = sb; sw_S.pend_e[s] = se; }
       __syncthreads();
       if (ovpos < 0) npend += __popcll(pm);
@@ -572,7 +587,9 @@ __device__ __forceinline__ int sw_find_seeds(const cp_seedw_read &R, int lane SW
   SW_STAMP(0);
   nrep = sw_first(nrep);
   const bool rep_big = nrep > SW_REP;                        // then the HBM list is searched (complete: rep_cap bounds the label runs)
-  for (int sel = 0; sel < 3; sel++)                          // H, D, then the repeats: one copy of the code
-    sw_select(R,Lm,sel == 0 ? 'H' : sel == 1 ? 'D' : 0,nrep > R.rep_cap ? R.rep_cap : nrep,rep_big,lane SW_PROF_PASS);
+  const int nr = nrep > R.rep_cap ? R.rep_cap : nrep;
+  for (int sel = 0; sel < 2; sel++)                          // H, then D: one copy of the code
+    sw_select<false>(R,Lm,sel == 0 ? 'H' : 'D',nr,rep_big,lane SW_PROF_PASS);
+  sw_select<true>(R,Lm,0,nr,rep_big,lane SW_PROF_PASS);
   return nrep;
 }

@@ -1875,9 +1875,7 @@ k_find_seeds(const char *__restrict__ seq, const int64_t *__restrict__ seq_off, 
   cp_seedw_read R;
   R.seq = seq+so; R.cls = labels+so+(K-1); R.prof = prof+po; R.state = seeds+so+(K-1);
   R.plen = (int)(prof_off[r+1]-po); R.K = K; R.cap = (int)(soff[r+1]-o);
-  R.seg_b = seg+o; R.seg_e = seg+totalS+o; R.seg_nw = seg+2*totalS+o;
-  R.ob = seg+3*totalS+o; R.oe = seg+4*totalS+o; R.onw = seg+5*totalS+o;
-  R.tmp = aux+o; R.order = aux+totalS+o;
+  R.rec = (int4 *)seg+o; R.orec = (int4 *)seg+totalS+o; R.tmp = aux+o;
   R.gmi_b = mi+2*(o+3*(int64_t)r); R.gmi_e = R.gmi_b+R.cap+3;
   R.rep_pairs = rep_pairs+2*roff[r]; R.rep_cap = (int)(roff[r+1]-roff[r]); R.err = err;
 #ifdef CP_SEED_PROF

@@ -17,8 +17,6 @@
  * ClassPro.c:209-226 does).  CP_MAX_READ_LEN is the reference's limit for FASTX inputs (ClassPro.c:184-187: the
  * command line enforces it there); the library itself takes longer reads (a Dazzler database is sized by its
  * longest read, ClassPro.c:87,110): reads beyond 65535 k-mers go through the sequential classify kernels.
- * d_seq is also read in aligned 4-byte words by the seed path: up to 3 bytes past its last base may be touched
- * (any device allocation qualifies).
  *
  * Pointers named d_* are DEVICE pointers (HBM); everything else is host memory.  `stream` is a
  * hipStream_t passed as void* (NULL = default stream).  No torch types appear in this ABI.

@@ -329,7 +329,7 @@ def test_reads_longer_than_65535_kmers(torch_dev, tmp_path):
     clf = Classifier(K, 20000, hc, dc)
     b = Batch.from_reads(seqs, profs)
     assert clf.classify(b).tobytes() == b"".join(want)
-    seeds, reps = clf.find_seeds(b)                          # the seed path too (flat form hands long reads to the plain form)
+    seeds, reps = clf.find_seeds(b)                          # the seed path too (reads of more than 65535 k-mers)
     so = b.seq_off_h
     for j, (s_, p_, lab) in enumerate(zip(seqs, profs, want)):
         sas, rep = O.find_seeds(s_, lab, p_)
