@@ -25,6 +25,7 @@ extern "C" const char *cp_version(void) { return "classpro_amd 0.1 (gfx950)"; }
 struct cp_params
   { cp_dev_params  host;
     cp_dev_params *dev;
+    double        *skel;                   // device table of logp_trans values (cp_types.h), or NULL
   };
 
 extern "C" int cp_hist_covs(const int64_t *hist, int low, int high, int64_t ilowcnt, int64_t ihighcnt,
@@ -81,12 +82,32 @@ extern "C" int cp_params_create_model(int K, int read_len, int hcov, int dcov, c
       free(p);
       return set_err(CP_EHIP,std::string("cp_params_create: ")+hipGetErrorString(e));
     }
+  // the table of logp_trans values: |ce-cb| <= 255 covers every pair of counts of reliable intervals (both below the
+  // REPEAT coverage <= 255); cov*|e-b| up to CLASSPRO_SKELLAM_TABLE_MB (default 1024 MB = 2^19 products; 0 = no table)
+  p->skel = NULL;
+  { long mb = 1024;
+    if (const char *e = getenv("CLASSPRO_SKELLAM_TABLE_MB")) mb = atol(e);
+    const int kmax = 255;
+    const long long cdmax = (long long)mb*1024*1024/8/(kmax+1)-1;
+    if (cdmax >= 0 && hipMalloc((void **)&p->skel,(size_t)(cdmax+1)*(kmax+1)*8) == hipSuccess)
+      { hipLaunchKernelGGL(k_skellam_table,dim3(4096),dim3(256),0,0,p->dev,p->skel,kmax,cdmax);
+        p->host.skel = p->skel; p->host.skel_kmax = kmax; p->host.skel_cdmax = cdmax;
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpy(p->dev,&p->host,sizeof(cp_dev_params),hipMemcpyHostToDevice);   // (after the kernel, same stream)
+        if (e != hipSuccess)
+          { (void)hipFree(p->skel); (void)hipFree(p->dev); free(p);
+            return set_err(CP_EHIP,std::string("cp_params_create: ")+hipGetErrorString(e));
+          }
+      }
+    else { p->skel = NULL; (void)hipGetLastError(); }       // no room for the table: every value is computed on the spot
+  }
   *out = p;
   return CP_OK;
 }
 
 extern "C" void cp_params_destroy(cp_params *p)
 { if (!p) return;
+  if (p->skel) (void)hipFree(p->skel);
   if (p->dev) (void)hipFree(p->dev);
   free(p);
 }

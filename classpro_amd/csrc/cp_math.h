@@ -185,11 +185,22 @@ CP_HD double cp_p_errorin(const LF &lf, int e, double erate, double lpe, double 
 { return cp_binom_test_g(lf,(e == CP_SELF) ? cin : cout-cin,cout,erate,lpe,l1mpe); }
 
 // ---- util.c:35-44 -----------------------------------------------------------------------------
+// (double)cov*d is an exact integer, so the value is a function of (|ce-cb|, cov*d): the table of cp_dev_params holds
+// what the line below gives for the pairs it covers (k_skellam_table runs this very function).
+CP_HD double cp_logp_trans_calc(const cp_dev_params *P, int k, double cd)
+{ return cp_logp_skellam(k,cd/P->read_len); }
+
 CP_HD double cp_logp_trans(const cp_dev_params *P, int b, int e, int cb, int ce, int cov)
 { cov &= 0xffff;
   int d = e-b;
   if (d < 0) d = -d;
-  return cp_logp_skellam(ce-cb,(double)cov*d/P->read_len);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int k = ce-cb < 0 ? cb-ce : ce-cb;
+  const long long cd = (long long)cov*d;
+  if (P->skel && k <= P->skel_kmax && cd <= P->skel_cdmax)
+    return P->skel[cd*(P->skel_kmax+1)+k];
+#endif
+  return cp_logp_trans_calc(P,ce-cb,(double)cov*d);
 }
 
 // ---- util.c:24-33 (positions are strictly ordered on every call path) -------------------------

@@ -58,6 +58,12 @@ struct cp_dev_params
     uint8_t cthres[3][21][256][2][2];      // [ctype][l][cout][INIT|FINAL][SELF|OTHERS], wall.c:190-224
     double  logfact[CP_MAX_KMER_CNT+1];    // prob.c:12-19
     double  logint[CP_MAX_KMER_CNT+1];     // log((double)n), n >= 1 (logp_poisson's log(lambda))
+    // logp_trans (util.c:35-44) depends on its five arguments only through |ce-cb| and the integer cov*|e-b|: values for
+    // |ce-cb| <= skel_kmax and cov*|e-b| <= skel_cdmax, computed once on the device by the same code
+    // (skel[cd*(skel_kmax+1)+k]); NULL = always computed on the spot
+    const double *skel;
+    int     skel_kmax;
+    long long skel_cdmax;
   };
 
 // E-/O-interval, ClassPro.h:153-157

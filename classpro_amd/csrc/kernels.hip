@@ -1816,6 +1816,20 @@ k_seq_context(const char *__restrict__ seq, const int64_t *__restrict__ seq_off,
 
 
 // ---------------------------------------------------------------------------------------------
+//  k_skellam_table: the values of logp_trans (util.c:35-44 -> prob.c:41-44 -> bessel.c:478-521) for every pair
+//  (cov*|e-b| <= cdmax, |ce-cb| <= kmax), by the function the kernels would otherwise run on the spot.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_skellam_table(const cp_dev_params *__restrict__ P, double *__restrict__ tab, int kmax, long long cdmax)
+{ const long long n = (cdmax+1)*(kmax+1);
+  for (long long i = (long long)blockIdx.x*blockDim.x+threadIdx.x; i < n; i += (long long)gridDim.x*blockDim.x)
+    { const long long cd = i/(kmax+1);
+      const int k = (int)(i-cd*(kmax+1));
+      tab[i] = cp_logp_trans_calc(P,k,(double)cd);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 //  -s seed path (src/seed.c:966-1032): cp_seed_wave.h, one wave per read.
 //  k_seed_caps: per read, the number of count runs and of label runs of its k-mers: the scratch a read's
 //  seed selection needs.  Segments of a selection: every count run starts at most one, every change of the valid
