@@ -187,7 +187,14 @@ CP_HD double cp_p_errorin(const LF &lf, int e, double erate, double lpe, double 
 // ---- util.c:35-44 -----------------------------------------------------------------------------
 // (double)cov*d is an exact integer, so the value is a function of (|ce-cb|, cov*d): the table of cp_dev_params holds
 // what the line below gives for the pairs it covers (k_skellam_table runs this very function).
-CP_HD double cp_logp_trans_calc(const cp_dev_params *P, int k, double cd)
+// Out of line on the device: with the table in place this is the rare path, and inlined into the classify kernels its
+// Bessel recurrence would set their register count (and so their occupancy) for nothing.
+#if defined(__HIPCC__)
+__host__ __device__ __attribute__((noinline))
+#else
+static inline
+#endif
+double cp_logp_trans_calc(const cp_dev_params *P, int k, double cd)
 { return cp_logp_skellam(k,cd/P->read_len); }
 
 CP_HD double cp_logp_trans(const cp_dev_params *P, int b, int e, int cb, int ce, int cov)

@@ -1229,11 +1229,13 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
 // (MAXM; G,MAXN) = (128; 8,192) 6.68 ms per step, (192; 8,192) 6.48, (128; 4,256) 6.51, (192; 4,256) 6.31,
 // (256; 4,256) 6.29.  Later, with four reads per wave in the rel kernel (8 lanes per direction, every lane
 // with a Bessel term): 5.00 ms at MAXM 256, 4.77 at 192, 5.39 at 128.
+// With the table of logp_trans values (cp_types.h) the Bessel term is a load and the balance moved again: whole step
+// 70.7 ms at MAXM 192, 68.7 at 128 or 96 (less LDS per wave: 3 waves per SIMD instead of 2); G = 2 74.8, G = 8 89.7.
 #ifndef REL_SMALL_G
 #define REL_SMALL_G 4
 #endif
 #ifndef REL_SMALL_MAXM
-#define REL_SMALL_MAXM 192
+#define REL_SMALL_MAXM 128
 #endif
 // (unrel, later, with K = 64/G/8 speculative update slots per read: G = 4 4.28 ms per step, G = 2 4.07, G = 1 4.04)
 #ifndef UNREL_SMALL_G
@@ -1382,8 +1384,11 @@ __device__ __forceinline__ int bits_right(const uint64_t *bits, int idx, int nwo
     }
 }
 
+#ifndef UNREL_WAVES_PER_EU
+#define UNREL_WAVES_PER_EU 4
+#endif
 template <int MINN, int MAXN, int G>
-__global__ void __launch_bounds__(WAVE)
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(UNREL_WAVES_PER_EU)))
 k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__restrict__ intvl_all,
                      const int64_t *__restrict__ ioff, const int32_t *__restrict__ nintvl,
                      double *__restrict__ memo_val, int32_t *__restrict__ memo_key, const int32_t *__restrict__ perm)

@@ -14,7 +14,7 @@ for r in csv.DictReader(open(f[0])):
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     n[(k, r["Counter_Name"])] += 1
 for k in acc:
-    if not any(x in k for x in ("find_wall", "classify_rel_grp", "classify_unrel_grp", "find_rel", "scan_cand")): continue
+    if not any(x in k for x in ("find_wall", "classify_rel", "classify_unrel", "find_rel", "scan_cand", "paint", "order_by")): continue
     print(k)
     for c, v in acc[k].items():
         print("    %-28s %16.0f per launch" % (c, v / n[(k, c)]))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic: where the candidate walk of k_find_wall spends its cycles (needs build/lib_prof.so, built
-with -DCP_PROF_WALK; run with CLASSPRO_AMD_LIB=build/lib_prof.so on the GPU box)."""
+"""Diagnostic: where the candidate walk of k_find_wall spends its cycles (needs build_diag/lib_walk.so, built
+with -DCP_PROF_WALK; run with CLASSPRO_AMD_LIB=build_diag/lib_walk.so on the GPU box)."""
 import ctypes as C
 import os
 import sys

@@ -556,3 +556,44 @@ def test_adversarial_inputs(torch_dev, seed):
         assert got[off:off + len(w)].tobytes() == w, "read %d of seed %d" % (r, seed)
         off += len(w)
     clf.close()
+
+
+def test_skellam_table_is_what_the_kernels_compute(torch_dev, ds_b, monkeypatch):
+    """logp_trans comes from a device-built table (cp_types.h: |ce-cb| <= 255, cov*|e-b| below a bound) or, outside
+    it, from the recurrence on the spot.  The table is filled by that very code, so a classifier without a table
+    (CLASSPRO_SKELLAM_TABLE_MB=0), one with a tiny table (most products outside it) and the default one must agree to
+    the last bit: labels, interval records (incl. their doubles) and the run on a 200-Mbase device-generated batch."""
+    torch = torch_dev
+    import ctypes as C
+    from classpro_amd.api import Classifier, Batch, INTVL_DTYPE, hist_covs
+    from classpro_amd._lib import check
+    from classpro_amd.synth_dev import DeviceSynth
+    ds, hc, dc = ds_b
+
+    def run(mb, batch_fn, hc_, dc_, rl):
+        if mb is None:
+            monkeypatch.delenv("CLASSPRO_SKELLAM_TABLE_MB", raising=False)
+        else:
+            monkeypatch.setenv("CLASSPRO_SKELLAM_TABLE_MB", str(mb))
+        clf = Classifier(K=K, read_len=rl, hcov=hc_, dcov=dc_)
+        b = batch_fn()
+        lab = clf.classify(b).copy()
+        nc, ni, nr, off = clf.counts(b)
+        tot = int(off[-1])
+        iv = np.zeros(tot, INTVL_DTYPE)
+        rv = np.zeros(tot, INTVL_DTYPE)
+        check(clf.L.cp_get_intervals(clf.ws, iv.ctypes.data, rv.ctypes.data, tot))
+        live = np.arange(tot) - off[np.searchsorted(off, np.arange(tot), side="right") - 1] < np.repeat(ni, np.diff(off))
+        clf.close()
+        return lab, iv[live].tobytes()
+    small = lambda: Batch.from_reads(ds["seqs"], ds["profiles"])
+    ref = run(0, small, hc, dc, 7000)
+    for mb in (1, None):
+        got = run(mb, small, hc, dc, 7000)
+        assert np.array_equal(got[0], ref[0]) and got[1] == ref[1], mb
+    sy = DeviceSynth(genome_len=5_000_000, cov=40, read_len=20000, seed=4)
+    h2, d2 = hist_covs(sy.hist[4], 1, 32767, 0, 0, 0)
+    big = lambda: Batch.from_device(sy.reads(0, sy.n_reads))
+    ref = run(0, big, h2, d2, 20000)
+    got = run(None, big, h2, d2, 20000)
+    assert np.array_equal(got[0], ref[0]) and got[1] == ref[1]
