@@ -2,7 +2,7 @@
 """End-to-end rate of the drop-in `ClassPro` binary (FASTA + FASTK files in, .class out) on files written to
 tmpfs from the device synthesiser's reads.  Run on the GPU box.
 
-    python scripts/cli_e2e.py [mbases=800] [threads=16] [devices=0] [gz=0]
+    python scripts/cli_e2e.py [mbases=800] [threads=4,16,32] [devices=0] [gz=0]
 """
 import os
 import struct
@@ -53,7 +53,10 @@ def run_cli(path, threads, devices=None, reps=2):
     if devices:
         env["CLASSPRO_DEVICES"] = devices
     best, lines = None, []
+    out = os.path.join(os.path.dirname(path), os.path.basename(path).split(".")[0] + ".class")
     for _ in range(reps):
+        if os.path.exists(out):
+            os.unlink(out)                     # a fresh output file every time (freeing the old one's pages is not the run's work)
         t0 = time.time()
         r = subprocess.run([cli, "-v", "-T%d" % threads, path], capture_output=True, text=True, env=env)
         dt = time.time() - t0
@@ -69,7 +72,8 @@ if __name__ == "__main__":
     import torch
     from classpro_amd.synth_dev import DeviceSynth
     mb = float(sys.argv[1]) if len(sys.argv) > 1 else 800.0
-    threads = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    tlist = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [4, 16, 32]
+    threads = tlist[0]
     devices = sys.argv[3] if len(sys.argv) > 3 else None
     gz = len(sys.argv) > 4 and sys.argv[4] == "1"
     ds = DeviceSynth(genome_len=200_000_000, cov=40, read_len=20000, seed=1)
@@ -86,7 +90,7 @@ if __name__ == "__main__":
         t0 = time.time()
         path = write_inputs(d, (seq, prof), so, hist, gz=gz)
         print("wrote %d reads, %.1f Mbases to %s in %.1f s" % (n, nb / 1e6, d, time.time() - t0), flush=True)
-        for t in ([threads] if len(sys.argv) > 2 else [4, 16, 32]):
+        for t in tlist:
             dt, lines = run_cli(path, t, devices)
             print("-T%d devices=%s: %.3f s wall, %.1f Mbases/s end to end" % (t, devices or "all", dt, nb / dt / 1e6), lines, flush=True)
         print("class file bytes", os.path.getsize(os.path.join(d, "reads.class")))
