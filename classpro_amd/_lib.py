@@ -35,6 +35,13 @@ def lib():
         raise ImportError(
             "classpro_amd: %s not found. Build it with `python -m classpro_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    # The Python layer shares device memory and streams with torch, so both must sit on ONE HIP runtime: torch's
+    # (it ships its own libamdhip64) has to be in the process first -- loaded after ours, it comes up as a second
+    # runtime and every later HIP call of this library answers "no ROCm-capable device".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
     L.cp_last_error.restype = C.c_char_p

@@ -90,7 +90,9 @@ extern "C" int cp_params_create_model(int K, int read_len, int hcov, int dcov, c
     const int kmax = 255;
     const long long cdmax = (long long)mb*1024*1024/8/(kmax+1)-1;
     if (cdmax >= 0 && hipMalloc((void **)&p->skel,(size_t)(cdmax+1)*(kmax+1)*8) == hipSuccess)
-      { hipLaunchKernelGGL(k_skellam_table,dim3(4096),dim3(256),0,0,p->dev,p->skel,kmax,cdmax);
+      { (void)hipGetLastError();              // (when this is the process's first HIP work, the runtime's own start-up
+                                              //  probing can leave an error code behind: it is not this launch's)
+        hipLaunchKernelGGL(k_skellam_table,dim3(4096),dim3(256),0,0,p->dev,p->skel,kmax,cdmax);
         p->host.skel = p->skel; p->host.skel_kmax = kmax; p->host.skel_cdmax = cdmax;
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpy(p->dev,&p->host,sizeof(cp_dev_params),hipMemcpyHostToDevice);   // (after the kernel, same stream)

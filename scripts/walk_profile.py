@@ -12,11 +12,18 @@ from classpro_amd import synth
 from classpro_amd.api import Classifier, Batch, hist_covs, STAGE_WALL
 from classpro_amd._lib import lib
 
-ds = synth.make_dataset(genome_len=5_000_000, cov=40, read_len=20000, K=40, het=0.001, n_repeats=62, min_len=3000, seed=1)
-low, high, il, ih, h = ds["hist"]
-hc, dc = hist_covs(h, low, high, il, ih, 0)
+if len(sys.argv) > 1 and sys.argv[1] == "python-synth":
+    ds = synth.make_dataset(genome_len=5_000_000, cov=40, read_len=20000, K=40, het=0.001, n_repeats=62, min_len=3000, seed=1)
+    low, high, il, ih, h = ds["hist"]
+    hc, dc = hist_covs(h, low, high, il, ih, 0)
+    b = Batch.from_reads(ds["seqs"], ds["profiles"])
+else:                                                     # the bench's generator: one 800-Mbase sub-batch
+    from classpro_amd.synth_dev import DeviceSynth
+    sy = DeviceSynth(genome_len=20_000_000, cov=40, read_len=20000, seed=1)
+    low, high, il, ih, h = sy.hist
+    hc, dc = hist_covs(h, low, high, il, ih, 0)
+    b = Batch.from_device(sy.reads(0, sy.n_reads))
 clf = Classifier(40, 20000, hc, dc)
-b = Batch.from_reads(ds["seqs"], ds["profiles"])
 ph = (C.c_ulonglong * 24)()
 lv = (C.c_ulonglong * 8)()
 clf.run(b, STAGE_WALL)
