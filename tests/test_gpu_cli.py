@@ -55,8 +55,9 @@ def cli_set(torch_dev, tmp_path_factory):
     return d, cli, b"".join(exp)
 
 
-def _run(cli, d, src, threads, devices=None, window_kb=None, batch_kb=None):
+def _run(cli, d, src, threads, devices=None, window_kb=None, batch_kb=None, extra_env=None):
     env = dict(os.environ)
+    env.update(extra_env or {})
     if devices:
         env["CLASSPRO_DEVICES"] = devices
     if window_kb:
@@ -123,3 +124,26 @@ def test_tiny_inputs(torch_dev, tmp_path):
     fastk.write_fastk(d, "two", K, [p0], ds["hist"], nparts=1)
     r = subprocess.run([cli, os.path.join(d, "two.fa")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "Inconsistent # of reads" in r.stderr
+
+
+def test_output_larger_than_the_upfront_estimate(torch_dev, tmp_path):
+    """A plain FASTA's output gets its pages up front from an estimate (2 x the input + 64 MB); records that print an
+    inherited comment (kseq keeps the last one) can make the output far larger than that: the rest is allocated window
+    by window.  Same bytes with the up-front allocation switched off."""
+    from classpro_amd import synth, fastk, build
+    d = str(tmp_path)
+    ds = synth.make_dataset(genome_len=60000, cov=30, read_len=5000, seed=5)
+    cli = os.path.join(os.path.dirname(build.OUT), "ClassPro")
+    n, cmt = 70000, b"c" * 1000
+    rng = np.random.default_rng(3)
+    seqs = [bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 30)]) for _ in range(n)]
+    with open(os.path.join(d, "wide.fa"), "wb") as f:
+        for i, s in enumerate(seqs):
+            f.write(b">r%d" % i + (b" " + cmt if i == 0 else b"") + b"\n" + s + b"\n")
+    fastk.write_fastk(d, "wide", K, [np.zeros(0, np.uint16)] * n, ds["hist"], nparts=2)
+    exp = b"".join(b"@r%d " % i + cmt + b"\n" + s + b"\n+\n" + b"N" * 30 + b"\n" for i, s in enumerate(seqs))
+    assert len(exp) > 2 * os.path.getsize(os.path.join(d, "wide.fa")) + (64 << 20)
+    got, _ = _run(cli, d, "wide.fa", 4, "0,0", 600, None)
+    assert got == exp
+    got, _ = _run(cli, d, "wide.fa", 4, "0,0", 600, None, {"CLASSPRO_OUT_ALLOC": "window"})
+    assert got == exp
