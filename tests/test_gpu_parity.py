@@ -580,8 +580,8 @@ def test_skellam_table_is_what_the_kernels_compute(torch_dev, ds_b, monkeypatch)
         lab = clf.classify(b).copy()
         nc, ni, nr, off = clf.counts(b)
         tot = int(off[-1])
-        iv = np.zeros(tot, INTVL_DTYPE)
-        rv = np.zeros(tot, INTVL_DTYPE)
+        iv = np.zeros((tot, INTVL_DTYPE.itemsize), np.uint8)          # raw records: every byte of them is compared
+        rv = np.zeros((tot, INTVL_DTYPE.itemsize), np.uint8)
         check(clf.L.cp_get_intervals(clf.ws, iv.ctypes.data, rv.ctypes.data, tot))
         live = np.arange(tot) - off[np.searchsorted(off, np.arange(tot), side="right") - 1] < np.repeat(ni, np.diff(off))
         clf.close()
