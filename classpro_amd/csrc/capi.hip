@@ -336,16 +336,18 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   ENSURE(ws->rpos,(size_t)totalI*2);
   ENSURE(ws->asgn,(size_t)totalI*2);
   HIPCHK(hipMemsetAsync(ws->asgn.p,0xff,(size_t)totalI*2,st));
-  hipLaunchKernelGGL(k_classify_rel,dim3(nreads < 1024 ? nreads : 1024),dim3(WAVE),0,st,
+  // size classes (kernels.hip: REL_SMALL_*): M <= 128 four reads per wave, up to 1024 one read per wave, larger (or a
+  // read beyond 65535 k-mers): the sequential kernel
+  hipLaunchKernelGGL(k_order_by_work,dim3(1),dim3(1024),0,st,(const int32_t *)ws->nrel.p,nreads,0,(int32_t *)ws->perm.p);
+  // (the classes touch disjoint reads; the rare classes are a handful of latency-bound waves -- on most batches none at
+  //  all, and the sequential kernel's 1024 scratch-using waves still cost 0.9 ms to start -- so they run beside the main
+  //  class on the auxiliary stream)
+  HIPCHK(hipEventRecord(ws->ev_fork,st));
+  HIPCHK(hipStreamWaitEvent(ws->aux,ws->ev_fork,0));
+  hipLaunchKernelGGL(k_classify_rel,dim3(nreads < 1024 ? nreads : 1024),dim3(WAVE),0,ws->aux,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->parent.p,(int32_t *)ws->eff.p,
                      (uint8_t *)ws->rpos.p,(int8_t *)ws->asgn.p,totalI);
-  // size classes (kernels.hip: REL_SMALL_*): M <= 192 four reads per wave, up to 1024 one read per wave, larger: sequential kernel above
-  hipLaunchKernelGGL(k_order_by_work,dim3(1),dim3(1024),0,st,(const int32_t *)ws->nrel.p,nreads,0,(int32_t *)ws->perm.p);
-  // (the classes touch disjoint reads; the long-read class is a handful of latency-bound waves, so it
-  //  runs beside the main class on the auxiliary stream)
-  HIPCHK(hipEventRecord(ws->ev_fork,st));
-  HIPCHK(hipStreamWaitEvent(ws->aux,ws->ev_fork,0));
   hipLaunchKernelGGL((k_classify_rel_grp<REL_SMALL_MAXM,1024,1>),dim3(nreads < 2048 ? nreads : 2048),dim3(WAVE),0,ws->aux,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI,(const int32_t *)ws->perm.p);
@@ -360,15 +362,16 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
 
   // ---- stage 5: classify_unrel -------------------------------------------------------------------
   ENSURE(ws->ord,(size_t)totalI*4);
-  hipLaunchKernelGGL(k_classify_unrel,dim3(nreads < 1024 ? nreads : 1024),dim3(WAVE),0,st,
-                     p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
-                     (int32_t *)ws->ord.p);
-  // size classes (kernels.hip: UNREL_SMALL_*): N <= 256 and up to 1024, two reads per wave each (four speculative update slots per read), larger: sequential kernel above
+  // size classes (kernels.hip: UNREL_SMALL_*): N <= 256 and up to 1024, two reads per wave each (four speculative update
+  // slots per read), larger: the sequential kernel; the rare classes on the auxiliary stream again
   ENSURE(ws->memo_val,(size_t)totalI*8*8);
   ENSURE(ws->memo_key,(size_t)totalI*8*4);
   hipLaunchKernelGGL(k_order_by_work,dim3(1),dim3(1024),0,st,(const int32_t *)ws->nintvl.p,nreads,0,(int32_t *)ws->perm.p);
   HIPCHK(hipEventRecord(ws->ev_fork,st));
   HIPCHK(hipStreamWaitEvent(ws->aux,ws->ev_fork,0));
+  hipLaunchKernelGGL(k_classify_unrel,dim3(nreads < 1024 ? nreads : 1024),dim3(WAVE),0,ws->aux,
+                     p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
+                     (int32_t *)ws->ord.p);
   hipLaunchKernelGGL((k_classify_unrel_grp<UNREL_SMALL_MAXN,1024,2>),dim3((nreads+1)/2 < 2048 ? (nreads+1)/2 : 2048),dim3(WAVE),0,ws->aux,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
                      (double *)ws->memo_val.p,(int32_t *)ws->memo_key.p,(const int32_t *)ws->perm.p);

@@ -12,6 +12,12 @@ corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE is in KiB and counts 1/2
 import collections
 import csv
 import glob
+
+
+def newest(pattern):
+    """gpurun merges every call's files into the same directory: take the latest run's"""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
 import json
 import os
 import shutil
@@ -22,7 +28,7 @@ tag, name = sys.argv[1], sys.argv[2]
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-shutil.copy(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, name + "_kernel_stats.csv"))
+shutil.copy(newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), os.path.join(dst, name + "_kernel_stats.csv"))
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
 json.dump(bench, open(os.path.join(dst, name + "_bench.json"), "w"), indent=1)
 kmers = bench["roofline"]["algorithmic_bytes_per_launch"] / 2.0
@@ -33,7 +39,7 @@ kernel_id = _bench_mod.scan_kernel_id()
 agg = collections.defaultdict(list)
 grid = {}
 for kind in ("fetch", "write"):
-    for r in csv.DictReader(open(glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv"))[0])):
+    for r in csv.DictReader(open(newest(os.path.join(src, kind, "*", "*_counter_collection.csv")))):
         agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
 with open(os.path.join(dst, name + "_pmc.txt"), "w") as f:
     f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 1 --warmup 1 --no-cpu --no-extras`\n")
@@ -57,7 +63,7 @@ print(open(os.path.join(dst, "scan_pmc.json")).read())
 
 # The default bench keeps two sub-batches in flight, so the scan launches of the pipeline overlap with other kernels; the
 # launches of bench.py's roofline loop (the last ones, back-to-back on one stream) are the ones its HIP events time.
-tr = glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))[0]
+tr = newest(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))
 rows = [r for r in csv.DictReader(open(tr)) if r["Kernel_Name"].startswith("k_scan_candidates")]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
