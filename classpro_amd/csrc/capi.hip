@@ -140,7 +140,7 @@ struct dbuf { void *p; size_t cap; };
 
 struct cp_workspace
   { dbuf bitmap, ncand, nintvl, nrel, ioff, eoff, hoff, wall, wall_s, hkeys, hvals, eintvl, ointvl, intvl, rintvl,
-         relmap, parent, eff, rpos, asgn, ord, err, memo_val, memo_key, perm, wlist, err2,
+         relmap, parent, eff, rpos, asgn, ord, err, memo_val, memo_key, perm, wlist, err2, tres, fwc,
          s_cap, s_rcap, s_dummy, s_key, s_seg, s_aux, s_mi, s_rep, s_repcnt;
     int64_t *h_totals;        // pinned: [totalI, totalE, totalH]
     int32_t *h_err;           // pinned
@@ -191,7 +191,7 @@ extern "C" void cp_workspace_destroy(cp_workspace *ws)
 { if (!ws) return;
   dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
                   &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
-                  &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist,&ws->err2,
+                  &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist,&ws->err2,&ws->tres,&ws->fwc,
                   &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_rep,&ws->s_repcnt };
   for (dbuf *b : all) if (b->p) (void)hipFree(b->p);
   if (ws->aux) (void)hipStreamDestroy(ws->aux);
@@ -206,7 +206,7 @@ extern "C" size_t cp_workspace_bytes(const cp_workspace *ws)
 { if (!ws) return 0;
   const dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
                         &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
-                        &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist,&ws->err2,
+                        &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist,&ws->err2,&ws->tres,&ws->fwc,
                   &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_rep,&ws->s_repcnt };
   size_t s = 0;
   for (const dbuf *b : all) s += b->cap;
@@ -310,12 +310,21 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   ENSURE(ws->wlist,(size_t)totalI*4*4);
   // longest reads first: key = wall candidates / 4 (bins of 4 up to 4096 candidates)
   hipLaunchKernelGGL(k_order_by_work,dim3(1),dim3(1024),0,st,(const int32_t *)ws->ncand.p,nreads,2,(int32_t *)ws->perm.p);
+  ENSURE(ws->tres,(size_t)totalI*sizeof(task_res));
+  ENSURE(ws->fwc,(size_t)nreads*16);
+  // the walk's read-only part (candidate list, filters, the pure part of every live (candidate, error type) pair), then
+  // the replay and the list phases: two kernels because the first wants registers and the second waves (kernels.hip)
+  hipLaunchKernelGGL(k_wall_tasks,dim3(nreads),dim3(WAVE),0,st,
+                     p->dev,d_seq,d_seq_off,d_prof,d_prof_off,nreads,(const uint64_t *)ws->bitmap.p,(uint8_t *)ws->wall.p,
+                     (const int64_t *)ws->ioff.p,(const int32_t *)ws->perm.p,(int32_t *)ws->wlist.p,(task_res *)ws->tres.p,
+                     (int32_t *)ws->fwc.p);
   hipLaunchKernelGGL(k_find_wall,dim3(nreads),dim3(WAVE),0,st,
-                     p->dev,d_seq,d_seq_off,d_prof,d_prof_off,nreads,(const uint64_t *)ws->bitmap.p,
+                     p->dev,d_seq,d_seq_off,d_prof,d_prof_off,nreads,
                      (uint8_t *)ws->wall.p,(uint8_t *)ws->wall_s.p,(int32_t *)ws->hkeys.p,(double *)ws->hvals.p,(const int64_t *)ws->hoff.p,
                      (cp_eintvl *)ws->eintvl.p,(cp_eintvl *)ws->ointvl.p,
                      (const int64_t *)ws->eoff.p,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,
-                     (int32_t *)ws->nintvl.p,(int32_t *)ws->err.p,(const int32_t *)ws->perm.p,(int32_t *)ws->wlist.p);
+                     (int32_t *)ws->nintvl.p,(int32_t *)ws->err.p,(const int32_t *)ws->perm.p,(int32_t *)ws->wlist.p,
+                     (const task_res *)ws->tres.p,(const int32_t *)ws->fwc.p);
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_WALL)
     return CP_OK;

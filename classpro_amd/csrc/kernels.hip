@@ -451,75 +451,49 @@ __device__ unsigned long long g_live_prof[8];
 #define PH_STAMP(k) ((void)0)
 #endif
 
-// k_find_wall is a chain of dependent cold loads and FP64 latencies, so it wants waves, not registers:
-// capped at 96 VGPRs (5 waves per SIMD; measured 3: 7.77, 4: 7.63, 5: 7.44, 6: 7.67, 8: 7.89 ms per step
-// against 8.32 ms uncapped at 188 VGPRs / 2 waves).
+// The walk of wall.c:590-707 is two kernels.  Every load of the reference's walk is a cold miss here (the profile,
+// bases and flag arrays of a sub-batch do not stay in L2), a candidate's loads depend on each other, and its binomial-tail
+// evaluations are long serial chains, so the walk is split (cp_wall.h) into
+//   0.  the wave lists the read's candidate positions from the bitmap (64 words per step);
+//   1a. 64 candidates at a time, lane k evaluates candidate k's shared prelude and the threshold filters of both error
+//       types (cp_wall_candidate_pre / _filter) and the (candidate, error type) pairs that stay alive -- ~40 % for
+//       SELF, ~3 % for OTHERS -- are appended to a task list;
+//   1b. 64 tasks at a time, lane k evaluates everything else about its pair that is a function of the read alone
+//       (cp_wall_candidate_live: own P(error), low-complexity partner, best high-complexity partner).  Dense lanes
+//       matter: this is where the instructions are -- and the registers: 96 VGPRs and 192 bytes of spills with this
+//       part inside, 70 and none without it;
+//   2.  the candidates are replayed in order (cp_wall_candidate_replay: paired flags, perror memo, flag and
+//       interval-list updates), the SELF pass on lane 0 and the OTHERS pass on lane 1 (disjoint state: own flag
+//       array, own memo table, own interval list).
+// k_wall_tasks does 0-1b (5 waves per SIMD) and leaves the lists and the task results in HBM; k_find_wall does 2 and
+// the list phases after the walk at 7 waves per SIMD: they are chains of dependent loads and want waves, not registers.
+// Scratch: the four int lists of `wl` hold per candidate [0] maxt,maxl and both filter results, [1] the position,
+// [2] the count pair, and [3] the task list; `tres` the task results; `fwc` per read n_c, n_t, SELF tasks, overflow.
+struct task_res { double own_pe, lc_v, hc_pe; int lc_j, hc;  };   // hc: lc_kind | (hc_j >= 0) << 2 | (hc_j - i) << 16
+
 #ifndef FW_WAVES_PER_EU
 #define FW_WAVES_PER_EU 5
 #endif
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FW_WAVES_PER_EU)))
-k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, const int64_t *__restrict__ seq_off,
-            const uint16_t *__restrict__ prof, const int64_t *__restrict__ prof_off, int nreads,
-            const uint64_t *__restrict__ bm, uint8_t *__restrict__ wall_all, uint8_t *__restrict__ walls_all,
-            int32_t *__restrict__ hkeys, double *__restrict__ hvals, const int64_t *__restrict__ hoff,
-            cp_eintvl *__restrict__ eintvl_all, cp_eintvl *__restrict__ ointvl_all, const int64_t *__restrict__ eoff,
-            cp_intvl *__restrict__ intvl_all, const int64_t *__restrict__ ioff,
-            int32_t *__restrict__ nintvl, int32_t *__restrict__ err, const int32_t *__restrict__ perm,
-            int32_t *__restrict__ wlist)
+k_wall_tasks(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, const int64_t *__restrict__ seq_off,
+             const uint16_t *__restrict__ prof, const int64_t *__restrict__ prof_off, int nreads,
+             const uint64_t *__restrict__ bm, uint8_t *__restrict__ wall_all, const int64_t *__restrict__ ioff,
+             const int32_t *__restrict__ perm, int32_t *__restrict__ wlist, task_res *__restrict__ tres_all,
+             int32_t *__restrict__ fwc)
 { if ((int)blockIdx.x >= nreads) return;
   const int r = perm[blockIdx.x];
   const int lane = lane_id();
   const int64_t po = prof_off[r];
   const int plen = (int)(prof_off[r+1]-po);
   const int rlen = (int)(seq_off[r+1]-seq_off[r]);
-
-  constexpr int LCAP0 = 256, LCAP1 = 64;                 // on-chip memo slots of the SELF / OTHERS pass
-  __shared__ int32_t s_mkey[LCAP0+LCAP1];
-  __shared__ double  s_mval[LCAP0+LCAP1];
   cp_read_t<cp_perr_hybrid> R;
   R.P = P; R.prof = prof+po; R.seq = seq+seq_off[r]; R.lf = P->logfact; R.plen = plen; R.rlen = rlen;
-  R.wall = wall_all+po+r;
-  R.wall_s = walls_all+po+r;
-  { const int64_t ho = hoff[r], hc = (hoff[r+1]-ho) >> 1;     // two tables, one per error type
-    R.perror.g.keys = hkeys+ho;
-    R.perror.g.vals = hvals+ho*4;
-    R.perror.g.mask = (uint32_t)hc-1;
-    R.perror.lkeys = (CP_LDS_PTR(int32_t))s_mkey;
-    R.perror.lvals = (CP_LDS_PTR(double))s_mval;
-    R.perror.lcap0 = LCAP0; R.perror.lcap1 = LCAP1;
-    R.perror.use_lds = 0;
-  }
-  for (int k = lane; k < LCAP0+LCAP1; k += WAVE)
-    s_mkey[k] = -1;
-  R.eintvl = eintvl_all+eoff[r];
-  R.ointvl = ointvl_all+eoff[r];
-  R.ecap = (int)(eoff[r+1]-eoff[r]);
-  R.eidx = R.oidx = 0; R.overflow = 0;
-  cp_intvl *intvl = intvl_all+ioff[r];
+  R.wall = wall_all+po+r; R.wall_s = R.wall;
+  R.eintvl = R.ointvl = nullptr; R.ecap = 0; R.eidx = R.oidx = 0; R.overflow = 0;
   const int icap = (int)(ioff[r+1]-ioff[r]);
   int32_t *wl = wlist+ioff[r]*4;                        // four int32 lists of capacity icap
+  task_res *tres = tres_all+ioff[r];
   uint8_t *wall = R.wall;
-  const uint8_t *wall_s = R.wall_s;
-
-  // ---- candidate walk (wall.c:590-707) ----------------------------------------------------------
-  // Every load of the reference's walk is a cold miss here (the profile, bases and flag arrays of a
-  // 200-Mbase batch do not stay in L2), a candidate's loads depend on each other, and its Bessel /
-  // binomial-tail evaluations are long serial chains.  The walk is therefore split (cp_wall.h):
-  //   0. the wave lists the read's candidate positions from the bitmap (64 words per step);
-  //   1a. 64 candidates at a time, lane k evaluates candidate k's shared prelude and the threshold
-  //       filters of both error types (cp_wall_candidate_pre / _filter) and the (candidate, error type)
-  //       pairs that stay alive -- ~40 % for SELF, ~3 % for OTHERS -- are appended to a task list;
-  //   1b. 64 tasks at a time, lane k evaluates everything else about its pair that is a function of the
-  //       read alone (cp_wall_candidate_live: own P(error), low-complexity partner, best high-complexity
-  //       partner).  Dense lanes matter: this is where the kernel's instructions are;
-  //   2. the candidates are replayed in order (cp_wall_candidate_replay: paired flags, perror memo,
-  //      flag and interval-list updates), the SELF pass on lane 0 and the OTHERS pass on lane 1
-  //      (disjoint state: own flag array, own memo table, own interval list).
-  // Scratch: the four int lists of `wl` (free until the post-walk phases) hold per candidate
-  // [0] maxt,maxl and both filter results, [1] the position, [2] the count pair, and [3] the task list;
-  // task results stay on chip.
-  struct task_res { double own_pe, lc_v, hc_pe; int lc_j, hc;  };   // hc: lc_kind | (hc_j >= 0) << 2 | (hc_j - i) << 16
-  __shared__ task_res s_res[WAVE];
   int32_t *cinfo = wl, *clist = wl+icap, *ccnt = wl+2*(int64_t)icap, *tlist = wl+3*(int64_t)icap;
   int n_c = 0;
 #ifdef CP_PROF_WALK
@@ -571,32 +545,14 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
       n_t += tot;
       n_live0 += __popcll(__ballot(l0));
     }
-  if (n_t > icap) { R.overflow = 1; n_t = 0; n_c = 0; }   // cannot happen: 2*n_c <= icap
-  // a pass memoises at most two entries per live candidate (its own and its low-complexity partner's)
-  R.perror.use_lds = ((8*n_live0 <= 3*LCAP0) ? 1 : 0) | ((8*(n_t-n_live0) <= 3*LCAP1) ? 2 : 0);
-  // a pass whose memo does not fit on chip uses its table in HBM: empty it here (the few reads that need one), instead
-  // of a memset over every read's tables per batch
-  { const int hc = (int)R.perror.g.mask+1;
-    for (int e = 0; e < 2; e++)
-      if (!((R.perror.use_lds >> e) & 1))
-        for (int k = lane; k < hc; k += WAVE) R.perror.g.keys[(size_t)e*hc+k] = -1;
-  }
+  int ovf = 0;
+  if (n_t > icap) { ovf = 1; n_t = 0; n_c = 0; }        // cannot happen: 2*n_c <= icap
   wave_sync();
-  // 1b + 2, 64 tasks at a time: lane k evaluates task k and leaves the result in LDS; then the chunk is
-  //    replayed in order, lane 0 taking the SELF tasks and lane 1 the OTHERS tasks (one lane active per task;
-  //    position and count pair come from the evaluating lane's registers by readlane).
-  if (lane < 2)
-    { R.use_win = (P->K+24+CP_MAX_N_HC < 128) ? 1 : 0;
-      R.win_base = 0; R.win_lo = R.win_hi = 0;
-      R.spec_wallnow = 1;
-    }
-  for (int tb = 0; tb < n_t; tb += WAVE)
+  for (int tb = 0; tb < n_t; tb += WAVE)                // 1b: lane k evaluates task k
     { const int nb = (n_t-tb < WAVE) ? n_t-tb : WAVE;
-      int code_l = 0, cc_l = 0, pos_l = 1;
       if (lane < nb)
         { const int code = tlist[tb+lane], k = code >> 1, e = code & 1;
           const int i = clist[k], tl = cinfo[k] & 255, cc = ccnt[k];
-          code_l = code; cc_l = cc; pos_l = i;
           cp_wall_pre pre;
           const int cim1 = cc & 0xffff, ci = (cc >> 16) & 0xffff;
           pre.cng = cim1 > ci ? cim1-ci : ci-cim1;
@@ -612,10 +568,94 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
           q.own_pe = c.own_pe; q.lc_v = c.lc_v; q.hc_pe = c.hc_pe;
           q.lc_j = c.lc_j;
           q.hc = c.lc_kind | (c.hc_j >= 0 ? 4 : 0) | ((c.hc_j >= 0 ? c.hc_j-i : 0) << 16);
-          s_res[lane] = q;
+          tres[tb+lane] = q;
+        }
+    }
+  PH_STAMP(6);
+  if (lane == 0) { fwc[4*(int64_t)r] = n_c; fwc[4*(int64_t)r+1] = n_t; fwc[4*(int64_t)r+2] = n_live0; fwc[4*(int64_t)r+3] = ovf; }
+}
+
+#ifndef FW2_WAVES_PER_EU
+#define FW2_WAVES_PER_EU 7
+#endif
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FW2_WAVES_PER_EU)))
+k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, const int64_t *__restrict__ seq_off,
+            const uint16_t *__restrict__ prof, const int64_t *__restrict__ prof_off, int nreads,
+            uint8_t *__restrict__ wall_all, uint8_t *__restrict__ walls_all,
+            int32_t *__restrict__ hkeys, double *__restrict__ hvals, const int64_t *__restrict__ hoff,
+            cp_eintvl *__restrict__ eintvl_all, cp_eintvl *__restrict__ ointvl_all, const int64_t *__restrict__ eoff,
+            cp_intvl *__restrict__ intvl_all, const int64_t *__restrict__ ioff,
+            int32_t *__restrict__ nintvl, int32_t *__restrict__ err, const int32_t *__restrict__ perm,
+            int32_t *__restrict__ wlist, const task_res *__restrict__ tres_all, const int32_t *__restrict__ fwc)
+{ if ((int)blockIdx.x >= nreads) return;
+  const int r = perm[blockIdx.x];
+  const int lane = lane_id();
+  const int64_t po = prof_off[r];
+  const int plen = (int)(prof_off[r+1]-po);
+  const int rlen = (int)(seq_off[r+1]-seq_off[r]);
+
+  constexpr int LCAP0 = 256, LCAP1 = 64;                 // on-chip memo slots of the SELF / OTHERS pass
+  __shared__ int32_t s_mkey[LCAP0+LCAP1];
+  __shared__ double  s_mval[LCAP0+LCAP1];
+  cp_read_t<cp_perr_hybrid> R;
+  R.P = P; R.prof = prof+po; R.seq = seq+seq_off[r]; R.lf = P->logfact; R.plen = plen; R.rlen = rlen;
+  R.wall = wall_all+po+r;
+  R.wall_s = walls_all+po+r;
+  { const int64_t ho = hoff[r], hc = (hoff[r+1]-ho) >> 1;     // two tables, one per error type
+    R.perror.g.keys = hkeys+ho;
+    R.perror.g.vals = hvals+ho*4;
+    R.perror.g.mask = (uint32_t)hc-1;
+    R.perror.lkeys = (CP_LDS_PTR(int32_t))s_mkey;
+    R.perror.lvals = (CP_LDS_PTR(double))s_mval;
+    R.perror.lcap0 = LCAP0; R.perror.lcap1 = LCAP1;
+    R.perror.use_lds = 0;
+  }
+  for (int k = lane; k < LCAP0+LCAP1; k += WAVE)
+    s_mkey[k] = -1;
+  R.eintvl = eintvl_all+eoff[r];
+  R.ointvl = ointvl_all+eoff[r];
+  R.ecap = (int)(eoff[r+1]-eoff[r]);
+  R.eidx = R.oidx = 0; R.overflow = 0;
+  cp_intvl *intvl = intvl_all+ioff[r];
+  const int icap = (int)(ioff[r+1]-ioff[r]);
+  int32_t *wl = wlist+ioff[r]*4;                        // four int32 lists of capacity icap
+  const task_res *tres = tres_all+ioff[r];
+  uint8_t *wall = R.wall;
+  const uint8_t *wall_s = R.wall_s;
+  __shared__ task_res s_res[WAVE];
+  int32_t *clist = wl+icap, *ccnt = wl+2*(int64_t)icap, *tlist = wl+3*(int64_t)icap;
+  const int n_c = fwc[4*(int64_t)r], n_t = fwc[4*(int64_t)r+1], n_live0 = fwc[4*(int64_t)r+2];
+  if (fwc[4*(int64_t)r+3]) R.overflow = 1;
+#ifdef CP_PROF_WALK
+  unsigned long long ph_t = wall_clock64();
+#endif
+  // a pass memoises at most two entries per live candidate (its own and its low-complexity partner's)
+  R.perror.use_lds = ((8*n_live0 <= 3*LCAP0) ? 1 : 0) | ((8*(n_t-n_live0) <= 3*LCAP1) ? 2 : 0);
+  // a pass whose memo does not fit on chip uses its table in HBM: empty it here (the few reads that need one), instead
+  // of a memset over every read's tables per batch
+  { const int hc = (int)R.perror.g.mask+1;
+    for (int e = 0; e < 2; e++)
+      if (!((R.perror.use_lds >> e) & 1))
+        for (int k = lane; k < hc; k += WAVE) R.perror.g.keys[(size_t)e*hc+k] = -1;
+  }
+  wave_sync();
+  // 2, 64 tasks at a time: the chunk's task results come from HBM into LDS, then the chunk is replayed in order,
+  //    lane 0 taking the SELF tasks and lane 1 the OTHERS tasks (one lane active per task; position and count pair
+  //    come from the loading lane's registers by readlane).
+  if (lane < 2)
+    { R.use_win = (P->K+24+CP_MAX_N_HC < 128) ? 1 : 0;
+      R.win_base = 0; R.win_lo = R.win_hi = 0;
+      R.spec_wallnow = 1;
+    }
+  for (int tb = 0; tb < n_t; tb += WAVE)
+    { const int nb = (n_t-tb < WAVE) ? n_t-tb : WAVE;
+      int code_l = 0, cc_l = 0, pos_l = 1;
+      if (lane < nb)
+        { const int code = tlist[tb+lane], k = code >> 1;
+          code_l = code; cc_l = ccnt[k]; pos_l = clist[k];
+          s_res[lane] = tres[tb+lane];
         }
       wave_sync();
-      PH_STAMP(6);
       for (int k = 0; k < nb; k++)
         { const int code = __builtin_amdgcn_readlane(code_l,k), cc = __builtin_amdgcn_readlane(cc_l,k);
           const int pos = __builtin_amdgcn_readlane(pos_l,k);
