@@ -140,7 +140,7 @@ struct dbuf { void *p; size_t cap; };
 
 struct cp_workspace
   { dbuf bitmap, ncand, nintvl, nrel, ioff, eoff, hoff, wall, wall_s, hkeys, hvals, eintvl, ointvl, intvl, rintvl,
-         relmap, parent, eff, rpos, asgn, ord, err, memo_val, memo_key, perm, wlist, err2, tres, fwc,
+         relmap, parent, eff, rpos, asgn, ord, err, memo_val, memo_key, perm, wlist, err2, tres, fwc, dtot,
          s_cap, s_rcap, s_dummy, s_key, s_seg, s_aux, s_mi, s_rep, s_repcnt;
     int64_t *h_totals;        // pinned: [totalI, totalE, totalH]
     int32_t *h_err;           // pinned
@@ -191,7 +191,7 @@ extern "C" void cp_workspace_destroy(cp_workspace *ws)
 { if (!ws) return;
   dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
                   &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
-                  &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist,&ws->err2,&ws->tres,&ws->fwc,
+                  &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist,&ws->err2,&ws->tres,&ws->fwc,&ws->dtot,
                   &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_rep,&ws->s_repcnt };
   for (dbuf *b : all) if (b->p) (void)hipFree(b->p);
   if (ws->aux) (void)hipStreamDestroy(ws->aux);
@@ -206,7 +206,7 @@ extern "C" size_t cp_workspace_bytes(const cp_workspace *ws)
 { if (!ws) return 0;
   const dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
                         &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
-                        &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist,&ws->err2,&ws->tres,&ws->fwc,
+                        &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist,&ws->err2,&ws->tres,&ws->fwc,&ws->dtot,
                   &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_rep,&ws->s_repcnt };
   size_t s = 0;
   for (const dbuf *b : all) s += b->cap;
@@ -276,16 +276,15 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   hipLaunchKernelGGL(k_count_caps,dim3(nreads),dim3(WAVE),0,st,
                      (const uint64_t *)ws->bitmap.p,d_prof_off,nreads,
                      (int32_t *)ws->ncand.p,(int64_t *)ws->ioff.p,(int64_t *)ws->eoff.p,(int64_t *)ws->hoff.p);
+  ENSURE(ws->dtot,32);
   hipLaunchKernelGGL(k_prefix_caps,dim3(1),dim3(1024),0,st,(int64_t *)ws->ioff.p,(int64_t *)ws->eoff.p,
-                     (int64_t *)ws->hoff.p,nreads);
+                     (int64_t *)ws->hoff.p,nreads,(int64_t *)ws->dtot.p);
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_SCAN)
     return CP_OK;
 
   // the only host round trip of the pipeline: scratch sizes depend on the data
-  HIPCHK(hipMemcpyAsync(&ws->h_totals[0],(int64_t *)ws->ioff.p+nreads,8,hipMemcpyDeviceToHost,st));
-  HIPCHK(hipMemcpyAsync(&ws->h_totals[1],(int64_t *)ws->eoff.p+nreads,8,hipMemcpyDeviceToHost,st));
-  HIPCHK(hipMemcpyAsync(&ws->h_totals[2],(int64_t *)ws->hoff.p+nreads,8,hipMemcpyDeviceToHost,st));
+  HIPCHK(hipMemcpyAsync(&ws->h_totals[0],ws->dtot.p,24,hipMemcpyDeviceToHost,st));
   HIPCHK(hipStreamSynchronize(st));
   const int64_t totalI = ws->h_totals[0], totalE = ws->h_totals[1], totalH = ws->h_totals[2];
   ws->totalI = totalI; ws->totalE = totalE; ws->totalH = totalH;
@@ -525,10 +524,11 @@ extern "C" int cp_find_seeds_batch(const cp_params *p, cp_workspace *ws, const c
   HIPCHK(hipMemsetAsync(ws->s_dummy.p,0,((size_t)nreads+1)*8,st));
   hipLaunchKernelGGL(k_seed_caps,dim3(nreads),dim3(WAVE),0,st,d_prof,d_prof_off,d_labels,d_seq_off,K,nreads,
                      (int64_t *)ws->s_cap.p,(int64_t *)ws->s_rcap.p,(int32_t *)ws->s_key.p);
-  hipLaunchKernelGGL(k_prefix_caps,dim3(1),dim3(1024),0,st,(int64_t *)ws->s_cap.p,(int64_t *)ws->s_rcap.p,(int64_t *)ws->s_dummy.p,nreads);
+  ENSURE(ws->dtot,32);
+  hipLaunchKernelGGL(k_prefix_caps,dim3(1),dim3(1024),0,st,(int64_t *)ws->s_cap.p,(int64_t *)ws->s_rcap.p,(int64_t *)ws->s_dummy.p,nreads,
+                     (int64_t *)ws->dtot.p);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(&ws->h_totals[0],(int64_t *)ws->s_cap.p+nreads,8,hipMemcpyDeviceToHost,st));
-  HIPCHK(hipMemcpyAsync(&ws->h_totals[1],(int64_t *)ws->s_rcap.p+nreads,8,hipMemcpyDeviceToHost,st));
+  HIPCHK(hipMemcpyAsync(&ws->h_totals[0],ws->dtot.p,16,hipMemcpyDeviceToHost,st));
   HIPCHK(hipStreamSynchronize(st));
   const int64_t totalS = ws->h_totals[0], totalR = ws->h_totals[1];
   ws->seed_totalR = totalR;

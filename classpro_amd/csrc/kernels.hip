@@ -13,11 +13,14 @@
 //   k_scan_candidates   streaming pass over the profile (the HBM-roofline kernel): wall.c:590-607
 //   k_count_caps        per-read candidate count -> scratch capacities
 //   k_prefix_caps       exclusive prefix sums of the capacities (single block)
-//   k_find_wall         one wave per read: wall.c:570-958
+//   k_wall_tasks        one wave per read: the read-only part of the candidate walk, wall.c:590-707 (lists + task results to HBM)
+//   k_find_wall         one wave per read: the walk's in-order replay and everything after it, wall.c:639-958
 //   k_find_rel          one wave per read, one lane per interval: wall.c:960-1051
-//   k_classify_rel_grp   2 reads per wave (1 for M > 256), lane per transition: class_rel.c:871-963
-//   k_classify_unrel_grp 8 reads per wave (2 for N > 256), lane per likelihood term: class_unrel.c:248-300
-//   k_classify_rel / k_classify_unrel   sequential fallbacks for reads with > 1024 intervals
+//   k_classify_rel_grp   4 reads per wave (1 for M > 128), 8 lanes per direction: class_rel.c:871-963
+//   k_classify_unrel_grp 2 reads per wave, speculative update slots committed in order: class_unrel.c:248-300
+//   k_classify_rel / k_classify_unrel   sequential forms for reads with > 1024 intervals or > 65535 k-mers
+//   k_skellam_table     the table of logp_trans values (cp_types.h), filled once per cp_params
+//   k_seed_caps / k_find_seeds   the -s seed path, one wave per read (cp_seed_wave.h): seed.c:966-1032
 //   k_paint_labels      one wave per read: ClassPro.c:116-119,265-271
 //   k_seq_context       dense context arrays (stage API / parity tests only): context.c:8-108
 //   k_decode_profiles   FASTK code strings -> counts on the device: libfastk.c:1467-1534
@@ -233,8 +236,8 @@ __device__ __forceinline__ T block_scan_excl_1024(T x, T *tmp, T *total)
 }
 
 __global__ void __launch_bounds__(1024)
-k_prefix_caps(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__restrict__ c, int n)
-{ __shared__ int64_t tmp[16], tot;
+k_prefix_caps(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__restrict__ c, int n, int64_t *__restrict__ totals)
+{ __shared__ int64_t tmp[16], tot;                        // totals (may be null): the three sums side by side, one D2H copy
   const int t = threadIdx.x;
   int64_t *arr[3] = { a, b, c };
 #pragma unroll
@@ -249,7 +252,7 @@ k_prefix_caps(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__restr
           carry += tot;
           __syncthreads();
         }
-      if (t == 0) v[n] = carry;
+      if (t == 0) { v[n] = carry; if (totals) totals[q] = carry; }
       __syncthreads();
     }
 }
