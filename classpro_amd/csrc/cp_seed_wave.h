@@ -307,17 +307,26 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
   // A segment that would start at the last k-mer is never made (the reference's loop ends first).
   { bool carry = false;                                      // the run entering the chunk already holds a valid k-mer
     int ob = 0, oc = 0; bool open = false;                   // the segment whose end is not known yet
+    // the loads of a step are issued one step ahead, so that they are in flight while lane 0 runs the chain
+    int ncnt[SW_STEP], ncpv[SW_STEP]; char ncl[SW_STEP], nst[SW_STEP];
+    auto load_step = [&](int e0)
+      {
+#pragma unroll
+        for (int u = 0; u < SW_STEP; u++)
+          { const int p = e0+u*WAVE+lane;
+            const bool in = p < plen;
+            ncnt[u] = in ? (int)R.prof[p] : 0;
+            ncpv[u] = (in && p > 0) ? (int)R.prof[p-1] : -1;
+            ncl[u] = in ? R.cls[p] : (char)0;
+            nst[u] = (in && rep) ? R.state[p] : (char)'E';
+          }
+      };
+    load_step(0);
     for (int e0 = 0; e0 < plen; e0 += SW_STEP*WAVE)
       { int cnt[SW_STEP], cpv[SW_STEP]; char cl[SW_STEP], st[SW_STEP];
 #pragma unroll
-        for (int u = 0; u < SW_STEP; u++)                    // all loads of the step first
-          { const int p = e0+u*WAVE+lane;
-            const bool in = p < plen;
-            cnt[u] = in ? (int)R.prof[p] : 0;
-            cpv[u] = (in && p > 0) ? (int)R.prof[p-1] : -1;
-            cl[u] = in ? R.cls[p] : (char)0;
-            st[u] = (in && rep) ? R.state[p] : (char)'E';
-          }
+        for (int u = 0; u < SW_STEP; u++) { cnt[u] = ncnt[u]; cpv[u] = ncpv[u]; cl[u] = ncl[u]; st[u] = nst[u]; }
+        if (e0+SW_STEP*WAVE < plen) load_step(e0+SW_STEP*WAVE);
         uint64_t sm[SW_STEP];
 #pragma unroll
         for (int u = 0; u < SW_STEP; u++)
