@@ -21,7 +21,7 @@
 //     whose predecessor run held a valid k-mer, or it is position 0): no walk over the positions.  Label runs for
 //     anno_repeat, the stable radix sort by window count (ballot ranks), the group tests against the masked-interval
 //     list (64 sorted segments at once) and the ntHash of a taken segment's k-mers (a lane per k-mer over a table of
-//     pre-rotated seeds in LDS, wave minimum) are wave-parallel too.
+//     pre-rotated seeds, wave minimum) are wave-parallel too.
 //   * lane 0: the one inherently sequential chain -- the monotone deque that gives every segment its window count --
 //     with its state on chip: the deque's two ends in registers, the ring in LDS.
 //   * the masked-interval list is restated slot for slot: the reference searches and sorts one slot past the live part
@@ -33,8 +33,8 @@
 #pragma once
 #include "cp_seed.h"
 
-#define SW_DQ    128
-#define SW_MI    512
+#define SW_DQ    64
+#define SW_MI    256
 #define SW_PEND  64
 #define SW_REP   64
 #define SW_KMAX  64                              // k-mer lengths served by the rotated-seed table (longer: byte-wise fold)
@@ -47,7 +47,6 @@ struct cp_seedw_lds
     int32_t  bins[32];
     int32_t  pend_b[SW_PEND], pend_e[SW_PEND];
     int32_t  rep[2*SW_REP];                      // repetitive stretches in k-mer coordinates while they fit
-    uint64_t rot[5*SW_KMAX];                     // rot[c*SW_KMAX+k] = seed of base class c rotated k times (c = 4: zero)
   };
 
 __shared__ cp_seedw_lds sw_S;                    // the wave's LDS block (one wave per workgroup)
@@ -77,13 +76,25 @@ __device__ __forceinline__ int sw_first(int v) { return __builtin_amdgcn_readfir
 
 // k applications of cp_nt_srol (nthash.h:181-207: rol1, then bits 0 and 33 swapped) = the low 33 bits and the high 31
 // bits each rotated left by k within themselves
-__device__ __forceinline__ uint64_t sw_srol_k(uint64_t v, int k)
+constexpr uint64_t sw_srol_k(uint64_t v, int k)
 { const uint64_t lo = v & 0x1ffffffffull, hi = v >> 33;
   const int a = k % 33, b = k % 31;
   const uint64_t l2 = a ? (((lo << a) | (lo >> (33-a))) & 0x1ffffffffull) : lo;
   const uint64_t h2 = b ? (((hi << b) | (hi >> (31-b))) & 0x7fffffffull) : hi;
   return l2 | (h2 << 33);
 }
+// rot[c*SW_KMAX+k] = seed of base class c (A C G T, 4 = none: zero) rotated k times: msTab of nthash.h, made at compile
+// time; read-only device memory (its 2.5 KB stay in the caches; in LDS they cost every wave a fifth of its block)
+struct sw_rot_tab { uint64_t v[5*SW_KMAX]; };
+constexpr sw_rot_tab sw_make_rot()
+{ sw_rot_tab t{};
+  for (int c = 0; c < 5; c++)
+    for (int k = 0; k < SW_KMAX; k++)
+      t.v[c*SW_KMAX+k] = sw_srol_k(c == 0 ? 0x3c8bfbb395c60474ull : c == 1 ? 0x3193c18562a02b4cull : c == 2 ? 0x20323ed082572324ull
+                                   : c == 3 ? 0x295549f54be24456ull : 0ull,k);
+  return t;
+}
+__device__ const sw_rot_tab sw_ROT = sw_make_rot();
 
 // ---- the masked-interval list (seed.c:120-188), in LDS or (big) in the read's HBM scratch ------------------------
 struct sw_list
@@ -202,8 +213,8 @@ __device__ __attribute__((noinline)) void sw_mark(const char *seq, const char *c
                 { uint64_t fh = 0, rh = 0;
                   for (int t = 0; t < K; t++)
                     { const int code = sw_S.cval[lane+t];
-                      fh ^= sw_S.rot[(code & 7)*SW_KMAX+(K-1-t)];
-                      rh ^= sw_S.rot[(code >> 3)*SW_KMAX+t];
+                      fh ^= sw_ROT.v[(code & 7)*SW_KMAX+(K-1-t)];
+                      rh ^= sw_ROT.v[(code >> 3)*SW_KMAX+t];
                     }
                   h = (int)((rh < fh ? rh : fh) % CP_SEED_MOD);
                 }
@@ -540,13 +551,6 @@ __device__ __forceinline__ int sw_find_seeds(const cp_seedw_read &R, int lane SW
 { const int plen = R.plen, K = R.K, Km1 = K-1;
   if (plen <= 0) return 0;
   for (int q = lane; q < SW_MI; q += WAVE) { sw_S.mi_b[q] = 0; sw_S.mi_e[q] = 0; }     // defined start state of the list
-  if (K <= SW_KMAX)                                          // seeds of A C G T rotated 0..63 times (msTab of nthash.h, made on the spot)
-    for (int q = lane; q < 5*SW_KMAX; q += WAVE)
-      { const int c = q/SW_KMAX, k = q % SW_KMAX;
-        const uint64_t sd = c == 0 ? 0x3c8bfbb395c60474ull : c == 1 ? 0x3193c18562a02b4cull : c == 2 ? 0x20323ed082572324ull
-                          : c == 3 ? 0x295549f54be24456ull : 0ull;
-        sw_S.rot[q] = sw_srol_k(sd,k);
-      }
   sw_list Lm; Lm.gb = R.gmi_b; Lm.ge = R.gmi_e; Lm.big = false;
   // ---- unique / repetitive stretches -> .rep intervals (seed.c:482-566): label runs from a ballot, lane 0 over the runs ----
   const int min_uniq = (int)(K*2.5);

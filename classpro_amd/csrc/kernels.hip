@@ -1924,7 +1924,10 @@ __device__ unsigned long long g_seed_prof[8];
 #endif
 #include "cp_seed_wave.h"
 // One wave per read (cp_seed_wave.h).
-__global__ void __launch_bounds__(WAVE)
+#ifndef SW_WAVES
+#define SW_WAVES 6
+#endif
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SW_WAVES)))
 k_find_seeds(const char *__restrict__ seq, const int64_t *__restrict__ seq_off, const uint16_t *__restrict__ prof,
              const int64_t *__restrict__ prof_off, const char *__restrict__ labels, int K, int nreads,
              const int64_t *__restrict__ soff, const int64_t *__restrict__ roff, const int32_t *__restrict__ perm,
