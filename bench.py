@@ -41,8 +41,8 @@ K = 40
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--genome", type=float, default=200e6, help="synthetic diploid genome length (configs[2]: 200 Mbp)")
     ap.add_argument("--cov", type=int, default=40)
     ap.add_argument("--read-len", type=int, default=20000)
