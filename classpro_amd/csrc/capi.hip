@@ -26,6 +26,7 @@ struct cp_params
   { cp_dev_params  host;
     cp_dev_params *dev;
     double        *skel;                   // device table of logp_trans values (cp_types.h), or NULL
+    double        *uerr;                   // device table of classify_unrel's binomial-test logs, or NULL
   };
 
 extern "C" int cp_hist_covs(const int64_t *hist, int low, int high, int64_t ilowcnt, int64_t ihighcnt,
@@ -102,6 +103,20 @@ extern "C" int cp_params_create_model(int K, int read_len, int hcov, int dcov, c
           }
       }
     else { p->skel = NULL; (void)hipGetLastError(); }       // no room for the table: every value is computed on the spot
+    // (the second table is small: 1024 x 1024 doubles; it goes with the first one)
+    p->uerr = NULL;
+    const int emax = 1023;
+    if (p->skel && hipMalloc((void **)&p->uerr,(size_t)(emax+1)*(emax+1)*8) == hipSuccess)
+      { hipLaunchKernelGGL(k_uerr_table,dim3(1024),dim3(256),0,0,p->dev,p->uerr,emax);
+        p->host.uerr = p->uerr; p->host.uerr_max = emax;
+        hipError_t e2 = hipGetLastError();
+        if (e2 == hipSuccess) e2 = hipMemcpy(p->dev,&p->host,sizeof(cp_dev_params),hipMemcpyHostToDevice);
+        if (e2 != hipSuccess)
+          { (void)hipFree(p->uerr); (void)hipFree(p->skel); (void)hipFree(p->dev); free(p);
+            return set_err(CP_EHIP,std::string("cp_params_create: ")+hipGetErrorString(e2));
+          }
+      }
+    else { p->uerr = NULL; (void)hipGetLastError(); }
   }
   *out = p;
   return CP_OK;
@@ -110,6 +125,7 @@ extern "C" int cp_params_create_model(int K, int read_len, int hcov, int dcov, c
 extern "C" void cp_params_destroy(cp_params *p)
 { if (!p) return;
   if (p->skel) (void)hipFree(p->skel);
+  if (p->uerr) (void)hipFree(p->uerr);
   if (p->dev) (void)hipFree(p->dev);
   free(p);
 }
@@ -140,7 +156,7 @@ struct dbuf { void *p; size_t cap; };
 
 struct cp_workspace
   { dbuf bitmap, ncand, nintvl, nrel, ioff, eoff, hoff, wall, wall_s, hkeys, hvals, eintvl, ointvl, intvl, rintvl,
-         relmap, parent, eff, rpos, asgn, ord, err, memo_val, memo_key, perm, wlist, err2, tres, fwc, dtot,
+         relmap, parent, eff, rpos, asgn, ord, err, perm, wlist, err2, tres, fwc, dtot,
          s_cap, s_rcap, s_dummy, s_key, s_seg, s_aux, s_mi, s_rep, s_repcnt;
     int64_t *h_totals;        // pinned: [totalI, totalE, totalH]
     int32_t *h_err;           // pinned
@@ -191,7 +207,7 @@ extern "C" void cp_workspace_destroy(cp_workspace *ws)
 { if (!ws) return;
   dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
                   &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
-                  &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist,&ws->err2,&ws->tres,&ws->fwc,&ws->dtot,
+                  &ws->asgn,&ws->ord,&ws->err,&ws->perm,&ws->wlist,&ws->err2,&ws->tres,&ws->fwc,&ws->dtot,
                   &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_rep,&ws->s_repcnt };
   for (dbuf *b : all) if (b->p) (void)hipFree(b->p);
   if (ws->aux) (void)hipStreamDestroy(ws->aux);
@@ -206,7 +222,7 @@ extern "C" size_t cp_workspace_bytes(const cp_workspace *ws)
 { if (!ws) return 0;
   const dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
                         &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
-                        &ws->asgn,&ws->ord,&ws->err,&ws->memo_val,&ws->memo_key,&ws->perm,&ws->wlist,&ws->err2,&ws->tres,&ws->fwc,&ws->dtot,
+                        &ws->asgn,&ws->ord,&ws->err,&ws->perm,&ws->wlist,&ws->err2,&ws->tres,&ws->fwc,&ws->dtot,
                   &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_rep,&ws->s_repcnt };
   size_t s = 0;
   for (const dbuf *b : all) s += b->cap;
@@ -372,8 +388,6 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   ENSURE(ws->ord,(size_t)totalI*4);
   // size classes (kernels.hip: UNREL_SMALL_*): N <= 256 and up to 1024, two reads per wave each (four speculative update
   // slots per read), larger: the sequential kernel; the rare classes on the auxiliary stream again
-  ENSURE(ws->memo_val,(size_t)totalI*8*8);
-  ENSURE(ws->memo_key,(size_t)totalI*8*4);
   hipLaunchKernelGGL(k_order_by_work,dim3(1),dim3(1024),0,st,(const int32_t *)ws->nintvl.p,nreads,0,(int32_t *)ws->perm.p);
   HIPCHK(hipEventRecord(ws->ev_fork,st));
   HIPCHK(hipStreamWaitEvent(ws->aux,ws->ev_fork,0));
@@ -382,11 +396,11 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
                      (int32_t *)ws->ord.p);
   hipLaunchKernelGGL((k_classify_unrel_grp<UNREL_SMALL_MAXN,1024,2>),dim3((nreads+1)/2 < 2048 ? (nreads+1)/2 : 2048),dim3(WAVE),0,ws->aux,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
-                     (double *)ws->memo_val.p,(int32_t *)ws->memo_key.p,(const int32_t *)ws->perm.p);
+                     (const int32_t *)ws->perm.p);
   HIPCHK(hipEventRecord(ws->ev_join,ws->aux));
   hipLaunchKernelGGL((k_classify_unrel_grp<0,UNREL_SMALL_MAXN,UNREL_SMALL_G>),dim3((nreads+UNREL_SMALL_G-1)/UNREL_SMALL_G),dim3(WAVE),0,st,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
-                     (double *)ws->memo_val.p,(int32_t *)ws->memo_key.p,(const int32_t *)ws->perm.p);
+                     (const int32_t *)ws->perm.p);
   HIPCHK(hipStreamWaitEvent(st,ws->ev_join,0));
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_CLASS_ALL)

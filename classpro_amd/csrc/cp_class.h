@@ -565,7 +565,7 @@ CP_HD double cp_logp_hd_u(const cp_dev_params *P, int s, int idx, const cp_intvl
       sf = cp_logp_trans(P,intvl[l_rel].e-1,I.b,intvl[l_rel].cce,I.cb,intvl[l_rel].cce);
     int est = cp_est_cov(P,I.b,idx,intvl,N,s,l_rel,r_rel);
     if (est >= I.cb)
-      sf_er = log(cp_p_errorin(P->logfact,CP_OTHERS,0.1,P->u_lpe,P->u_l1mpe,est,I.cb));
+      sf_er = cp_logp_uerr(P,est,I.cb);
     double m = (er > sf) ? er : sf;
     logp_l = (m > sf_er) ? m : sf_er;
   }
@@ -576,7 +576,7 @@ CP_HD double cp_logp_hd_u(const cp_dev_params *P, int s, int idx, const cp_intvl
       sf = cp_logp_trans(P,I.e-1,intvl[r_rel].b,I.ce,intvl[r_rel].ccb,intvl[r_rel].ccb);
     int est = cp_est_cov(P,I.e-1,idx,intvl,N,s,l_rel,r_rel);
     if (est >= I.ce)
-      sf_er = log(cp_p_errorin(P->logfact,CP_OTHERS,0.1,P->u_lpe,P->u_l1mpe,est,I.ce));
+      sf_er = cp_logp_uerr(P,est,I.ce);
     double m = (er > sf) ? er : sf;
     logp_r = (m > sf_er) ? m : sf_er;
   }

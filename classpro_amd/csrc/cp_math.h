@@ -210,6 +210,24 @@ CP_HD double cp_logp_trans(const cp_dev_params *P, int b, int e, int cb, int ce,
   return cp_logp_trans_calc(P,ce-cb,(double)cov*d);
 }
 
+// ---- class_unrel.c:137-147: log P(count c | estimated count est, max_erate 0.1), est >= c ------
+#if defined(__HIPCC__)
+__host__ __device__ __attribute__((noinline))
+#else
+static inline
+#endif
+double cp_logp_uerr_calc(const cp_dev_params *P, int est, int c)
+{ return log(cp_p_errorin(P->logfact,CP_OTHERS,0.1,P->u_lpe,P->u_l1mpe,est,c)); }
+
+CP_HD double cp_logp_uerr(const cp_dev_params *P, int est, int c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (P->uerr && est <= P->uerr_max && c >= 0 && c <= est)
+    return P->uerr[(long long)est*(P->uerr_max+1)+c];
+#endif
+  return cp_logp_uerr_calc(P,est,c);
+}
+
 // ---- util.c:24-33 (positions are strictly ordered on every call path) -------------------------
 CP_HD double cp_linear_interpolation(int x, int pos1, int cnt1, int pos2, int cnt2)
 { return (double)cnt1+((double)cnt2-cnt1)*(x-pos1)/(pos2-pos1); }

@@ -64,6 +64,10 @@ struct cp_dev_params
     const double *skel;
     int     skel_kmax;
     long long skel_cdmax;
+    // classify_unrel's log(binom_test(count | estimated count, 0.1)) (class_unrel.c:137-147) is a function of two
+    // integers: uerr[est*(uerr_max+1)+c] for c <= est <= uerr_max, filled on the device by the same code; NULL = none
+    const double *uerr;
+    int     uerr_max;
   };
 
 // E-/O-interval, ClassPro.h:153-157

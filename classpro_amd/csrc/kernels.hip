@@ -1438,7 +1438,7 @@ template <int MINN, int MAXN, int G>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(UNREL_WAVES_PER_EU)))
 k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__restrict__ intvl_all,
                      const int64_t *__restrict__ ioff, const int32_t *__restrict__ nintvl,
-                     double *__restrict__ memo_val, int32_t *__restrict__ memo_key, const int32_t *__restrict__ perm)
+                     const int32_t *__restrict__ perm)
 { __shared__ unrel_grp_lds<MAXN,G> S;
   constexpr int L = WAVE/G;
   static_assert(L >= 8 && (L % 8) == 0, "8 role lanes per read");
@@ -1454,9 +1454,6 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
   cp_intvl *intvl = intvl_all+io;
   if (N <= MINN || N > MAXN || intvl[N-1].e > GRP_MAX_PLEN) N = 0;   // other size classes / sequential kernel
   if (__ballot(N > 0) == 0) continue;
-  // memo of the expensive terms between the two sweeps: 8 (key,value) pairs per interval
-  double  *mval = memo_val+io*8;
-  int32_t *mkey = memo_key+io*8;
   const int nwords = (N+63) >> 6;
   const int REP = P->cov[CP_REPEAT];
   int maxN = N;
@@ -1580,26 +1577,14 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
                   }
               }
           }
-        // The Skellam term depends only on which neighbour was found, the binomial term only on the
-        // estimated count: the second sweep reuses the first sweep's value when that key is unchanged.
+        // The Skellam term and the binomial term are table look-ups (cp_types.h: skel, uerr; the recurrence / the
+        // tail sum only outside the tables), so the second sweep simply evaluates them again: the per-interval memo
+        // in HBM that used to carry them from the first sweep cost more than that.
         double val = -INFINITY;
-        const int key = do_sf ? ((side == 0) ? tb : te) : (do_bin ? est : -1);   // tb/te identify the neighbour
-        if (pass == 1 && (do_sf || do_bin))
-          { if (mkey[idx*8+role] == key)
-              { val = mval[idx*8+role];
-                do_sf = do_bin = false;
-              }
-          }
-        const bool fresh = do_sf || do_bin;
-        // one convergent call per kind for every slot of every read of the wave
         if (do_sf)
           val = cp_logp_trans(P,tb,te,tcb,tce,tcov);
         if (do_bin)
-          val = log(cp_p_errorin(P->logfact,CP_OTHERS,0.1,P->u_lpe,P->u_l1mpe,est,c));
-        if (pass == 0 && on)
-          { mkey[idx*8+role] = fresh ? key : -1;
-            mval[idx*8+role] = val;
-          }
+          val = cp_logp_uerr(P,est,c);
         if (on)
           { if (kind == 0)
               val = (er > val) ? er : val;
@@ -1878,6 +1863,16 @@ k_skellam_table(const cp_dev_params *__restrict__ P, double *__restrict__ tab, i
     { const long long cd = i/(kmax+1);
       const int k = (int)(i-cd*(kmax+1));
       tab[i] = cp_logp_trans_calc(P,k,(double)cd);
+    }
+}
+
+// the table of classify_unrel's binomial-test logs (cp_types.h), by the function the kernels would otherwise run
+__global__ void __launch_bounds__(256)
+k_uerr_table(const cp_dev_params *__restrict__ P, double *__restrict__ tab, int emax)
+{ const long long n = (long long)(emax+1)*(emax+1);
+  for (long long i = (long long)blockIdx.x*blockDim.x+threadIdx.x; i < n; i += (long long)gridDim.x*blockDim.x)
+    { const int est = (int)(i/(emax+1)), c = (int)(i-(long long)est*(emax+1));
+      tab[i] = (c <= est) ? cp_logp_uerr_calc(P,est,c) : 0.;
     }
 }
 
