@@ -27,6 +27,7 @@ struct cp_params
     cp_dev_params *dev;
     double        *skel;                   // device table of logp_trans values (cp_types.h), or NULL
     double        *uerr;                   // device table of classify_unrel's binomial-test logs, or NULL
+    double        *petab;                  // device table of the walk's P(error in) values, or NULL
   };
 
 extern "C" int cp_hist_covs(const int64_t *hist, int low, int high, int64_t ilowcnt, int64_t ihighcnt,
@@ -117,6 +118,20 @@ extern "C" int cp_params_create_model(int K, int read_len, int hcov, int dcov, c
           }
       }
     else { p->uerr = NULL; (void)hipGetLastError(); }
+    // (the third: 2 error types x 63 error rates x counts <= 255: 66 MB)
+    p->petab = NULL;
+    const int cmax = 255;
+    if (p->skel && hipMalloc((void **)&p->petab,(size_t)2*63*(cmax+1)*(cmax+1)*8) == hipSuccess)
+      { hipLaunchKernelGGL(k_pe_table,dim3(4096),dim3(256),0,0,p->dev,p->petab,cmax);
+        p->host.petab = p->petab; p->host.pe_cmax = cmax;
+        hipError_t e3 = hipGetLastError();
+        if (e3 == hipSuccess) e3 = hipMemcpy(p->dev,&p->host,sizeof(cp_dev_params),hipMemcpyHostToDevice);
+        if (e3 != hipSuccess)
+          { (void)hipFree(p->petab); if (p->uerr) (void)hipFree(p->uerr); (void)hipFree(p->skel); (void)hipFree(p->dev); free(p);
+            return set_err(CP_EHIP,std::string("cp_params_create: ")+hipGetErrorString(e3));
+          }
+      }
+    else { p->petab = NULL; (void)hipGetLastError(); }
   }
   *out = p;
   return CP_OK;
@@ -126,6 +141,7 @@ extern "C" void cp_params_destroy(cp_params *p)
 { if (!p) return;
   if (p->skel) (void)hipFree(p->skel);
   if (p->uerr) (void)hipFree(p->uerr);
+  if (p->petab) (void)hipFree(p->petab);
   if (p->dev) (void)hipFree(p->dev);
   free(p);
 }

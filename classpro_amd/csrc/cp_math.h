@@ -210,6 +210,24 @@ CP_HD double cp_logp_trans(const cp_dev_params *P, int b, int e, int cb, int ce,
   return cp_logp_trans_calc(P,ce-cb,(double)cov*d);
 }
 
+// ---- p_errorin with one of the model's own error rates pe[t][l] (every call of the candidate walk) ----
+#if defined(__HIPCC__)
+__host__ __device__ __attribute__((noinline))
+#else
+static inline
+#endif
+double cp_p_errorin_calc(const cp_dev_params *P, int e, int t, int l, int cout, int cin)
+{ return cp_p_errorin(P->logfact,e,P->pe[t][l],P->lpe[t][l],P->l1mpe[t][l],cout,cin); }
+
+CP_HD double cp_p_errorin_tl(const cp_dev_params *P, int e, int t, int l, int cout, int cin)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (P->petab && cin >= 0 && cin <= cout && cout <= P->pe_cmax)
+    return P->petab[((long long)(e*63+t*21+l)*(P->pe_cmax+1)+cout)*(P->pe_cmax+1)+cin];
+#endif
+  return cp_p_errorin_calc(P,e,t,l,cout,cin);
+}
+
 // ---- class_unrel.c:137-147: log P(count c | estimated count est, max_erate 0.1), est >= c ------
 #if defined(__HIPCC__)
 __host__ __device__ __attribute__((noinline))

@@ -68,6 +68,10 @@ struct cp_dev_params
     // integers: uerr[est*(uerr_max+1)+c] for c <= est <= uerr_max, filled on the device by the same code; NULL = none
     const double *uerr;
     int     uerr_max;
+    // the walk's P(error in) (util.c:46-55 -> prob.c:76-112) for one of the 63 error rates pe[t][l], error type e and
+    // counts cin <= cout <= pe_cmax: petab[((e*63+t*21+l)*(pe_cmax+1)+cout)*(pe_cmax+1)+cin], same code; NULL = none
+    const double *petab;
+    int     pe_cmax;
   };
 
 // E-/O-interval, ClassPro.h:153-157

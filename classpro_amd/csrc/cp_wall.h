@@ -278,7 +278,7 @@ CP_HD void cp_wall_candidate_live(RD *R, int i, int e, const cp_wall_pre &pre, c
   out->flags = CP_CF_LIVE; out->lc_kind = CP_LC_NONE; out->lc_j = -1; out->hc_j = -1;
   out->lc_v = out->hc_pe = CP_NEG_INF;
   CP_LT0();
-  out->own_pe = cp_p_errorin(R->lf,e,pre.maxpe,pre.lpe,pre.l1mpe,cout,cin);
+  out->own_pe = cp_p_errorin_tl(P,e,t,l,cout,cin);
   CP_LT(0);
 
   // find_gain (w == DROP: partner GAIN to the right of i) / find_drop (w == GAIN: partner DROP to the
@@ -314,7 +314,7 @@ CP_HD void cp_wall_candidate_live(RD *R, int i, int e, const cp_wall_pre &pre, c
           && !(cout_j < CMAX && cp_cthres_ng(e,cin_j,P->cthres[t][l][cout_j][CP_FINAL][e]))
           && (e == CP_SELF || (right ? cp_logp_diff_pair(R,i,j) : cp_logp_diff_pair(R,j,i)) >= CP_THRES_DIFF_EO))
         { out->lc_kind = CP_LC_PAIR;
-          out->lc_v = cp_p_errorin(R->lf,e,pre.maxpe,pre.lpe,pre.l1mpe,cout_j,cin_j);
+          out->lc_v = cp_p_errorin_tl(P,e,t,l,cout_j,cin_j);
         }
       else
         out->lc_kind = CP_LC_REJECT;
@@ -339,10 +339,10 @@ CP_HD void cp_wall_candidate_live(RD *R, int i, int e, const cp_wall_pre &pre, c
       if (e == CP_OTHERS && (right ? cp_logp_diff_pair(R,i,j) : cp_logp_diff_pair(R,j,i)) < CP_THRES_DIFF_EO)
         continue;
       if (!have_pe_i)                                   // same arguments every time (wall.c:398)
-        { pe_i = cp_p_errorin(R->lf,e,P->hc_erate,P->hc_lpe,P->hc_l1mpe,cout,cin);
+        { pe_i = cp_p_errorin_tl(P,e,CP_HP,1,cout,cin);      // HC_ERATE = pe[HP][1], wall.c:180
           have_pe_i = true;
         }
-      double pe_j = cp_p_errorin(R->lf,e,P->hc_erate,P->hc_lpe,P->hc_l1mpe,cout_j,cin_j);
+      double pe_j = cp_p_errorin_tl(P,e,CP_HP,1,cout_j,cin_j);
       double pe = pe_i * pe_j;
       if (max_pe < pe)
         { max_j  = j;

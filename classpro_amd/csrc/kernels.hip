@@ -1866,6 +1866,19 @@ k_skellam_table(const cp_dev_params *__restrict__ P, double *__restrict__ tab, i
     }
 }
 
+// the table of the walk's P(error in) values (cp_types.h), by the function the kernels would otherwise run
+__global__ void __launch_bounds__(256)
+k_pe_table(const cp_dev_params *__restrict__ P, double *__restrict__ tab, int cmax)
+{ const long long per = (long long)(cmax+1)*(cmax+1), n = 2*63*per;
+  for (long long i = (long long)blockIdx.x*blockDim.x+threadIdx.x; i < n; i += (long long)gridDim.x*blockDim.x)
+    { const int et = (int)(i/per);
+      const long long q = i-(long long)et*per;
+      const int cout = (int)(q/(cmax+1)), cin = (int)(q-(long long)cout*(cmax+1));
+      const int e = et/63, tl = et%63;
+      tab[i] = (cin <= cout) ? cp_p_errorin_calc(P,e,tl/21,tl%21,cout,cin) : 0.;
+    }
+}
+
 // the table of classify_unrel's binomial-test logs (cp_types.h), by the function the kernels would otherwise run
 __global__ void __launch_bounds__(256)
 k_uerr_table(const cp_dev_params *__restrict__ P, double *__restrict__ tab, int emax)
