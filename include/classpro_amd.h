@@ -72,8 +72,9 @@ int cp_hist_covs(const int64_t *hist, int low, int high, int64_t ilowcnt, int64_
  * (src/ClassPro.c:544-548) and calc_init_thres(NULL) (src/wall.c:167-244): builds the read-only
  * tables on the host and uploads them to the current HIP device.  It also has the device fill a table of
  * logp_trans values (util.c:35-44: a function of |ce-cb| and the integer cov*|e-b| alone; 1 GB of device memory by
- * default, environment CLASSPRO_SKELLAM_TABLE_MB, 0 = none) with the code the kernels otherwise run on the spot, so
- * results are the same bits with or without it; when the memory is not there the library goes on without the table.
+ * default, environment CLASSPRO_SKELLAM_TABLE_MB, 0 = none) and two small ones (classify_unrel's binomial-test logs,
+ * the walk's P(error in): 74 MB) with the code the kernels otherwise run on the spot, so results are the same bits
+ * with or without them; when the memory is not there the library goes on without the tables.
  * CP_ERCOV when the repeat threshold exceeds 255 (wall.c:174-177). */
 typedef struct cp_params cp_params;
 int  cp_params_create(int K, int read_len, int hcov, int dcov, cp_params **out);
