@@ -478,6 +478,36 @@ __device__ unsigned long long g_live_prof[8];
 // [2] the count pair, and [3] the task list; `tres` the task results; `fwc` per read n_c, n_t, SELF tasks, overflow.
 struct task_res { double own_pe, lc_v, hc_pe; int lc_j, hc;  };   // hc: lc_kind | (hc_j >= 0) << 2 | (hc_j - i) << 16
 
+// The sequence-context scans of the walk (cp_ctx.h: runs of equal bases / of period 2 and 3 around a position) are
+// chains of dependent byte loads.  A lane copies the 96 bases around its candidate into its row of an LDS block once
+// (six independent 16-byte loads) and the scans read the row; a position outside the row is read from HBM as before.
+#define FW_SEQ_WIN    96
+#define FW_SEQ_STRIDE 100            // bytes per lane: 25 dwords, an odd number of banks apart
+struct cp_seq_lwin
+  { const char *g; CP_LDS_PTR(const char) w; int lo, len;
+    __device__ __forceinline__ char operator[](int p) const
+    { const unsigned d = (unsigned)(p-lo); return d < (unsigned)len ? w[d] : g[p]; }
+  };
+struct __attribute__((packed, aligned(1))) cp_u8x16 { uint32_t v[4]; };
+__device__ __forceinline__ void fw_seq_win_load(cp_seq_lwin &sq, char *row, int i, int rlen)
+{ int lo = i-32;
+  if (lo > rlen-FW_SEQ_WIN) lo = rlen-FW_SEQ_WIN;
+  if (lo < 0) lo = 0;
+  const int len = rlen-lo < FW_SEQ_WIN ? rlen-lo : FW_SEQ_WIN;
+  uint32_t *rw = reinterpret_cast<uint32_t *>(row);
+  if (len == FW_SEQ_WIN)
+    {
+#pragma unroll
+      for (int k = 0; k < FW_SEQ_WIN/16; k++)
+        { const cp_u8x16 x = *reinterpret_cast<const cp_u8x16 *>(sq.g+lo+16*k);
+          rw[4*k] = x.v[0]; rw[4*k+1] = x.v[1]; rw[4*k+2] = x.v[2]; rw[4*k+3] = x.v[3];
+        }
+    }
+  else
+    for (int k = 0; k < len; k++) row[k] = sq.g[lo+k];
+  sq.lo = lo; sq.len = len;
+}
+
 #ifndef FW_WAVES_PER_EU
 #define FW_WAVES_PER_EU 5
 #endif
@@ -493,8 +523,10 @@ k_wall_tasks(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, 
   const int64_t po = prof_off[r];
   const int plen = (int)(prof_off[r+1]-po);
   const int rlen = (int)(seq_off[r+1]-seq_off[r]);
-  cp_read_t<cp_perr_hybrid> R;
-  R.P = P; R.prof = prof+po; R.seq = seq+seq_off[r]; R.lf = P->logfact; R.plen = plen; R.rlen = rlen;
+  __shared__ __attribute__((aligned(4))) char s_win[WAVE*FW_SEQ_STRIDE];
+  cp_read_t<cp_perr_hybrid,cp_seq_lwin> R;
+  R.P = P; R.prof = prof+po; R.lf = P->logfact; R.plen = plen; R.rlen = rlen;
+  R.seq.g = seq+seq_off[r]; R.seq.w = (CP_LDS_PTR(const char))(s_win+lane*FW_SEQ_STRIDE); R.seq.lo = 0; R.seq.len = 0;
   R.wall = wall_all+po+r; R.wall_s = R.wall;
   R.eintvl = R.ointvl = nullptr; R.ecap = 0; R.eidx = R.oidx = 0; R.overflow = 0;
   const int icap = (int)(ioff[r+1]-ioff[r]);
@@ -533,6 +565,7 @@ k_wall_tasks(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, 
     { int f0 = 0, f1 = 0;
       if (base+lane < n_c)
         { const int i = clist[base+lane];
+          fw_seq_win_load(R.seq,s_win+lane*FW_SEQ_STRIDE,i,rlen);
           cp_wall_pre pre;
           cp_wall_candidate_pre(&R,i,&pre);
           f0 = cp_wall_candidate_filter(P,CP_SELF,pre);
@@ -560,6 +593,7 @@ k_wall_tasks(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, 
       if (lane < nb)
         { const int code = tlist[tb+lane], k = code >> 1, e = code & 1;
           const int i = clist[k], tl = cinfo[k] & 255, cc = ccnt[k];
+          fw_seq_win_load(R.seq,s_win+lane*FW_SEQ_STRIDE,i,rlen);
           cp_wall_pre pre;
           const int cim1 = cc & 0xffff, ci = (cc >> 16) & 0xffff;
           pre.cng = cim1 > ci ? cim1-ci : ci-cim1;
