@@ -688,7 +688,10 @@ CP_HD int cp_sum_steps(const uint16_t *prof, int lo, int hi, int plen, int sgn)
 // correct_wall_cnt + the filters of find_rel_intvl, wall.c:960-1051, for interval `idx`.
 // The reference's position-indexed loops at wall.c:999-1006 only ever touch the interval itself when
 // its index equals its start position (SURVEY.md hazard 2); that case is applied explicitly.
-CP_HD bool cp_rel_interval(const cp_dev_params *P, const uint16_t *prof, const char *seq, int rlen,
+// seq_b / seq_e: the read's bases as seen by the context scan after the interval's begin / before its end (the same
+// pointer on the host; on the device two short LDS windows backed by the pointer, kernels.hip).
+template <class SEQB, class SEQE>
+CP_HD bool cp_rel_interval(const cp_dev_params *P, const uint16_t *prof, const SEQB &seq_b, const SEQE &seq_e, int rlen,
                            cp_intvl *I, int idx)
 { const int K = P->K;
   if (I->e-I->b < K)
@@ -705,7 +708,7 @@ CP_HD bool cp_rel_interval(const cp_dev_params *P, const uint16_t *prof, const c
   if (I->b+K-1 < I->e)
     { lmax = 0;
       for (int t = 0; t < 3; t++)
-        { int l = cp_rctx(seq,rlen,I->b+K-1,t)*(t+1);
+        { int l = cp_rctx(seq_b,rlen,I->b+K-1,t)*(t+1);
           if (lmax < l) lmax = l;
         }
       last = I->b+lmax;
@@ -716,7 +719,7 @@ CP_HD bool cp_rel_interval(const cp_dev_params *P, const uint16_t *prof, const c
   if (I->b < I->e-K+1)
     { lmax = 0;
       for (int t = 0; t < 3; t++)
-        { int l = cp_lctx(seq,rlen,(I->e-K+1)+K-2,t)*(t+1);   // ctx[DROP][e-K+1]
+        { int l = cp_lctx(seq_e,rlen,(I->e-K+1)+K-2,t)*(t+1); // ctx[DROP][e-K+1]
           if (lmax < l) lmax = l;
         }
       first = I->e-lmax;

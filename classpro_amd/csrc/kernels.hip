@@ -508,6 +508,25 @@ __device__ __forceinline__ void fw_seq_win_load(cp_seq_lwin &sq, char *row, int 
   sq.lo = lo; sq.len = len;
 }
 
+#define FR_STRIDE 68                 // k_find_rel: two 32-base windows per lane, 17 dwords apart
+__device__ __forceinline__ void fr_seq_win_load(cp_seq_lwin &sq, char *row, int lo, int rlen)
+{ if (lo > rlen-32) lo = rlen-32;
+  if (lo < 0) lo = 0;
+  const int len = rlen-lo < 32 ? rlen-lo : 32;
+  uint32_t *rw = reinterpret_cast<uint32_t *>(row);
+  if (len == 32)
+    {
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+        { const cp_u8x16 x = *reinterpret_cast<const cp_u8x16 *>(sq.g+lo+16*k);
+          rw[4*k] = x.v[0]; rw[4*k+1] = x.v[1]; rw[4*k+2] = x.v[2]; rw[4*k+3] = x.v[3];
+        }
+    }
+  else
+    for (int k = 0; k < len; k++) row[k] = sq.g[lo+k];
+  sq.lo = lo; sq.len = len;
+}
+
 #ifndef FW_WAVES_PER_EU
 #define FW_WAVES_PER_EU 5
 #endif
@@ -914,6 +933,7 @@ k_find_rel(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, co
   const char *sq = seq+seq_off[r];
   cp_intvl *intvl = intvl_all+ioff[r], *rintvl = rintvl_all+ioff[r];
   int32_t *relmap = relmap_all+ioff[r];
+  __shared__ __attribute__((aligned(4))) char s_ctx[WAVE*FR_STRIDE];
   int M = 0;
   for (int base = 0; base < N; base += WAVE)
     { int idx = base+lane;
@@ -921,7 +941,16 @@ k_find_rel(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, co
       cp_intvl I;
       if (idx < N)
         { I = intvl[idx];
-          ok = cp_rel_interval(P,pr,sq,rlen,&I,idx);
+          // the two context scans of correct_wall_cnt read forward from b+K-1 and backward from e-1: 32 bases each in LDS
+          cp_seq_lwin sb, se;
+          sb.g = se.g = sq;
+          sb.w = (CP_LDS_PTR(const char))(s_ctx+lane*FR_STRIDE); se.w = (CP_LDS_PTR(const char))(s_ctx+lane*FR_STRIDE+32);
+          sb.lo = se.lo = 0; sb.len = se.len = 0;
+          if (I.e-I.b >= P->K)
+            { fr_seq_win_load(sb,s_ctx+lane*FR_STRIDE,I.b+P->K-1,rlen);
+              fr_seq_win_load(se,s_ctx+lane*FR_STRIDE+32,I.e-1-31,rlen);
+            }
+          ok = cp_rel_interval(P,pr,sb,se,rlen,&I,idx);
           I.is_rel = ok ? 1 : 0;
           intvl[idx] = I;
         }

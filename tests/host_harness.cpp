@@ -93,7 +93,7 @@ int hh_classify_read(void *Pv, const char *seq, int rlen, const uint16_t *prof, 
   int M = 0;
   std::vector<int> relmap;
   for (int idx = 0; idx < N; idx++)
-    if (cp_rel_interval(P,prof,seq,rlen,&intvl[idx],idx))
+    if (cp_rel_interval(P,prof,seq,seq,rlen,&intvl[idx],idx))
       { intvl[idx].is_rel = 1; rintvl[M++] = intvl[idx]; relmap.push_back(idx); }
   *M_out = M;
   if (M > 0)
