@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--genome", type=float, default=200e6, help="synthetic diploid genome length (configs[2]: 200 Mbp)")
     ap.add_argument("--cov", type=int, default=40)
     ap.add_argument("--read-len", type=int, default=20000)
-    ap.add_argument("--batch-mbases", type=float, default=800.0, help="sub-batch size of one cp_classify_batch call")
+    ap.add_argument("--batch-mbases", type=float, default=1200.0, help="sub-batch size of one cp_classify_batch call")
     ap.add_argument("--streams", type=int, default=2, help="sub-batches alternate over this many streams / workspaces")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--seed", type=int, default=1)
