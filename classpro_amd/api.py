@@ -135,6 +135,12 @@ class Classifier:
         return dict(cov=list(cov), dr_ratio=dr.value, cmax=cmax.value, hc_erate=hc.value,
                     cthres=cth, pe=pe, logfact=lf)
 
+    def tables(self):
+        """Device bytes of the look-up tables in use (0 = computed on the spot): dict(skel, uerr, petab)."""
+        v = [C.c_size_t() for _ in range(3)]
+        check(self.L.cp_params_tables(self.p, *[C.byref(x) for x in v]))
+        return dict(skel=v[0].value, uerr=v[1].value, petab=v[2].value)
+
     # ---- pipeline ----
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

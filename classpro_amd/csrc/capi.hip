@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <mutex>
+#include <vector>
 #include "cp_host_setup.h"
 #include "kernels.hip"
 
@@ -25,10 +27,58 @@ extern "C" const char *cp_version(void) { return "classpro_amd 0.1 (gfx950)"; }
 struct cp_params
   { cp_dev_params  host;
     cp_dev_params *dev;
+    int            device;                 // HIP device the tables live on
     double        *skel;                   // device table of logp_trans values (cp_types.h), or NULL
     double        *uerr;                   // device table of classify_unrel's binomial-test logs, or NULL
     double        *petab;                  // device table of the walk's P(error in) values, or NULL
+    size_t         skel_bytes, uerr_bytes, petab_bytes;
   };
+
+// ---------------------------------------------------------------------------------------------
+//  The three read-only tables are pure functions of a few setup values (logp_trans: READ_LEN; the unrel binomial
+//  term: nothing; P(error in): the error model), so every cp_params of a process that agrees on those shares ONE copy
+//  per device (the command line creates one cp_params per device shard, CLASSPRO_DEVICES=0,0,0,0 four on one card:
+//  1 GB instead of 4).  Reference-counted; filled on a private non-blocking stream, so that creating a cp_params does
+//  not wait for -- or stall -- kernels other threads have in flight on the device's blocking streams.
+// ---------------------------------------------------------------------------------------------
+struct cp_tab_entry { int dev; std::string key; double *p; size_t bytes; int refs; };
+static std::mutex g_tab_mu;
+static std::vector<cp_tab_entry> g_tabs;
+
+template <class Fill>
+static double *tab_acquire(int dev, const std::string &key, size_t bytes, Fill fill)
+{ std::lock_guard<std::mutex> lk(g_tab_mu);
+  for (cp_tab_entry &t : g_tabs)
+    if (t.dev == dev && t.key == key && t.bytes == bytes) { t.refs++; return t.p; }
+  double *p = NULL;
+  if (hipMalloc((void **)&p,bytes) != hipSuccess) { (void)hipGetLastError(); return NULL; }   // no room: computed on the spot
+  hipStream_t st = NULL;
+  hipError_t e = hipStreamCreateWithFlags(&st,hipStreamNonBlocking);
+  if (e == hipSuccess)
+    { (void)hipGetLastError();                    // (when this is the process's first HIP work, the runtime's own start-up
+                                                  //  probing can leave an error code behind: it is not this launch's)
+      fill(p,st);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      (void)hipStreamDestroy(st);
+    }
+  if (e != hipSuccess) { (void)hipFree(p); (void)hipGetLastError(); return NULL; }
+  g_tabs.push_back(cp_tab_entry{dev,key,p,bytes,1});
+  return p;
+}
+
+static void tab_release(double *p)
+{ if (!p) return;
+  std::lock_guard<std::mutex> lk(g_tab_mu);
+  for (size_t i = 0; i < g_tabs.size(); i++)
+    if (g_tabs[i].p == p)
+      { if (--g_tabs[i].refs == 0)
+          { (void)hipFree(p);
+            g_tabs.erase(g_tabs.begin()+(long)i);
+          }
+        return;
+      }
+}
 
 extern "C" int cp_hist_covs(const int64_t *hist, int low, int high, int64_t ilowcnt, int64_t ihighcnt,
                             int coverage_opt, int *hcov, int *dcov)
@@ -75,75 +125,78 @@ extern "C" int cp_params_create_model(int K, int read_len, int hcov, int dcov, c
       free(p);
       return set_err(rc,buf);
     }
-  p->dev = NULL;
-  hipError_t e = hipMalloc((void **)&p->dev,sizeof(cp_dev_params));
-  if (e == hipSuccess)
-    e = hipMemcpy(p->dev,&p->host,sizeof(cp_dev_params),hipMemcpyHostToDevice);
+  p->dev = NULL; p->skel = p->uerr = p->petab = NULL; p->skel_bytes = p->uerr_bytes = p->petab_bytes = 0;
+  p->device = 0;
+  hipStream_t st = NULL;
+  hipError_t e = hipGetDevice(&p->device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&st,hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc((void **)&p->dev,sizeof(cp_dev_params));
+  if (e == hipSuccess) e = hipMemcpyAsync(p->dev,&p->host,sizeof(cp_dev_params),hipMemcpyHostToDevice,st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess)
     { if (p->dev) (void)hipFree(p->dev);
+      if (st) (void)hipStreamDestroy(st);
       free(p);
       return set_err(CP_EHIP,std::string("cp_params_create: ")+hipGetErrorString(e));
     }
-  // the table of logp_trans values: |ce-cb| <= 255 covers every pair of counts of reliable intervals (both below the
-  // REPEAT coverage <= 255); cov*|e-b| up to CLASSPRO_SKELLAM_TABLE_MB (default 1024 MB = 2^19 products; 0 = no table)
-  p->skel = NULL;
-  { long mb = 1024;
-    if (const char *e = getenv("CLASSPRO_SKELLAM_TABLE_MB")) mb = atol(e);
-    const int kmax = 255;
-    const long long cdmax = (long long)mb*1024*1024/8/(kmax+1)-1;
-    if (cdmax >= 0 && hipMalloc((void **)&p->skel,(size_t)(cdmax+1)*(kmax+1)*8) == hipSuccess)
-      { (void)hipGetLastError();              // (when this is the process's first HIP work, the runtime's own start-up
-                                              //  probing can leave an error code behind: it is not this launch's)
-        hipLaunchKernelGGL(k_skellam_table,dim3(4096),dim3(256),0,0,p->dev,p->skel,kmax,cdmax);
-        p->host.skel = p->skel; p->host.skel_kmax = kmax; p->host.skel_cdmax = cdmax;
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpy(p->dev,&p->host,sizeof(cp_dev_params),hipMemcpyHostToDevice);   // (after the kernel, same stream)
-        if (e != hipSuccess)
-          { (void)hipFree(p->skel); (void)hipFree(p->dev); free(p);
-            return set_err(CP_EHIP,std::string("cp_params_create: ")+hipGetErrorString(e));
-          }
+  // The tables (cp_types.h).  CLASSPRO_TABLES=0: none of them; CLASSPRO_SKELLAM_TABLE_MB=<n>: size of the logp_trans
+  // table (default 1024 MB = 2^19 products cov*|e-b|; 0 = no such table, the two small ones stay).  A table that
+  // finds no memory is left out -- every value is then computed on the spot, same bits -- and cp_params_tables() says so.
+  bool tables = true;
+  if (const char *t = getenv("CLASSPRO_TABLES")) tables = atol(t) != 0;
+  if (tables)
+    { const cp_dev_params *dP = p->dev;
+      // |ce-cb| <= 255 covers every pair of counts of reliable intervals (both below the REPEAT coverage <= 255)
+      long mb = 1024;
+      if (const char *m = getenv("CLASSPRO_SKELLAM_TABLE_MB")) mb = atol(m);
+      const int kmax = 255;
+      const long long cdmax = (long long)mb*1024*1024/8/(kmax+1)-1;
+      if (cdmax >= 0)
+        { const size_t bytes = (size_t)(cdmax+1)*(kmax+1)*8;
+          p->skel = tab_acquire(p->device,"skel r"+std::to_string(read_len),bytes,[&](double *t, hipStream_t s)
+            { hipLaunchKernelGGL(k_skellam_table,dim3(4096),dim3(256),0,s,dP,t,kmax,cdmax); });
+          if (p->skel) { p->host.skel = p->skel; p->host.skel_kmax = kmax; p->host.skel_cdmax = cdmax; p->skel_bytes = bytes; }
+        }
+      const int emax = 1023;                                   // 1024 x 1024 doubles
+      { const size_t bytes = (size_t)(emax+1)*(emax+1)*8;
+        p->uerr = tab_acquire(p->device,"uerr",bytes,[&](double *t, hipStream_t s)
+          { hipLaunchKernelGGL(k_uerr_table,dim3(1024),dim3(256),0,s,dP,t,emax); });
+        if (p->uerr) { p->host.uerr = p->uerr; p->host.uerr_max = emax; p->uerr_bytes = bytes; }
       }
-    else { p->skel = NULL; (void)hipGetLastError(); }       // no room for the table: every value is computed on the spot
-    // (the second table is small: 1024 x 1024 doubles; it goes with the first one)
-    p->uerr = NULL;
-    const int emax = 1023;
-    if (p->skel && hipMalloc((void **)&p->uerr,(size_t)(emax+1)*(emax+1)*8) == hipSuccess)
-      { hipLaunchKernelGGL(k_uerr_table,dim3(1024),dim3(256),0,0,p->dev,p->uerr,emax);
-        p->host.uerr = p->uerr; p->host.uerr_max = emax;
-        hipError_t e2 = hipGetLastError();
-        if (e2 == hipSuccess) e2 = hipMemcpy(p->dev,&p->host,sizeof(cp_dev_params),hipMemcpyHostToDevice);
-        if (e2 != hipSuccess)
-          { (void)hipFree(p->uerr); (void)hipFree(p->skel); (void)hipFree(p->dev); free(p);
-            return set_err(CP_EHIP,std::string("cp_params_create: ")+hipGetErrorString(e2));
-          }
+      const int cmax = 255;                                    // 2 error types x 63 error rates x counts <= 255: 66 MB
+      { const size_t bytes = (size_t)2*63*(cmax+1)*(cmax+1)*8;
+        std::string key("petab ");
+        key.append((const char *)p->host.pe,sizeof(p->host.pe));      // the error model decides the values
+        p->petab = tab_acquire(p->device,key,bytes,[&](double *t, hipStream_t s)
+          { hipLaunchKernelGGL(k_pe_table,dim3(4096),dim3(256),0,s,dP,t,cmax); });
+        if (p->petab) { p->host.petab = p->petab; p->host.pe_cmax = cmax; p->petab_bytes = bytes; }
       }
-    else { p->uerr = NULL; (void)hipGetLastError(); }
-    // (the third: 2 error types x 63 error rates x counts <= 255: 66 MB)
-    p->petab = NULL;
-    const int cmax = 255;
-    if (p->skel && hipMalloc((void **)&p->petab,(size_t)2*63*(cmax+1)*(cmax+1)*8) == hipSuccess)
-      { hipLaunchKernelGGL(k_pe_table,dim3(4096),dim3(256),0,0,p->dev,p->petab,cmax);
-        p->host.petab = p->petab; p->host.pe_cmax = cmax;
-        hipError_t e3 = hipGetLastError();
-        if (e3 == hipSuccess) e3 = hipMemcpy(p->dev,&p->host,sizeof(cp_dev_params),hipMemcpyHostToDevice);
-        if (e3 != hipSuccess)
-          { (void)hipFree(p->petab); if (p->uerr) (void)hipFree(p->uerr); (void)hipFree(p->skel); (void)hipFree(p->dev); free(p);
-            return set_err(CP_EHIP,std::string("cp_params_create: ")+hipGetErrorString(e3));
-          }
-      }
-    else { p->petab = NULL; (void)hipGetLastError(); }
-  }
+      e = hipMemcpyAsync(p->dev,&p->host,sizeof(cp_dev_params),hipMemcpyHostToDevice,st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e != hipSuccess)
+        { tab_release(p->skel); tab_release(p->uerr); tab_release(p->petab);
+          (void)hipFree(p->dev); (void)hipStreamDestroy(st); free(p);
+          return set_err(CP_EHIP,std::string("cp_params_create: ")+hipGetErrorString(e));
+        }
+    }
+  (void)hipStreamDestroy(st);
   *out = p;
   return CP_OK;
 }
 
 extern "C" void cp_params_destroy(cp_params *p)
 { if (!p) return;
-  if (p->skel) (void)hipFree(p->skel);
-  if (p->uerr) (void)hipFree(p->uerr);
-  if (p->petab) (void)hipFree(p->petab);
+  tab_release(p->skel); tab_release(p->uerr); tab_release(p->petab);
   if (p->dev) (void)hipFree(p->dev);
   free(p);
+}
+
+extern "C" int cp_params_tables(const cp_params *p, size_t *skel_bytes, size_t *uerr_bytes, size_t *petab_bytes)
+{ if (!p) return set_err(CP_EINVAL,"cp_params_tables: null params");
+  if (skel_bytes) *skel_bytes = p->skel_bytes;
+  if (uerr_bytes) *uerr_bytes = p->uerr_bytes;
+  if (petab_bytes) *petab_bytes = p->petab_bytes;
+  return CP_OK;
 }
 
 extern "C" int cp_params_export(const cp_params *p, int *cov4, double *dr_ratio, int *cmax, double *hc_erate,
@@ -182,37 +235,59 @@ struct cp_workspace
     int      last_stage;
     int      decode_pending;  // a cp_decode_profiles result has not been checked yet
     int      seed_nreads; int64_t seed_totalR;   // shape of the last cp_find_seeds_batch
+    std::vector<void *> *retired;   // buffers that were outgrown while a stream could still be using them (ensure())
     hipStream_t stream;
     hipStream_t aux;          // size classes of one stage run side by side: the rare long reads are latency-bound
     hipEvent_t  ev_fork, ev_join;
   };
 
-static int ensure(dbuf &b, size_t need)
+// Grow-only.  A buffer that is outgrown may still be read by kernels of the previous call on the workspace's stream (the
+// entry points are asynchronous), and hipFree synchronises the whole device: the old buffer is parked on the
+// workspace's retired list and freed where the stream is waited for anyway (cp_workspace_check, cp_workspace_destroy).
+// A quarter of head-room, so that a sequence of sub-batches of about one size allocates once.
+static int ensure(cp_workspace *ws, dbuf &b, size_t need)
 { if (need <= b.cap) return CP_OK;
-  if (b.p) { (void)hipFree(b.p); b.p = NULL; b.cap = 0; }
-  size_t want = need+need/8+256;
-  hipError_t e = hipMalloc(&b.p,want);
+  size_t want = need+need/4+256;
+  void *np = NULL;
+  hipError_t e = hipMalloc(&np,want);
+  if (e != hipSuccess && ws->retired && !ws->retired->empty())
+    { (void)hipGetLastError();                     // out of memory with parked buffers: give them back and try again
+      if (ws->stream) (void)hipStreamSynchronize(ws->stream);
+      for (void *q : *ws->retired) (void)hipFree(q);
+      ws->retired->clear();
+      e = hipMalloc(&np,want);
+    }
   if (e != hipSuccess)
     { char m[160];
       snprintf(m,sizeof(m),"hipMalloc(%zu bytes): %s",want,hipGetErrorString(e));
+      (void)hipGetLastError();
       return set_err(CP_ENOMEM,m);
     }
-  b.cap = want;
+  if (b.p) ws->retired->push_back(b.p);
+  b.p = np; b.cap = want;
   return CP_OK;
 }
-#define ENSURE(b,n) do { int rc_ = ensure(b,(size_t)(n)); if (rc_ != CP_OK) return rc_; } while (0)
+#define ENSURE(b,n) do { int rc_ = ensure(ws,b,(size_t)(n)); if (rc_ != CP_OK) return rc_; } while (0)
 
 extern "C" int cp_workspace_create(cp_workspace **out)
 { if (!out) return set_err(CP_EINVAL,"cp_workspace_create: null out");
   cp_workspace *ws = (cp_workspace *)calloc(1,sizeof(cp_workspace));
   if (!ws) return set_err(CP_ENOMEM,"cp_workspace_create: out of memory");
+  ws->retired = new std::vector<void *>();
   hipError_t e = hipHostMalloc((void **)&ws->h_totals,4*sizeof(int64_t),hipHostMallocDefault);
-  if (e == hipSuccess) e = hipHostMalloc((void **)&ws->h_err,sizeof(int32_t),hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&ws->h_err,4*sizeof(int32_t),hipHostMallocDefault);
+  // the error words (device): [0] find_wall / classification, [1] find_seeds, [2] profile decode.  Sticky: kernels OR
+  // into them, only cp_workspace_check reads and clears them, so a flag raised by any call since the last check is seen
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ws->aux,hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&ws->err.p,16);
+  if (e == hipSuccess) { ws->err.cap = 16; e = hipMemsetAsync(ws->err.p,0,16,ws->aux); }
+  if (e == hipSuccess) e = hipStreamSynchronize(ws->aux);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ws->ev_fork,hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ws->ev_join,hipEventDisableTiming);
   if (e != hipSuccess)
-    { free(ws);
+    { if (ws->err.p) (void)hipFree(ws->err.p);
+      delete ws->retired;
+      free(ws);
       return set_err(CP_EHIP,std::string("cp_workspace_create: ")+hipGetErrorString(e));
     }
   *out = ws;
@@ -226,6 +301,8 @@ extern "C" void cp_workspace_destroy(cp_workspace *ws)
                   &ws->asgn,&ws->ord,&ws->err,&ws->perm,&ws->wlist,&ws->err2,&ws->tres,&ws->fwc,&ws->dtot,
                   &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_rep,&ws->s_repcnt };
   for (dbuf *b : all) if (b->p) (void)hipFree(b->p);
+  for (void *q : *ws->retired) (void)hipFree(q);
+  delete ws->retired;
   if (ws->aux) (void)hipStreamDestroy(ws->aux);
   if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
   if (ws->ev_join) (void)hipEventDestroy(ws->ev_join);
@@ -299,8 +376,6 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   ENSURE(ws->ioff,((size_t)nreads+1)*8);
   ENSURE(ws->eoff,((size_t)nreads+1)*8);
   ENSURE(ws->hoff,((size_t)nreads+1)*8);
-  ENSURE(ws->err,16);
-  HIPCHK(hipMemsetAsync(ws->err.p,0,16,st));
   HIPCHK(hipMemsetAsync(ws->nintvl.p,0,(size_t)nreads*4,st));
   HIPCHK(hipMemsetAsync(ws->nrel.p,0,(size_t)nreads*4,st));
   int rc = launch_scan(&p->host,d_prof,total_kmers,(uint64_t *)ws->bitmap.p,ws->nwords,st);
@@ -443,21 +518,26 @@ extern "C" int cp_classify_batch(const cp_params *p, cp_workspace *ws,
 // The reference aborts in the same situation ("# E-intvls >= plen", wall.c:783-788).
 extern "C" int cp_workspace_check(cp_workspace *ws)
 { if (!ws) return set_err(CP_EINVAL,"cp_workspace_check: null workspace");
-  if (ws->decode_pending)
-    { ws->decode_pending = 0;
-      HIPCHK(hipMemcpyAsync(ws->h_err,ws->err2.p,4,hipMemcpyDeviceToHost,ws->stream));
-      HIPCHK(hipStreamSynchronize(ws->stream));
-      if (*ws->h_err)
-        return set_err(CP_EINVAL,"cp_decode_profiles: a code string does not expand to its read's profile length (rlen != plen+K-1)");
-    }
-  if (ws->nreads == 0 && ws->seed_nreads == 0) return CP_OK;
-  HIPCHK(hipMemcpyAsync(ws->h_err,ws->err.p,4,hipMemcpyDeviceToHost,ws->stream));
+  // one read-back of the three sticky error words, then they are cleared: every flag raised by a call on this
+  // workspace since the previous check is reported once
+  HIPCHK(hipMemcpyAsync(ws->h_err,ws->err.p,16,hipMemcpyDeviceToHost,ws->stream));
+  HIPCHK(hipMemsetAsync(ws->err.p,0,16,ws->stream));
   HIPCHK(hipStreamSynchronize(ws->stream));
-  if (*ws->h_err)
+  for (void *q : *ws->retired) (void)hipFree(q);          // nothing on the stream uses an outgrown buffer any more
+  ws->retired->clear();
+  ws->decode_pending = 0;
+  const int ew = ws->h_err[0], es = ws->h_err[1], ed = ws->h_err[2];
+  if (ed)
+    return set_err(CP_EINVAL,"cp_decode_profiles: a code string does not expand to its read's profile length (rlen != plen+K-1)");
+  if (ew)
     { char m[160];
-      if (*ws->h_err & 8) snprintf(m,sizeof(m),"# E-intvls >= plen: the reference exits on a read of this batch (wall.c:783-788) (flags=%d)",*ws->h_err);
-      else if (*ws->h_err & 4) snprintf(m,sizeof(m),"scratch overflow in find_seeds (flags=%d)",*ws->h_err);
-      else snprintf(m,sizeof(m),"scratch overflow in find_wall (flags=%d): too many E-intervals for a read",*ws->h_err);
+      if (ew & 8) snprintf(m,sizeof(m),"# E-intvls >= plen: the reference exits on a read of this batch (wall.c:783-788) (flags=%d)",ew);
+      else snprintf(m,sizeof(m),"scratch overflow in find_wall (flags=%d): too many E-intervals for a read",ew);
+      return set_err(CP_EOVERFLOW,m);
+    }
+  if (es)
+    { char m[160];
+      snprintf(m,sizeof(m),"scratch overflow in find_seeds (flags=%d)",es);
       return set_err(CP_EOVERFLOW,m);
     }
   return CP_OK;
@@ -521,10 +601,8 @@ extern "C" int cp_decode_profiles(cp_workspace *ws, const uint8_t *d_codes, cons
     return set_err(CP_EINVAL,"cp_decode_profiles: bad argument");
   if (nreads == 0) return CP_OK;
   hipStream_t st = (hipStream_t)stream;
-  ENSURE(ws->err2,16);
-  HIPCHK(hipMemsetAsync(ws->err2.p,0,16,st));
   hipLaunchKernelGGL(k_decode_profiles,dim3(nreads),dim3(WAVE),0,st,
-                     d_codes,d_code_off,d_prof_off,nreads,d_prof,(int32_t *)ws->err2.p);
+                     d_codes,d_code_off,d_prof_off,nreads,d_prof,(int32_t *)ws->err.p+2);
   HIPCHK(hipGetLastError());
   ws->decode_pending = 1;
   ws->stream = st;
@@ -549,8 +627,6 @@ extern "C" int cp_find_seeds_batch(const cp_params *p, cp_workspace *ws, const c
   ENSURE(ws->s_key,(size_t)nreads*4);
   ENSURE(ws->perm,(size_t)nreads*4);
   ENSURE(ws->s_repcnt,(size_t)nreads*4);
-  ENSURE(ws->err,16);
-  if (ws->nreads == 0) HIPCHK(hipMemsetAsync(ws->err.p,0,16,st));      // no classification run shares the flag word
   HIPCHK(hipMemsetAsync(ws->s_dummy.p,0,((size_t)nreads+1)*8,st));
   hipLaunchKernelGGL(k_seed_caps,dim3(nreads),dim3(WAVE),0,st,d_prof,d_prof_off,d_labels,d_seq_off,K,nreads,
                      (int64_t *)ws->s_cap.p,(int64_t *)ws->s_rcap.p,(int32_t *)ws->s_key.p);
@@ -573,7 +649,7 @@ extern "C" int cp_find_seeds_batch(const cp_params *p, cp_workspace *ws, const c
   hipLaunchKernelGGL(k_find_seeds,dim3(nreads),dim3(WAVE),0,st,d_seq,d_seq_off,d_prof,d_prof_off,d_labels,K,nreads,
                      (const int64_t *)ws->s_cap.p,(const int64_t *)ws->s_rcap.p,(const int32_t *)ws->perm.p,
                      (int32_t *)ws->s_seg.p,(int32_t *)ws->s_aux.p,(int32_t *)ws->s_mi.p,
-                     (int32_t *)ws->s_rep.p,(int32_t *)ws->s_repcnt.p,d_seeds,(int32_t *)ws->err.p,totalS);
+                     (int32_t *)ws->s_rep.p,(int32_t *)ws->s_repcnt.p,d_seeds,(int32_t *)ws->err.p+1,totalS);
   HIPCHK(hipGetLastError());
   return CP_OK;
 }

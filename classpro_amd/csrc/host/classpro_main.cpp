@@ -46,6 +46,8 @@
 #include <atomic>
 #include <memory>
 #include <condition_variable>
+#include <csignal>
+#include <cerrno>
 #include "../../../include/classpro_amd.h"
 #include "host_io.h"
 #include "dazz_db.h"
@@ -252,6 +254,30 @@ struct Run
     }
 }
 
+// The outputs are written through shared mappings of files that were sized with ftruncate: a page that could not be
+// allocated (a full tmpfs / disk, a quota) shows up as SIGBUS at the first store into it, not as a failed write().  The
+// reference's fprintf path reports "no space" and exits 1; so does this one: fallocate's result is checked (give_pages)
+// and, for file systems without fallocate, a SIGBUS handler says what happened.  Either way the partial outputs go.
+static char g_out_files[4][1024];
+static void remember_output(const std::string &p)
+{ for (auto &f : g_out_files) if (!f[0]) { snprintf(f,sizeof(f),"%s",p.c_str()); return; } }
+static void on_sigbus(int)
+{ static const char msg[] = "ClassPro: no space left on the output device (a page of the mapped output could not be allocated)\n";
+  ssize_t w = write(2,msg,sizeof(msg)-1); (void)w;
+  for (auto &f : g_out_files) if (f[0]) unlink(f);
+  _exit(1);
+}
+static void give_pages(int fd, int mode, int64_t lo, int64_t n, const char *what)
+{ if (n <= 0) return;
+  int rc;
+  do rc = fallocate(fd,mode,(off_t)lo,(off_t)n); while (rc != 0 && errno == EINTR);
+  if (rc == 0 || errno == EOPNOTSUPP || errno == ENOSYS || errno == EINVAL)
+    return;                                    // (no fallocate here: pages come at first touch, on_sigbus reports a full device)
+  const int e = errno;
+  for (auto &f : g_out_files) if (f[0]) unlink(f);
+  die("%s: cannot allocate %lld bytes of %s: %s\n",PROG,(long long)n,what,strerror(e));
+}
+
 static inline void unpack_bases(const unsigned char *pk, int len, char *dst)      // DB.c:342-381 (Uncompress_Read + Upper_Read)
 { static const char letter[4] = { 'A', 'C', 'G', 'T' };
   for (int k = 0; k < len; k++)
@@ -284,6 +310,10 @@ struct Device
           if (R->model_path.empty())
             fprintf(stderr,"Error model not specified. Using the default error model.\n");
           fprintf(stderr,"Classifying %d-mers...\n",R->K);
+          size_t tb[3] = {0,0,0};
+          cp_params_tables(params,&tb[0],&tb[1],&tb[2]);
+          fprintf(stderr,"device tables: logp_trans %zu MB, unrel binomial %zu MB, P(error in) %zu MB%s\n",tb[0] >> 20,tb[1] >> 20,tb[2] >> 20,
+                  (tb[0] && tb[1] && tb[2]) ? "" : " (0 = computed on the spot: no device memory for it, or switched off)");
         }
       // the slots (0.8 GB of pinned memory each: the costly part of start-up) come up on a helper thread, one by
       // one, while the first batches are already moving
@@ -628,8 +658,8 @@ int main(int argc, char **argv)
                 if (R.pre_upto > lo) lo = R.pre_upto;
               }
           }
-          if (w->out_hi > lo) (void)fallocate(R.out_fd,0,(off_t)lo,(off_t)(w->out_hi-lo));
-          if (w->trk_hi > w->trk_lo) (void)fallocate(R.trk_fd,0,(off_t)w->trk_lo,(off_t)(w->trk_hi-w->trk_lo));
+          give_pages(R.out_fd,0,lo,w->out_hi-lo,"the .class output");
+          give_pages(R.trk_fd,0,w->trk_lo,w->trk_hi-w->trk_lo,"the .class.data track");
           t_alloc += secs(t0,now());
           { std::lock_guard<std::mutex> lk(R.am); w->allocated = true; }
           R.acv.notify_all();
@@ -639,6 +669,8 @@ int main(int argc, char **argv)
 
   R.out_fd = open(out_path.c_str(),O_RDWR|O_CREAT|O_TRUNC,0644);
   if (R.out_fd < 0) die("Cannot open %s\n",out_path.c_str());
+  remember_output(out_path);
+  { struct sigaction sa; memset(&sa,0,sizeof(sa)); sa.sa_handler = on_sigbus; sigaction(SIGBUS,&sa,nullptr); }
   if (is_db)
     { // .anno: int nreads, int size = 8, int64 0, then the end offset of every read's data (what merge_anno, io.c:15-68,
       // makes of the per-thread pieces); the offsets only depend on the read lengths, so the file is written up front
@@ -646,6 +678,7 @@ int main(int argc, char **argv)
       FILE *anno = fopen(an.c_str(),"wb");
       R.trk_fd = open(dn.c_str(),O_RDWR|O_CREAT|O_TRUNC,0644);
       if (!anno || R.trk_fd < 0) die("Cannot open .*.class.*\n");
+      remember_output(dn);
       const int nr = db.nreads, size = 8; const int64_t zero = 0;
       fwrite(&nr,4,1,anno); fwrite(&size,4,1,anno); fwrite(&zero,8,1,anno);
       int64_t t = 0;
@@ -673,7 +706,8 @@ int main(int argc, char **argv)
           { const int64_t step = (int64_t)256 << 20;
             for (int64_t a = 0; a < est; a += step)
               { const int64_t n = std::min(step,est-a);
-                if (fallocate(R.out_fd,FALLOC_FL_KEEP_SIZE,(off_t)a,(off_t)n) != 0) break;   // (no room, no fallocate: window by window)
+                if (fallocate(R.out_fd,FALLOC_FL_KEEP_SIZE,(off_t)a,(off_t)n) != 0) break;   // (an estimate only: what it could not get
+                                                                                             //  is asked for again, and checked, window by window)
                 { std::lock_guard<std::mutex> lk(R.am); R.pre_upto = a+n; }
                 R.acv.notify_all();
               }

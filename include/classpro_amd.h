@@ -72,9 +72,11 @@ int cp_hist_covs(const int64_t *hist, int low, int high, int64_t ilowcnt, int64_
  * (src/ClassPro.c:544-548) and calc_init_thres(NULL) (src/wall.c:167-244): builds the read-only
  * tables on the host and uploads them to the current HIP device.  It also has the device fill a table of
  * logp_trans values (util.c:35-44: a function of |ce-cb| and the integer cov*|e-b| alone; 1 GB of device memory by
- * default, environment CLASSPRO_SKELLAM_TABLE_MB, 0 = none) and two small ones (classify_unrel's binomial-test logs,
- * the walk's P(error in): 74 MB) with the code the kernels otherwise run on the spot, so results are the same bits
- * with or without them; when the memory is not there the library goes on without the tables.
+ * default, environment CLASSPRO_SKELLAM_TABLE_MB, 0 = no such table) and two small ones (classify_unrel's
+ * binomial-test logs, the walk's P(error in): 74 MB) with the code the kernels otherwise run on the spot, so results
+ * are the same bits with or without them (CLASSPRO_TABLES=0: none of the three).  The tables depend on READ_LEN / the
+ * error model only, so all cp_params of a process that agree on those share one reference-counted copy per device.
+ * A table that finds no device memory is left out (slower, same results); cp_params_tables tells which are in use.
  * CP_ERCOV when the repeat threshold exceeds 255 (wall.c:174-177). */
 typedef struct cp_params cp_params;
 int  cp_params_create(int K, int read_len, int hcov, int dcov, cp_params **out);
@@ -87,6 +89,9 @@ int  cp_params_create(int K, int read_len, int hcov, int dcov, cp_params **out);
 int  cp_params_create_model(int K, int read_len, int hcov, int dcov, const char *model_path, cp_params **out);
 int  cp_load_error_model(const char *model_path, double *pe63);
 void cp_params_destroy(cp_params *p);
+/* Device bytes of the three look-up tables this cp_params uses (0 = that table is not in use: its values are
+ * computed on the spot). */
+int  cp_params_tables(const cp_params *p, size_t *skel_bytes, size_t *uerr_bytes, size_t *petab_bytes);
 /* Host copies of the tables, for inspection/tests: cov[4]=GLOBAL_COV[E,R,H,D]; cthres is
  * [3][21][256][2][2] = [ctype][l][cout][INIT|FINAL][SELF|OTHERS]; pe is [3][21]; logfact[32768]. */
 int  cp_params_export(const cp_params *p, int *cov4, double *dr_ratio, int *cmax, double *hc_erate,
@@ -151,9 +156,10 @@ int cp_find_seeds_batch(const cp_params *p, cp_workspace *ws,
 int cp_get_rep_masks(cp_workspace *ws, int32_t *count, int64_t *cap_off, int32_t *pairs, int64_t capacity);
 int64_t cp_rep_masks_capacity(const cp_workspace *ws);
 
-/* Waits for the last run on `ws` and returns CP_EOVERFLOW if a read needed more E-interval /
- * interval scratch than its capacity (the reference aborts likewise: "# E-intvls >= plen",
- * src/wall.c:783-788).  Call after cp_classify_batch before trusting the labels. */
+/* Waits for the work queued on `ws` and returns CP_EOVERFLOW if, in ANY call on `ws` since the previous check, a read
+ * needed more E-interval / interval / seed scratch than its capacity (the reference aborts likewise: "# E-intvls >=
+ * plen", src/wall.c:783-788), CP_EINVAL for a bad code string in cp_decode_profiles.  The device-side flags are sticky
+ * and are cleared by this call only.  Call after cp_classify_batch before trusting the labels. */
 int cp_workspace_check(cp_workspace *ws);
 
 /* Stage entry points (the reference's per-read internal contract, batched).  They run the

@@ -1,3 +1,4 @@
+import hashlib
 import os
 import subprocess
 import sys
@@ -13,6 +14,24 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def build_if_changed(out, cmd, deps):
+    """Runs `cmd` (which writes `out`) unless `out` exists and was built from exactly these sources and this command:
+    the key is a hash of the CONTENT of `deps` kept beside the output (`<out>.srchash`), not file times -- after a
+    fresh checkout, or on a snapshot copied to another box, every mtime is the copy time and says nothing."""
+    h = hashlib.sha1(" ".join(cmd).encode())
+    for d in sorted(deps):
+        h.update(d.encode())
+        h.update(open(d, "rb").read())
+    key = h.hexdigest()
+    side = out + ".srchash"
+    if os.path.exists(out) and os.path.exists(side) and open(side).read().strip() == key:
+        return out
+    subprocess.check_call(cmd)
+    with open(side, "w") as f:
+        f.write(key + "\n")
+    return out
 
 
 @pytest.fixture(scope="session")
@@ -31,9 +50,9 @@ def harness(built):
     import ctypes as C
     src = os.path.join(ROOT, "tests", "host_harness.cpp")
     out = os.path.join(ROOT, "tests", "_host_harness.so")
-    deps = [src] + [os.path.join(ROOT, "classpro_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "classpro_amd", "csrc"))]
-    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-o", out, src])
+    csrc = os.path.join(ROOT, "classpro_amd", "csrc")
+    deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
+    build_if_changed(out, ["g++", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-o", out, src], deps)
     H = C.CDLL(out)
     H.hh_params_new.restype = C.c_void_p
     H.hh_params_cthres.restype = C.c_void_p

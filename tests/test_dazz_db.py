@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 import eval_case
-from conftest import ROOT
+from conftest import ROOT, build_if_changed
 
 K = 40
 TOOLS = os.path.join(ROOT, "classpro_amd")
@@ -97,8 +97,7 @@ def test_writer_and_tracks_against_reference_db_library(built, tmp_path, dam):
     exe = os.path.join(ROOT, "tests", "_track_harness")
     srcs = [os.path.join(ROOT, "tests", "track_harness.cpp"), os.path.join(TOOLS, "csrc", "host", "dazz_db.h"),
             os.path.join(TOOLS, "csrc", "host", "host_io.h")]
-    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(x) for x in srcs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", srcs[0], "-o", exe, "-lz"])
+    build_if_changed(exe, ["g++", "-O2", "-std=c++17", srcs[0], "-o", exe, "-lz"], srcs)
     subprocess.check_call([exe, d, "reads", os.path.join(d, "est.class")])
     alen = (C.c_int * len(seqs))()
     data = C.create_string_buffer(sum(len(s) for s in seqs))

@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, build_if_changed
 
 
 @pytest.fixture(scope="module")
@@ -17,9 +17,7 @@ def checker():
     src = os.path.join(ROOT, "tests", "fx_index_check.cpp")
     out = os.path.join(ROOT, "tests", "_fx_index_check")
     deps = [src] + [os.path.join(ROOT, "classpro_amd", "csrc", "host", f) for f in ("fastx_index.h", "host_io.h", "thread_pool.h")]
-    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", out, src, "-lz", "-lpthread"])
-    return out
+    return build_if_changed(out, ["g++", "-O2", "-std=c++17", "-o", out, src, "-lz", "-lpthread"], deps)
 
 
 def _reads(rng, n, lo=50, hi=4000):

@@ -561,7 +561,7 @@ def test_adversarial_inputs(torch_dev, seed):
 def test_skellam_table_is_what_the_kernels_compute(torch_dev, ds_b, monkeypatch):
     """logp_trans comes from a device-built table (cp_types.h: |ce-cb| <= 255, cov*|e-b| below a bound) or, outside
     it, from the recurrence on the spot.  The table is filled by that very code, so a classifier without a table
-    (CLASSPRO_SKELLAM_TABLE_MB=0), one with a tiny table (most products outside it) and the default one must agree to
+    (CLASSPRO_TABLES=0), one with a tiny table (most products outside it) and the default one must agree to
     the last bit: labels, interval records (incl. their doubles) and the run on a 200-Mbase device-generated batch."""
     torch = torch_dev
     import ctypes as C
@@ -571,11 +571,17 @@ def test_skellam_table_is_what_the_kernels_compute(torch_dev, ds_b, monkeypatch)
     ds, hc, dc = ds_b
 
     def run(mb, batch_fn, hc_, dc_, rl):
-        if mb is None:
-            monkeypatch.delenv("CLASSPRO_SKELLAM_TABLE_MB", raising=False)
-        else:
+        monkeypatch.delenv("CLASSPRO_SKELLAM_TABLE_MB", raising=False)
+        monkeypatch.delenv("CLASSPRO_TABLES", raising=False)
+        if mb == 0:
+            monkeypatch.setenv("CLASSPRO_TABLES", "0")               # none of the three tables
+        elif mb is not None:
             monkeypatch.setenv("CLASSPRO_SKELLAM_TABLE_MB", str(mb))
         clf = Classifier(K=K, read_len=rl, hcov=hc_, dcov=dc_)
+        tb = clf.tables()
+        assert (tb["skel"] == 0) == (mb == 0) and (tb["uerr"] == 0) == (mb == 0) and (tb["petab"] == 0) == (mb == 0), tb
+        if mb == 1:
+            assert tb["skel"] == 1 << 20
         b = batch_fn()
         lab = clf.classify(b).copy()
         nc, ni, nr, off = clf.counts(b)
