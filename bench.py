@@ -7,12 +7,18 @@ distinct seeded reads, 8.0 Gbases, 16 GB of uint16 count profiles, generated on 
 path (cp_classify_batch: candidate scan, find_wall, find_rel_intvl, classify_rel, classify_unrel, label paint)
 over the whole resident read set, issued as sub-batches of --batch-mbases (the size that fills the machine).
 
-N > 1 (strong scaling, BASELINE configs[3]'s shape): the SAME read set is sharded over the ranks as contiguous
-read ranges balanced by bases (classpro_amd.shard.plan_shards); every rank generates and classifies only its own
-range; there is no data-path collective (torch.distributed = barrier + max-over-ranks time only).
-`--scaling weak` gives every rank its own full-size set instead.
+N > 1 (strong scaling) defaults to BASELINE configs[3]: a synthetic 3 Gbp diploid genome at 40x, 6 000 000 reads,
+120 Gbases, sharded over the ranks as contiguous read ranges balanced by bases (classpro_amd.shard.plan_shards);
+every rank generates and classifies only its own range; there is no data-path collective (torch.distributed =
+barrier + max-over-ranks time only).  A rank's share (15 Gbases = 60 GB of bases, counts and labels at N = 8) is
+resident in HBM when it fits; a share that does not fit (N = 1, 2: 120 / 60 Gbases) is taken in resident WINDOWS of
+at most --window-gbases: a window is generated (untimed), then the W warm-up and the K timed passes run over it
+between barriers, then the next window; a step's time is the sum over the windows, so every step still classifies
+every base of the share exactly once and the inputs of every timed region are resident when it starts.
+`--shard r/N` runs rank r's share of an N-rank run in ONE process on one GPU (no process group): the way one shard
+of configs[3] is measured on a single-GPU box.  `--scaling weak` gives every rank its own full-size set instead.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--genome 3e9 --shard r/N]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 `python bench.py --gpus N` without a launcher starts the N ranks itself (before any GPU call).
@@ -43,7 +49,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--genome", type=float, default=200e6, help="synthetic diploid genome length (configs[2]: 200 Mbp)")
+    ap.add_argument("--genome", type=float, default=None,
+                    help="synthetic diploid genome length; default 200e6 (configs[2]) for one GPU, 3e9 (configs[3]) for --gpus N > 1 or --shard")
+    ap.add_argument("--shard", default=None, metavar="r/N",
+                    help="classify only shard r of the N contiguous shards of the read set, in this one process (no process group)")
+    ap.add_argument("--window-gbases", type=float, default=32.0,
+                    help="a rank's share is resident in HBM in windows of at most this many Gbases (4 B of HBM per base + workspace)")
     ap.add_argument("--cov", type=int, default=40)
     ap.add_argument("--read-len", type=int, default=20000)
     ap.add_argument("--batch-mbases", type=float, default=1200.0, help="sub-batch size of one cp_classify_batch call")
@@ -110,35 +121,43 @@ def main():
 
     # ---- synthetic workload, generated in HBM -------------------------------------------------------------
     t0 = time.time()
+    shard_r, shard_n = (rank, world)
+    if a.shard:
+        if world != 1:
+            sys.stderr.write("bench.py: --shard runs in one process (--gpus 1)\n")
+            sys.exit(2)
+        shard_r, shard_n = (int(x) for x in a.shard.split("/"))
+        if not 0 <= shard_r < shard_n:
+            sys.stderr.write("bench.py: --shard r/N needs 0 <= r < N\n")
+            sys.exit(2)
+    if a.genome is None:
+        a.genome = 3e9 if (world > 1 or a.shard) and a.scaling == "strong" else 200e6
     G = int(a.genome)
+    cfg = "BASELINE configs[3]" if G >= 3_000_000_000 else "BASELINE configs[2]" if G == 200_000_000 else "configs[2]-like"
     seed = a.seed + (rank if a.scaling == "weak" else 0)
     ds = DeviceSynth(genome_len=G, cov=a.cov, read_len=a.read_len, K=K, seed=seed, device=str(dev))
+    torch.cuda.synchronize()
+    t_setup = time.time() - t0
     low, high, il, ih, h = ds.hist
     hcov, dcov = hist_covs(h, low, high, il, ih, 0)
     if a.scaling == "strong":
-        bounds = plan_shards(ds.seq_off_all, world)
-        first, last = bounds[rank], bounds[rank + 1]
+        bounds = plan_shards(ds.seq_off_all, shard_n)
+        first, last = bounds[shard_r], bounds[shard_r + 1]
     else:
         first, last = 0, ds.n_reads
-    # sub-batches of at most --batch-mbases, their number a multiple of the stream count (so that consecutive
-    # sub-batches, also across steps, alternate over the streams); a rank's share is never a single sub-batch
     share = int(ds.seq_off_all[last] - ds.seq_off_all[first])
-    nst_ = max(1, a.streams)
-    nb_ = max(nst_, -(-share // int(a.batch_mbases * 1e6)))
-    nb_ = -(-nb_ // nst_) * nst_
-    plan = ds.plan_batches(-(-share // nb_) + 1, first, last)
-    batches = []
-    for i, (r0, n) in enumerate(plan):
-        rd = ds.reads(r0, n, truth=(i == 0 and rank == 0))
-        batches.append((rd, Batch.from_device(rd)))
-    torch.cuda.synchronize()
-    ds.check()
-    t_gen = time.time() - t0
-    my_bases = sum(b.total_bases for _, b in batches)
-    my_kmers = sum(b.total_kmers for _, b in batches)
+    nst = max(1, a.streams)
+    # resident windows of the share (one when it fits), every rank the same number of them (the barriers pair up)
+    nwin = max(1, -(-share // int(a.window_gbases * 1e9)))
+    if world > 1:
+        t = torch.tensor([nwin], dtype=torch.int64, device=rdev or dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        nwin = int(t.item())
+    windows = ds.plan_batches(-(-share // nwin) + 1, first, last)
+    while len(windows) < nwin:
+        windows.append((last, 0))
 
     clf = Classifier(K=K, read_len=a.read_len, hcov=hcov, dcov=dcov, device=str(dev))
-    nst = max(1, a.streams)
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nst - 1)]
     wss = [clf.ws]
     for _ in range(nst - 1):
@@ -146,7 +165,23 @@ def main():
         check(L.cp_workspace_create(C.byref(w)))
         wss.append(w)
 
-    def step():
+    def make_batches(w_first, w_count, truth):
+        """sub-batches of at most --batch-mbases, their number a multiple of the stream count (so that consecutive
+        sub-batches, also across steps, alternate over the streams); a window is never a single sub-batch"""
+        if w_count == 0:
+            return []
+        wb = int(ds.seq_off_all[w_first + w_count] - ds.seq_off_all[w_first])
+        nb_ = max(nst, -(-wb // int(a.batch_mbases * 1e6)))
+        nb_ = -(-nb_ // nst) * nst
+        out = []
+        for i, (r0, n) in enumerate(ds.plan_batches(-(-wb // nb_) + 1, w_first, w_first + w_count)):
+            rd = ds.reads(r0, n, truth=(truth and i == 0))
+            out.append((rd, Batch.from_device(rd)))
+        torch.cuda.synchronize()
+        ds.check()
+        return out
+
+    def step(batches):
         for i, (_, b) in enumerate(batches):
             k = i % nst
             check(L.cp_classify_batch(clf.p, wss[k], b.seq.data_ptr(), b.seq_off.data_ptr(), b.prof.data_ptr(),
@@ -158,16 +193,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    for w in wss:
-        check(L.cp_workspace_check(w))
+    dt, t_gen, my_bases, my_kmers, nsub = 0.0, 0.0, 0, 0, 0
+    batches = []
+    for wi, (w_first, w_count) in enumerate(windows):
+        del batches
+        torch.cuda.empty_cache()                            # the previous window's 4 B per base go back before the next is generated
+        tg = time.time()
+        batches = make_batches(w_first, w_count, truth=(rank == 0))
+        t_gen += time.time() - tg
+        my_bases += sum(b.total_bases for _, b in batches)
+        my_kmers += sum(b.total_kmers for _, b in batches)
+        nsub += len(batches)
+        for _ in range(a.warmup):
+            step(batches)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step(batches)
+        barrier()
+        dt += time.perf_counter() - t0
+        for w in wss:                                       # the error words are sticky: every launch since the last check is covered
+            check(L.cp_workspace_check(w))
+    # (the last window stays resident: the roofline loop, the CPU legs and the extras below run on it)
+    win_bases = sum(b.total_bases for _, b in batches)
+    win_kmers = sum(b.total_kmers for _, b in batches)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=rdev or dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -199,7 +248,7 @@ def main():
         torch.cuda.synchronize()
         nlaunch = reps * len(batches)
         scan_ms = e0.elapsed_time(e1) / nlaunch
-        alg_bytes = 2.0 * my_kmers / len(batches)       # 2 B (uint16 count) per position; average launch
+        alg_bytes = 2.0 * win_kmers / len(batches)      # 2 B (uint16 count) per position; average launch
         achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
         del bms
         traffic, traffic_src = None, None
@@ -216,11 +265,13 @@ def main():
         roof = {"kernel": "k_scan_candidates", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "ms_per_launch": round(scan_ms, 4), "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": nlaunch,
-                "working_set_bytes": 2.0 * my_kmers}
+                "working_set_bytes": 2.0 * win_kmers}
 
         rd0, b0 = batches[0]
         extras = {"whole_step_algorithmic_gb_per_s": round((2.0 * my_kmers + 2.0 * my_bases) * world / (dt / a.steps) / 1e9, 1),
-                  "gen_seconds": round(t_gen, 2), "sub_batches_per_rank": len(batches), "streams": nst,
+                  "synth_setup_seconds": round(t_setup, 2), "gen_seconds": round(t_gen, 2), "sub_batches_per_rank": nsub,
+                  "resident_windows_per_rank": len(windows), "window_gbases": round(win_bases / 1e9, 2), "streams": nst,
+                  "tables_bytes": clf.tables(), "hbm_peak_allocated_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
                   "workspace_gb": round(sum(int(L.cp_workspace_bytes(w)) for w in wss) / 1e9, 2),
                   "synth_err_kmer_fraction": round(ds.n_err_kmers / max(1, ds.total_bases), 4)}
 
@@ -236,9 +287,9 @@ def main():
         # ---- CPU baseline: the oracle (a port, pthreads) on bounded samples of the same workload; every label
         #      of the samples is also compared with the HIP result --------------------------------------------
         cpu = None
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:                 # (the contract: on rank 0 at N = 1 only)
             cpu = cpu_baseline(a, ds, batches, hcov, dcov)
-        if not a.no_extras:
+        if not a.no_extras and world == 1 and not a.shard and G <= 200_000_000:
             extras.update(extra_rates(a, ds, clf, batches, hcov, dcov, dev, stream))
 
         out = {
@@ -246,11 +297,16 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "u16/f64",
             "data": "synthetic",
-            "config": {"workload": "synthetic %.0f Mbp diploid, %dx HiFi, r=%d, k=40 (BASELINE configs[2]): %d distinct reads, %.2f Gbases, resident in HBM, "
-                                   "sub-batches of %.0f Mbases" % (G / 1e6, a.cov, a.read_len, ds.n_reads, ds.total_bases / 1e9, a.batch_mbases),
+            "config": {"workload": "synthetic %.0f Mbp diploid, %dx HiFi, r=%d, k=40 (%s): %d distinct reads, %.2f Gbases%s; a rank's share resident in HBM "
+                                   "%s, sub-batches of at most %.0f Mbases"
+                                   % (G / 1e6, a.cov, a.read_len, cfg, ds.n_reads, ds.total_bases / 1e9,
+                                      (", of which shard %d of %d (%.2f Gbases) in this process" % (shard_r, shard_n, my_bases / 1e9)) if a.shard else "",
+                                      "whole" if len(windows) == 1 else "in %d windows (each generated untimed, then warm-up + timed steps over it; a step = the sum over windows)" % len(windows),
+                                      a.batch_mbases),
                        "reads_total": ds.n_reads if a.scaling == "strong" else ds.n_reads * world, "bases_total": total_bases_all,
                        "reads_rank0": last - first, "bases_rank0": my_bases, "hcov": hcov, "dcov": dcov,
-                       "parallelism": "contiguous read ranges balanced by bases x%d (%s), no collective" % (world, a.scaling)},
+                       "shard": a.shard,
+                       "parallelism": "contiguous read ranges balanced by bases x%d (%s), no collective" % (shard_n if a.shard else world, a.scaling)},
             "roofline": roof, "cpu_baseline": cpu, "extras": extras,
         }
         print(json.dumps(out), flush=True)

@@ -53,6 +53,22 @@ def _chk(rc):
         raise RuntimeError("synth_gen: " + lib().sg_last_error().decode(errors="replace"))
 
 
+def _cumsum_into(src, out, chunk=1 << 28):
+    """out[i] = sum(src[0..i]) as int32, chunk by chunk with a carried total: the arrays of a 3-Gbp genome hold more
+    than 2^31 elements and a chunk's temporary stays at 1 GB.  `out` may be `src` itself (int32, in place)."""
+    carry = 0
+    n = src.numel()
+    for a in range(0, n, chunk):
+        b = min(a + chunk, n)
+        t = torch.cumsum(src[a:b], 0, dtype=torch.int32)
+        if carry:
+            t += carry
+        carry = int(t[-1])
+        out[a:b] = t
+        del t
+    return out
+
+
 def _thr(rate):
     return int(min(max(rate, 0.0), 0.999999) * 4294967296.0)
 
@@ -110,7 +126,12 @@ class DeviceSynth:
         self.gen = torch.empty(G, dtype=torch.uint8, device=dev)
         _chk(self.L.sg_genome(C.byref(p), d_slot_fam.data_ptr(), self.gen.data_ptr(), st))
         snpcum = torch.zeros(G + 1, dtype=torch.int32, device=dev)
-        snpcum[1:] = torch.cumsum((self.gen >> 4) & 1, 0, dtype=torch.int32)
+        for a in range(0, G, 1 << 28):                     # SNP flags -> prefix counts, 256 M positions at a time
+            b = min(a + (1 << 28), G)
+            t = torch.cumsum((self.gen[a:b] >> 4) & 1, 0, dtype=torch.int32)
+            t += snpcum[a]
+            snpcum[a + 1:b + 1] = t
+            del t
 
         diffA = torch.zeros(G + 1, dtype=torch.int32, device=dev)
         diffB = torch.zeros(G + 1, dtype=torch.int32, device=dev)
@@ -118,10 +139,9 @@ class DeviceSynth:
         nerr = torch.zeros(1, dtype=torch.int64, device=dev)
         _chk(self.L.sg_reads_pass1(C.byref(p), self.gen.data_ptr(), diffA.data_ptr(), diffB.data_ptr(),
                                    self.rlen.data_ptr(), nerr.data_ptr(), st))
-        cntA = torch.cumsum(diffA, 0, dtype=torch.int32)
-        del diffA
-        cntB = torch.cumsum(diffB, 0, dtype=torch.int32)
-        del diffB
+        cntA = _cumsum_into(diffA, diffA)                   # in place: clean coverage per window and haplotype
+        cntB = _cumsum_into(diffB, diffB)
+        del diffA, diffB
 
         nwin = copy_len - K + 1
         famtot = torch.zeros(max(nf * nwin, 1), dtype=torch.int32, device=dev)
