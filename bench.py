@@ -461,6 +461,59 @@ def extra_rates(a, ds, clf, batches, hcov, dcov, dev, stream):
         del sl
     except Exception as e:
         ex["pcie_3_in_flight_error"] = repr(e)[:200]
+    # the same three-in-flight pipeline with 2-bit payloads: host-packed bases in (cp_pack_bases -> cp_unpack_bases), FASTK
+    # codes in, 2-bit labels out (cp_pack_labels; the host side's cp_unpack_labels is checked on one slot): 0.52 B/base
+    # in and 0.25 out instead of 1.27 and 1
+    try:
+        from classpro_amd.api import pack_bases, unpack_labels
+        pk = pack_bases(hm["seqs"])
+        if pk is None:
+            raise RuntimeError("the synthetic reads should be pure ACGT")
+        h_pk = torch.from_numpy(pk[0]).pin_memory()
+        d_pko = torch.from_numpy(pk[1]).to(dev)
+        npk = int(pk[1][-1])
+        NS = 3
+        sl = []
+        for _ in range(NS):
+            w = C.c_void_p()
+            check(L.cp_workspace_create(C.byref(w)))
+            sl.append(dict(st=torch.cuda.Stream(dev), ws=w, d_pk=torch.empty(npk, dtype=torch.uint8, device=dev), d_seq=torch.empty_like(bm.seq),
+                           d_code=torch.empty(len(codes), dtype=torch.uint8, device=dev), d_prof=torch.empty_like(bm.prof),
+                           d_lab=torch.empty_like(bm.labels), d_plab=torch.empty(npk, dtype=torch.uint8, device=dev),
+                           h_plab=torch.empty(npk, dtype=torch.uint8).pin_memory()))
+
+        def run2(nb):
+            for i in range(nb):
+                q = sl[i % NS]
+                q["st"].synchronize()
+                with torch.cuda.stream(q["st"]):
+                    sp = C.c_void_p(q["st"].cuda_stream)
+                    q["d_pk"].copy_(h_pk, non_blocking=True)
+                    q["d_code"].copy_(h_code, non_blocking=True)
+                    check(L.cp_unpack_bases(q["d_pk"].data_ptr(), d_pko.data_ptr(), bm.seq_off.data_ptr(), bm.nreads, q["d_seq"].data_ptr(), sp))
+                    check(L.cp_decode_profiles(q["ws"], q["d_code"].data_ptr(), d_coff.data_ptr(), bm.prof_off.data_ptr(), bm.nreads,
+                                               q["d_prof"].data_ptr(), sp))
+                    check(L.cp_classify_batch(clf.p, q["ws"], q["d_seq"].data_ptr(), bm.seq_off.data_ptr(), q["d_prof"].data_ptr(),
+                                              bm.prof_off.data_ptr(), bm.nreads, bm.total_bases, bm.total_kmers, q["d_lab"].data_ptr(), sp))
+                    check(L.cp_pack_labels(q["d_lab"].data_ptr(), bm.seq_off.data_ptr(), d_pko.data_ptr(), bm.nreads, q["d_plab"].data_ptr(), sp))
+                    q["h_plab"].copy_(q["d_plab"], non_blocking=True)
+            torch.cuda.synchronize()
+        run2(NS)
+        t0 = time.perf_counter()
+        run2(12)
+        dt2 = time.perf_counter() - t0
+        for q in sl:
+            check(L.cp_workspace_check(q["ws"]))
+        ex["pcie_inclusive_2bit_3_in_flight_mbases_per_s"] = round(12 * bm.total_bases / dt2 / 1e6, 1)
+        ex["pcie_2bit_bytes_per_base_in_out"] = [round((npk + len(codes)) / bm.total_bases, 3), round(npk / bm.total_bases, 3)]
+        got = unpack_labels(sl[0]["h_plab"].numpy(), pk[1], np.diff(rdm["seq_off_h"]), K)
+        ex["pcie_2bit_labels_match"] = bool(np.array_equal(got, h_lab.numpy())
+                                            and all(torch.equal(q["h_plab"], sl[0]["h_plab"]) for q in sl))
+        for q in sl:
+            L.cp_workspace_destroy(q["ws"])
+        del sl, h_pk
+    except Exception as e:
+        ex["pcie_2bit_error"] = repr(e)[:200]
     del m, rdm, bm, d_prof, h_seq, h_code, h_lab
 
     # BASELINE configs[4] stand-in: 60x, r=25000, with the -s seed path (cp_find_seeds_batch after the classification)

@@ -58,6 +58,33 @@ def encode_profiles(profiles):
     return codes, np.array(off, np.int64)
 
 
+def pack_bases(seqs):
+    """2-bit packing of a list of reads (bytes) for cp_unpack_bases: (uint8 packed, int64 pack_off[n+1]) or None when a
+    read holds a letter other than upper-case A, C, G, T (the batch then travels as characters)."""
+    L = lib()
+    off = np.zeros(len(seqs) + 1, np.int64)
+    np.cumsum([(len(x) + 3) // 4 for x in seqs], out=off[1:])
+    out = np.zeros(max(int(off[-1]), 1), np.uint8)
+    for i, x in enumerate(seqs):
+        b = np.frombuffer(bytes(x), np.uint8)
+        if len(b) and check(L.cp_pack_bases(b.ctypes.data, len(b), out[off[i]:].ctypes.data)) == 0:
+            return None
+    return out, off
+
+
+def unpack_labels(packed, pack_off, rlens, K):
+    """cp_unpack_labels for every read of a batch: the concatenated label bytes."""
+    L = lib()
+    packed = np.ascontiguousarray(packed, np.uint8)
+    so = np.zeros(len(rlens) + 1, np.int64)
+    np.cumsum(rlens, out=so[1:])
+    out = np.zeros(max(int(so[-1]), 1), np.uint8)
+    for i, n in enumerate(rlens):
+        if n:
+            check(L.cp_unpack_labels(packed[pack_off[i]:].ctypes.data, int(n), K, out[so[i]:].ctypes.data))
+    return out[:so[-1]]
+
+
 class Batch:
     """A batch of reads resident in HBM in the flat layout of include/classpro_amd.h."""
 

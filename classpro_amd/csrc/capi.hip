@@ -226,7 +226,8 @@ struct dbuf { void *p; size_t cap; };
 struct cp_workspace
   { dbuf bitmap, ncand, nintvl, nrel, ioff, eoff, hoff, wall, wall_s, hkeys, hvals, eintvl, ointvl, intvl, rintvl,
          relmap, parent, eff, rpos, asgn, ord, err, perm, wlist, err2, tres, fwc, dtot,
-         s_cap, s_rcap, s_dummy, s_key, s_seg, s_aux, s_mi, s_rep, s_repcnt;
+         s_cap, s_rcap, s_dummy, s_key, s_seg, s_aux, s_mi, s_rep, s_repcnt, scan_state, order_tmp;
+    int      scan_epoch;      // tag of the next k_prefix_caps_mb launch (its state array is never cleared)
     int64_t *h_totals;        // pinned: [totalI, totalE, totalH]
     int32_t *h_err;           // pinned
     // shape of the last run
@@ -299,7 +300,7 @@ extern "C" void cp_workspace_destroy(cp_workspace *ws)
   dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
                   &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
                   &ws->asgn,&ws->ord,&ws->err,&ws->perm,&ws->wlist,&ws->err2,&ws->tres,&ws->fwc,&ws->dtot,
-                  &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_rep,&ws->s_repcnt };
+                  &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_rep,&ws->s_repcnt,&ws->scan_state,&ws->order_tmp };
   for (dbuf *b : all) if (b->p) (void)hipFree(b->p);
   for (void *q : *ws->retired) (void)hipFree(q);
   delete ws->retired;
@@ -316,7 +317,7 @@ extern "C" size_t cp_workspace_bytes(const cp_workspace *ws)
   const dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
                         &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
                         &ws->asgn,&ws->ord,&ws->err,&ws->perm,&ws->wlist,&ws->err2,&ws->tres,&ws->fwc,&ws->dtot,
-                  &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_rep,&ws->s_repcnt };
+                  &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_rep,&ws->s_repcnt,&ws->scan_state,&ws->order_tmp };
   size_t s = 0;
   for (const dbuf *b : all) s += b->cap;
   return s;
@@ -348,6 +349,32 @@ extern "C" int cp_scan_candidates(const cp_params *p, const uint16_t *d_prof, in
   return launch_scan(&p->host,d_prof,total_kmers,d_bitmap,total_kmers/64+1,(hipStream_t)stream);
 }
 
+// exclusive prefix sums of the three capacity arrays (+ totals), one block per 1024 reads
+static int launch_prefix_caps(cp_workspace *ws, int64_t *a, int64_t *b, int64_t *c, int n, int64_t *totals, hipStream_t st)
+{ const int tiles = (n+SCAN_TILE-1)/SCAN_TILE;
+  const size_t c0 = ws->scan_state.cap;
+  ENSURE(ws->scan_state,(size_t)tiles*sizeof(cp_scan_state));
+  if (ws->scan_state.cap != c0)
+    { HIPCHK(hipMemsetAsync(ws->scan_state.p,0,ws->scan_state.cap,st)); ws->scan_epoch = 0; }
+  if (++ws->scan_epoch == 0x7fffffff)                     // (never in practice: the tags wrap, start over from a cleared array)
+    { HIPCHK(hipMemsetAsync(ws->scan_state.p,0,ws->scan_state.cap,st)); ws->scan_epoch = 1; }
+  hipLaunchKernelGGL(k_prefix_caps_mb,dim3(tiles),dim3(256),0,st,a,b,c,n,totals,(cp_scan_state *)ws->scan_state.p,ws->scan_epoch);
+  HIPCHK(hipGetLastError());
+  return CP_OK;
+}
+
+// perm[] = read ids by decreasing key >> shift (kernels.hip: k_order_hist / k_order_scatter)
+static int launch_order_by_work(cp_workspace *ws, const int32_t *key, int n, int shift, int32_t *perm, hipStream_t st)
+{ ENSURE(ws->order_tmp,(size_t)2*ORDER_BINS*4);
+  const int blocks = (n+ORDER_TILE-1)/ORDER_TILE;
+  HIPCHK(hipMemsetAsync(ws->order_tmp.p,0,(size_t)2*ORDER_BINS*4,st));
+  int32_t *ghist = (int32_t *)ws->order_tmp.p, *gcur = ghist+ORDER_BINS;
+  hipLaunchKernelGGL(k_order_hist,dim3(blocks),dim3(256),0,st,key,n,shift,ghist);
+  hipLaunchKernelGGL(k_order_scatter,dim3(blocks),dim3(256),0,st,key,n,shift,(const int32_t *)ghist,gcur,perm);
+  HIPCHK(hipGetLastError());
+  return CP_OK;
+}
+
 extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
                              const char *d_seq, const int64_t *d_seq_off,
                              const uint16_t *d_prof, const int64_t *d_prof_off,
@@ -376,23 +403,27 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   ENSURE(ws->ioff,((size_t)nreads+1)*8);
   ENSURE(ws->eoff,((size_t)nreads+1)*8);
   ENSURE(ws->hoff,((size_t)nreads+1)*8);
-  HIPCHK(hipMemsetAsync(ws->nintvl.p,0,(size_t)nreads*4,st));
-  HIPCHK(hipMemsetAsync(ws->nrel.p,0,(size_t)nreads*4,st));
-  int rc = launch_scan(&p->host,d_prof,total_kmers,(uint64_t *)ws->bitmap.p,ws->nwords,st);
+  // The head of a call: scan, candidate counts, prefix sums, then the one host round trip (scratch sizes depend on the
+  // data).  (Tried: the head on a high-priority stream of its own, forked from the caller's -- 143.9 against 146.9
+  // Gbases/s without: the other stream's wide kernels are what fills the machine, and pre-empting them costs more than
+  // the head's latency gains.)
+  hipStream_t hs = st;
+  HIPCHK(hipMemsetAsync(ws->nintvl.p,0,(size_t)nreads*4,hs));
+  HIPCHK(hipMemsetAsync(ws->nrel.p,0,(size_t)nreads*4,hs));
+  int rc = launch_scan(&p->host,d_prof,total_kmers,(uint64_t *)ws->bitmap.p,ws->nwords,hs);
   if (rc != CP_OK) return rc;
-  hipLaunchKernelGGL(k_count_caps,dim3(nreads),dim3(WAVE),0,st,
+  hipLaunchKernelGGL(k_count_caps,dim3(nreads),dim3(WAVE),0,hs,
                      (const uint64_t *)ws->bitmap.p,d_prof_off,nreads,
                      (int32_t *)ws->ncand.p,(int64_t *)ws->ioff.p,(int64_t *)ws->eoff.p,(int64_t *)ws->hoff.p);
   ENSURE(ws->dtot,32);
-  hipLaunchKernelGGL(k_prefix_caps,dim3(1),dim3(1024),0,st,(int64_t *)ws->ioff.p,(int64_t *)ws->eoff.p,
-                     (int64_t *)ws->hoff.p,nreads,(int64_t *)ws->dtot.p);
-  HIPCHK(hipGetLastError());
+  rc = launch_prefix_caps(ws,(int64_t *)ws->ioff.p,(int64_t *)ws->eoff.p,(int64_t *)ws->hoff.p,nreads,(int64_t *)ws->dtot.p,hs);
+  if (rc != CP_OK) return rc;
   if (last_stage == CP_STAGE_SCAN)
     return CP_OK;
 
-  // the only host round trip of the pipeline: scratch sizes depend on the data
-  HIPCHK(hipMemcpyAsync(&ws->h_totals[0],ws->dtot.p,24,hipMemcpyDeviceToHost,st));
-  HIPCHK(hipStreamSynchronize(st));
+  // the only host round trip of the pipeline
+  HIPCHK(hipMemcpyAsync(&ws->h_totals[0],ws->dtot.p,24,hipMemcpyDeviceToHost,hs));
+  HIPCHK(hipStreamSynchronize(hs));
   const int64_t totalI = ws->h_totals[0], totalE = ws->h_totals[1], totalH = ws->h_totals[2];
   ws->totalI = totalI; ws->totalE = totalE; ws->totalH = totalH;
 
@@ -415,7 +446,8 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   ENSURE(ws->perm,(size_t)nreads*4);
   ENSURE(ws->wlist,(size_t)totalI*4*4);
   // longest reads first: key = wall candidates / 4 (bins of 4 up to 4096 candidates)
-  hipLaunchKernelGGL(k_order_by_work,dim3(1),dim3(1024),0,st,(const int32_t *)ws->ncand.p,nreads,2,(int32_t *)ws->perm.p);
+  rc = launch_order_by_work(ws,(const int32_t *)ws->ncand.p,nreads,2,(int32_t *)ws->perm.p,st);
+  if (rc != CP_OK) return rc;
   ENSURE(ws->tres,(size_t)totalI*sizeof(task_res));
   ENSURE(ws->fwc,(size_t)nreads*16);
   // the walk's read-only part (candidate list, filters, the pure part of every live (candidate, error type) pair), then
@@ -453,7 +485,8 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   HIPCHK(hipMemsetAsync(ws->asgn.p,0xff,(size_t)totalI*2,st));
   // size classes (kernels.hip: REL_SMALL_*): M <= 128 four reads per wave, up to 1024 one read per wave, larger (or a
   // read beyond 65535 k-mers): the sequential kernel
-  hipLaunchKernelGGL(k_order_by_work,dim3(1),dim3(1024),0,st,(const int32_t *)ws->nrel.p,nreads,0,(int32_t *)ws->perm.p);
+  rc = launch_order_by_work(ws,(const int32_t *)ws->nrel.p,nreads,0,(int32_t *)ws->perm.p,st);
+  if (rc != CP_OK) return rc;
   // (the classes touch disjoint reads; the rare classes are a handful of latency-bound waves -- on most batches none at
   //  all, and the sequential kernel's 1024 scratch-using waves still cost 0.9 ms to start -- so they run beside the main
   //  class on the auxiliary stream)
@@ -479,7 +512,8 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   ENSURE(ws->ord,(size_t)totalI*4);
   // size classes (kernels.hip: UNREL_SMALL_*): N <= 256 and up to 1024, two reads per wave each (four speculative update
   // slots per read), larger: the sequential kernel; the rare classes on the auxiliary stream again
-  hipLaunchKernelGGL(k_order_by_work,dim3(1),dim3(1024),0,st,(const int32_t *)ws->nintvl.p,nreads,0,(int32_t *)ws->perm.p);
+  rc = launch_order_by_work(ws,(const int32_t *)ws->nintvl.p,nreads,0,(int32_t *)ws->perm.p,st);
+  if (rc != CP_OK) return rc;
   HIPCHK(hipEventRecord(ws->ev_fork,st));
   HIPCHK(hipStreamWaitEvent(ws->aux,ws->ev_fork,0));
   hipLaunchKernelGGL(k_classify_unrel,dim3(nreads < 1024 ? nreads : 1024),dim3(WAVE),0,ws->aux,
@@ -631,9 +665,9 @@ extern "C" int cp_find_seeds_batch(const cp_params *p, cp_workspace *ws, const c
   hipLaunchKernelGGL(k_seed_caps,dim3(nreads),dim3(WAVE),0,st,d_prof,d_prof_off,d_labels,d_seq_off,K,nreads,
                      (int64_t *)ws->s_cap.p,(int64_t *)ws->s_rcap.p,(int32_t *)ws->s_key.p);
   ENSURE(ws->dtot,32);
-  hipLaunchKernelGGL(k_prefix_caps,dim3(1),dim3(1024),0,st,(int64_t *)ws->s_cap.p,(int64_t *)ws->s_rcap.p,(int64_t *)ws->s_dummy.p,nreads,
-                     (int64_t *)ws->dtot.p);
-  HIPCHK(hipGetLastError());
+  { int rc = launch_prefix_caps(ws,(int64_t *)ws->s_cap.p,(int64_t *)ws->s_rcap.p,(int64_t *)ws->s_dummy.p,nreads,(int64_t *)ws->dtot.p,st);
+    if (rc != CP_OK) return rc;
+  }
   HIPCHK(hipMemcpyAsync(&ws->h_totals[0],ws->dtot.p,16,hipMemcpyDeviceToHost,st));
   HIPCHK(hipStreamSynchronize(st));
   const int64_t totalS = ws->h_totals[0], totalR = ws->h_totals[1];
@@ -645,7 +679,9 @@ extern "C" int cp_find_seeds_batch(const cp_params *p, cp_workspace *ws, const c
   HIPCHK(hipMemsetAsync(d_seeds,'E',(size_t)total_bases,st));
   hipLaunchKernelGGL(k_seed_prefix,dim3(nreads),dim3(WAVE),0,st,d_seq_off,K,nreads,d_seeds);
   // longest reads first: key = plen / 64
-  hipLaunchKernelGGL(k_order_by_work,dim3(1),dim3(1024),0,st,(const int32_t *)ws->s_key.p,nreads,6,(int32_t *)ws->perm.p);
+  { int rc = launch_order_by_work(ws,(const int32_t *)ws->s_key.p,nreads,6,(int32_t *)ws->perm.p,st);
+    if (rc != CP_OK) return rc;
+  }
   hipLaunchKernelGGL(k_find_seeds,dim3(nreads),dim3(WAVE),0,st,d_seq,d_seq_off,d_prof,d_prof_off,d_labels,K,nreads,
                      (const int64_t *)ws->s_cap.p,(const int64_t *)ws->s_rcap.p,(const int32_t *)ws->perm.p,
                      (int32_t *)ws->s_seg.p,(int32_t *)ws->s_aux.p,(int32_t *)ws->s_mi.p,
@@ -676,6 +712,62 @@ extern "C" int cp_unpack_bases(const uint8_t *d_packed, const int64_t *d_pack_of
   hipLaunchKernelGGL(k_unpack_bases,dim3(nreads),dim3(256),0,(hipStream_t)stream,d_packed,d_pack_off,d_seq_off,nreads,d_seq);
   HIPCHK(hipGetLastError());
   return CP_OK;
+}
+
+extern "C" int cp_pack_labels(const char *d_labels, const int64_t *d_seq_off, const int64_t *d_pack_off, int nreads,
+                              uint8_t *d_packed, void *stream)
+{ if (nreads < 0 || (nreads > 0 && (!d_labels || !d_seq_off || !d_pack_off || !d_packed)))
+    return set_err(CP_EINVAL,"cp_pack_labels: bad argument");
+  if (nreads == 0) return CP_OK;
+  hipLaunchKernelGGL(k_pack_labels,dim3(nreads),dim3(256),0,(hipStream_t)stream,d_labels,d_seq_off,d_pack_off,nreads,d_packed);
+  HIPCHK(hipGetLastError());
+  return CP_OK;
+}
+
+// host: the inverse of cp_pack_labels for one read (stoc of const.c:19 on the codes; the first K-1 labels are 'N')
+extern "C" int cp_unpack_labels(const uint8_t *packed, int rlen, int K, char *labels)
+{ if (rlen < 0 || K < 1 || (rlen > 0 && (!packed || !labels)))
+    return set_err(CP_EINVAL,"cp_unpack_labels: bad argument");
+  static const char stoc[4] = { 'E', 'R', 'H', 'D' };
+  const int np = K-1 < rlen ? K-1 : rlen;
+  for (int i = 0; i < np; i++) labels[i] = 'N';
+  for (int i = np; i < rlen; i++)
+    labels[i] = stoc[(packed[i >> 2] >> (6-2*(i & 3))) & 3];
+  return CP_OK;
+}
+
+// host: a read's bases as 2-bit codes in the layout cp_unpack_bases expands (Compress_Read, gene_core.c:235-254), if it
+// consists of upper-case A, C, G, T only.  Returns 1 (packed: (rlen+3)/4 bytes written) or 0 (another letter: the read
+// -- and the batch it is in -- goes to the device as characters; the context scans compare raw characters,
+// context.c:8-108, so a lower-case or ambiguous base must arrive as it is).
+extern "C" int cp_pack_bases(const char *seq, int rlen, uint8_t *packed)
+{ if (rlen < 0 || (rlen > 0 && (!seq || !packed)))
+    return set_err(CP_EINVAL,"cp_pack_bases: bad argument");
+  static const signed char code[256] = {
+#define X -1
+    X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,
+    X,0,X,1,X,X,X,2,X,X,X,X,X,X,X,X, X,X,X,X,3,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,
+    X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,
+    X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X
+#undef X
+  };
+  int bad = 0;
+  int i = 0;
+  for (; i+4 <= rlen; i += 4)
+    { const int a = code[(unsigned char)seq[i]], b = code[(unsigned char)seq[i+1]], c = code[(unsigned char)seq[i+2]], d = code[(unsigned char)seq[i+3]];
+      bad |= a | b | c | d;
+      packed[i >> 2] = (uint8_t)((a << 6) | (b << 4) | (c << 2) | d);
+    }
+  if (i < rlen)
+    { int v = 0;
+      for (int q = 0; q < 4; q++)
+        { const int a = (i+q < rlen) ? code[(unsigned char)seq[i+q]] : 0;
+          bad |= a;
+          v |= (a & 3) << (6-2*q);
+        }
+      packed[i >> 2] = (uint8_t)v;
+    }
+  return bad < 0 ? 0 : 1;
 }
 
 extern "C" int cp_seq_context(const char *d_seq, const int64_t *d_seq_off, int nreads, int64_t total_bases,

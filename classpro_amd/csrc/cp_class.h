@@ -163,9 +163,10 @@ CP_HD void cp_rel_only_r_cell(int s, int i, cp_cell *c)
 
 // New cell for target state t at interval i given its best predecessor (class_rel.c:390-499).
 // View gives the hot fields of the interval standing in for path index k: view(k) -> cp_riv.
-template <class View>
+// `prev` = the four cells of the previous interval (cp_cell, or a padded record derived from it: Cell).
+template <class View, class Cell>
 CP_HD void cp_rel_target_cell(const cp_dev_params *P, int t, int i, const cp_riv &I, int F, const int *COV,
-                              int max_s, double max_logp, const cp_cell *prev, const View &view, cp_cell *out)
+                              int max_s, double max_logp, const Cell *prev, const View &view, cp_cell *out)
 { cp_cell c;
   c.dp = max_logp;
   c.dhr = -INFINITY;

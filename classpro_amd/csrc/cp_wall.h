@@ -116,9 +116,21 @@ struct cp_perr_hybrid
     CP_HDM void   set(int pos, int e, int w, double v) { store(cell(pos,e,w),v); }
   };
 
+// E-/O-interval list (ClassPro.h:153-157 arrays): a plain array here; k_find_wall keeps the list in LDS while it is
+// short (kernels.hip: fw_evl, same member functions).  put() returns false when slot i does not exist.
+struct cp_ev_ptr
+  { cp_eintvl *p;
+    CP_HDM cp_ev_ptr(cp_eintvl *q = nullptr) : p(q) {}
+    CP_HDM int       b(int i) const { return p[i].b; }
+    CP_HDM int       e(int i) const { return p[i].e; }
+    CP_HDM double    pe(int i) const { return p[i].pe; }
+    CP_HDM cp_eintvl get(int i) const { return p[i]; }
+    CP_HDM void      put(int i, const cp_eintvl &v) { p[i] = v; }
+  };
+
 // SEQ / PROF / LF: anything indexable like the read's bases, its counts and the log-factorial table
-// (plain pointers, or the LDS-window accessors of kernels.hip).
-template <class PE, class SEQ = const char *, class PROF = const uint16_t *, class LF = const double *>
+// (plain pointers, or the LDS-window accessors of kernels.hip).  EVL: the interval lists (cp_ev_ptr or fw_evl).
+template <class PE, class SEQ = const char *, class PROF = const uint16_t *, class LF = const double *, class EVL = cp_ev_ptr>
 struct cp_read_t
   { const cp_dev_params *P;
     PROF                 prof;
@@ -129,7 +141,7 @@ struct cp_read_t
     uint8_t             *wall_s;    // flags written by the SELF pass (may alias `wall`: the bits are disjoint)
     PE                   perror;    // memo of both error types (one object: indexing an array of stores by the
                                     // error type at run time would push the whole record into scratch memory)
-    cp_eintvl           *eintvl, *ointvl;
+    EVL                  eintvl, ointvl;
     int                  ecap;
     int                  eidx, oidx;
     int                  overflow;
@@ -175,6 +187,10 @@ CP_HD double cp_logp_diff_pair(const RD *R, int i, int j)
   int cov    = pr[i-1] > pr[j] ? pr[i-1] : pr[j];
   return cp_logp_trans(R->P,i,j,n_drop,n_gain,cov);
 }
+
+// eight consecutive counts from position lo (only 2-byte aligned; gfx9 global loads take unaligned addresses)
+struct __attribute__((packed, aligned(2))) cp_u16x8 { uint16_t v[8]; };
+CP_HD cp_u16x8 cp_load_u16x8(const uint16_t *prof, int lo) { return *reinterpret_cast<const cp_u16x8 *>(prof+lo); }
 
 // wall.c:324-329
 CP_HD bool cp_cthres_ng(int e, int cin, int ct)
@@ -321,31 +337,71 @@ CP_HD void cp_wall_candidate_live(RD *R, int i, int e, const cp_wall_pre &pre, c
     }
 
   CP_LT(2);
-  // high-complexity partners (wall.c:380-404 / 469-493)
+  // high-complexity partners (wall.c:380-404 / 469-493).  The six partners sit at consecutive positions, so their
+  // seven counts come from ONE 16-byte load where that stays inside the read, and each partner's two look-ups (its
+  // P(error in), and for OTHERS the Skellam term of logp_diff_pair) are independent of the other partners': all of
+  // them are issued before the first is used (first pass), then the reference's loop picks the first strict maximum
+  // (second pass).  One dependent chain of six round trips became two.
+  int    hcj[CP_MAX_N_HC+1], hcin[CP_MAX_N_HC+1], hcout[CP_MAX_N_HC+1];
+  bool   hok[CP_MAX_N_HC+1];
+  double hpe[CP_MAX_N_HC+1], hdiff[CP_MAX_N_HC+1];
+  int    cw[CP_MAX_N_HC+2];                               // counts at j0-1 .. j0+5 (right) / j0-6 .. j0 (left), j0 = the n = 0 partner
+  const int j0 = right ? (i+K-1) : (i-K+1);
+  const int lo8 = right ? j0-1 : j0-(CP_MAX_N_HC+1);
+  const bool wide = lo8 >= 0 && lo8+8 <= plen;
+  if (wide)
+    { const cp_u16x8 x = cp_load_u16x8(pr,lo8);
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+      for (int q = 0; q < CP_MAX_N_HC+2; q++) cw[q] = x.v[q];
+    }
+  const bool pass_i = !(cout < CMAX && cp_cthres_ng(e,cin,P->cthres[CP_HP][1][cout][CP_FINAL][e]));
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+  for (n = 0; n <= CP_MAX_N_HC; n++)
+    { j = right ? j0+n : j0-n;
+      hcj[n] = j; hok[n] = false; hpe[n] = 0.; hdiff[n] = 0.;
+      if (right ? (j >= plen) : (j <= 0))
+        { hcj[n] = -1; continue; }                        // the reference's loop ends here
+      int a, b;                                           // counts at j-1, j
+      if (wide) { a = cw[right ? n : CP_MAX_N_HC-n]; b = cw[right ? n+1 : CP_MAX_N_HC+1-n]; }
+      else      { a = pr[j-1]; b = pr[j]; }
+      if (right) { cin_j = a; cout_j = b; }
+      else       { cout_j = a; cin_j = b; }
+      hcin[n] = cin_j; hcout[n] = cout_j;
+      if (!(cin_j <= cout_j) || !pass_i
+          || (cout_j < CMAX && cp_cthres_ng(e,cin_j,P->cthres[CP_HP][1][cout_j][CP_FINAL][e])))
+        continue;
+      hok[n] = true;
+      if (e == CP_OTHERS)                                 // logp_diff_pair (wall.c:317-322) with the counts already in hand
+        { const int pim1 = pr[i-1], pi = pr[i];
+          const int n_drop = right ? pim1-pi : a-b;       // (p[i-1]-p[i]) of the DROP position
+          const int n_gain = right ? b-a : pi-pim1;       // (p[j]-p[j-1]) of the GAIN position
+          const int cv = right ? (pim1 > b ? pim1 : b) : (a > pi ? a : pi);
+          hdiff[n] = cp_logp_trans(P,right ? i : j,right ? j : i,n_drop,n_gain,cv);
+        }
+      hpe[n] = cp_p_errorin_tl(P,e,CP_HP,1,cout_j,cin_j);
+    }
   bool   have_pe_i = false;
   double pe_i = 0., max_pe = CP_NEG_INF;
   int    max_j = -1;
+#ifdef __HIPCC__
+#pragma unroll
+#endif
   for (n = 0; n <= CP_MAX_N_HC; n++)
-    { j = right ? (i+K-1)+n : (i-K+1)-n;
-      if (right ? (j >= plen) : (j <= 0))
-        break;
-      if (right) { cin_j = pr[j-1]; cout_j = pr[j]; }
-      else       { cout_j = pr[j-1]; cin_j = pr[j]; }
-      if (!(cin_j <= cout_j))
-        continue;
-      if ((cout < CMAX && cp_cthres_ng(e,cin,P->cthres[CP_HP][1][cout][CP_FINAL][e]))
-          || (cout_j < CMAX && cp_cthres_ng(e,cin_j,P->cthres[CP_HP][1][cout_j][CP_FINAL][e])))
-        continue;
-      if (e == CP_OTHERS && (right ? cp_logp_diff_pair(R,i,j) : cp_logp_diff_pair(R,j,i)) < CP_THRES_DIFF_EO)
+    { if (hcj[n] < 0) break;
+      if (!hok[n]) continue;
+      if (e == CP_OTHERS && hdiff[n] < CP_THRES_DIFF_EO)
         continue;
       if (!have_pe_i)                                   // same arguments every time (wall.c:398)
         { pe_i = cp_p_errorin_tl(P,e,CP_HP,1,cout,cin);      // HC_ERATE = pe[HP][1], wall.c:180
           have_pe_i = true;
         }
-      double pe_j = cp_p_errorin_tl(P,e,CP_HP,1,cout_j,cin_j);
-      double pe = pe_i * pe_j;
+      double pe = pe_i * hpe[n];
       if (max_pe < pe)
-        { max_j  = j;
+        { max_j  = hcj[n];
           max_pe = pe;
         }
     }
@@ -452,7 +508,7 @@ CP_HD void cp_wall_candidate_replay(RD *R, int i, int e, int wtype, const cp_can
             { R->wall_s[I.b] |= (CP_W_WALL_S|CP_W_PAIRED_S);
               R->wall_s[I.e] |= (CP_W_WALL_S|CP_W_PAIRED_S);
             }
-          if (R->eidx < R->ecap) R->eintvl[R->eidx++] = I;
+          if (R->eidx < R->ecap) R->eintvl.put(R->eidx++,I);
           else R->overflow = 1;
         }
     }
@@ -467,7 +523,7 @@ CP_HD void cp_wall_candidate_replay(RD *R, int i, int e, int wtype, const cp_can
           if (R->spec_wallnow && j > i) R->wall[j] = CP_W_PAIRED_O;    // not reached yet: the reference has 0 there
           else                          R->wall[j] |= CP_W_PAIRED_O;
           if (win) cp_win_mark(R,j);
-          if (R->oidx < R->ecap) R->ointvl[R->oidx++] = I;
+          if (R->oidx < R->ecap) R->ointvl.put(R->oidx++,I);
           else R->overflow = 1;
           return;
         }
@@ -499,15 +555,18 @@ CP_HD bool cp_eintvl_before(const cp_eintvl &a, int ia, const cp_eintvl &b, int 
 }
 
 // wall.c:530-546
-CP_HD int cp_bs_eintvl(const cp_eintvl *v, int l, int r, int b, int e)
+template <class EVL>
+CP_HD int cp_bs_eintvl(const EVL &v, int l, int r, int b, int e)
 { while (l <= r)
     { int m = (l+r)/2;
-      if (v[m].b == b)
-        { if (v[m].e == e) return m;
-          else if (e > v[m].e) l = m+1;
+      const int vb = v.b(m);
+      if (vb == b)
+        { const int ve = v.e(m);
+          if (ve == e) return m;
+          else if (e > ve) l = m+1;
           else r = m-1;
         }
-      else if (b > v[m].b) l = m+1;
+      else if (b > vb) l = m+1;
       else r = m-1;
     }
   return -1;
@@ -538,7 +597,8 @@ CP_HD void cp_wall_mult(RD *R, int i, int NS, int *midx)
 { uint8_t *wall = R->wall;
   const uint8_t *wall_s = R->wall_s;
   const int plen = R->plen;
-  cp_eintvl *ev = R->eintvl;
+  auto &ev = R->eintvl;
+  auto ev_put = [&](int k, int b, int e, double p) { cp_eintvl x; x.b = b; x.e = e; x.pe = p; ev.put(k,x); };
   double pe, pe_i, pe_j;
   for (int w = CP_DROP; w <= CP_GAIN; w++)
     { if ((pe_i = CP_PERR(R,i,CP_SELF,w)) < CP_PE_THRES_FINAL)
@@ -550,7 +610,7 @@ CP_HD void cp_wall_mult(RD *R, int i, int NS, int *midx)
                 { if ((pe = pe_i * pe_i) < CP_PE_THRES_FINAL)
                     continue;
                   if (*midx >= R->ecap) { R->overflow = 1; return; }
-                  ev[*midx].b = i; ev[*midx].e = plen; ev[*midx].pe = pe;
+                  ev_put(*midx,i,plen,pe);
                   wall[i] |= CP_W_PAIRED_M;
                   (*midx)++;
                   if (*midx >= plen) { R->overflow = 8; return; }        // the reference exits here: "# E-intvls >= plen" (wall.c:783-788)
@@ -561,7 +621,7 @@ CP_HD void cp_wall_mult(RD *R, int i, int NS, int *midx)
                 { pe_j = CP_PERR(R,j,CP_SELF,CP_GAIN);
                   if ((pe = pe_i * pe_j) >= CP_PE_THRES_FINAL)
                     { if (*midx >= R->ecap) { R->overflow = 1; return; }
-                      ev[*midx].b = i; ev[*midx].e = j; ev[*midx].pe = pe;
+                      ev_put(*midx,i,j,pe);
                       wall[i] |= CP_W_PAIRED_M;
                       wall[j] |= CP_W_PAIRED_M;
                       (*midx)++;
@@ -579,7 +639,7 @@ CP_HD void cp_wall_mult(RD *R, int i, int NS, int *midx)
                 { if ((pe = pe_i * pe_i) < CP_PE_THRES_FINAL)
                     continue;
                   if (*midx >= R->ecap) { R->overflow = 1; return; }
-                  ev[*midx].b = 0; ev[*midx].e = i; ev[*midx].pe = pe;
+                  ev_put(*midx,0,i,pe);
                   wall[i] |= CP_W_PAIRED_M;
                   (*midx)++;
                   if (*midx >= plen) { R->overflow = 8; return; }        // the reference exits here: "# E-intvls >= plen" (wall.c:783-788)
@@ -590,7 +650,7 @@ CP_HD void cp_wall_mult(RD *R, int i, int NS, int *midx)
                 { pe_j = CP_PERR(R,j,CP_SELF,CP_DROP);
                   if ((pe = pe_i * pe_j) >= CP_PE_THRES_FINAL)
                     { if (*midx >= R->ecap) { R->overflow = 1; return; }
-                      ev[*midx].b = j; ev[*midx].e = i; ev[*midx].pe = pe;
+                      ev_put(*midx,j,i,pe);
                       wall[i] |= CP_W_PAIRED_M;
                       wall[j] |= CP_W_PAIRED_M;
                       (*midx)++;
@@ -609,16 +669,18 @@ CP_HD void cp_wall_mult(RD *R, int i, int NS, int *midx)
 // into the entries it has just appended (which are not in sorted position); reproduced literally.
 template <class RD>
 CP_HD int cp_merge_eintvl(RD *R, int NS)
-{ cp_eintvl *ev = R->eintvl;
+{ auto &ev = R->eintvl;
   int i = 0, j;
   while (i < NS-1)
-    { int    max_e  = ev[i].e;
-      double max_pe = ev[i].pe;
+    { int    max_e  = ev.e(i);
+      double max_pe = ev.pe(i);
       j = i;
       while (j < NS-1)
-        { if (ev[j+1].b <= ev[j].e)
-            { if (max_e < ev[j+1].e) max_e = ev[j+1].e;
-              if (!(max_pe > ev[j+1].pe)) max_pe = ev[j+1].pe;
+        { if (ev.b(j+1) <= ev.e(j))
+            { const int e1 = ev.e(j+1);
+              const double p1 = ev.pe(j+1);
+              if (max_e < e1) max_e = e1;
+              if (!(max_pe > p1)) max_pe = p1;
               j++;
             }
           else
@@ -626,7 +688,8 @@ CP_HD int cp_merge_eintvl(RD *R, int NS)
         }
       if (i < j)
         { if (NS >= R->ecap) { R->overflow = 1; return NS; }
-          ev[NS].b = ev[i].b; ev[NS].e = max_e; ev[NS].pe = max_pe;
+          cp_eintvl x; x.b = ev.b(i); x.e = max_e; x.pe = max_pe;
+          ev.put(NS,x);
           NS++;
           if (NS >= R->plen) { R->overflow = 8; return NS; }      // the reference exits here too ("# E-intvls >= plen", wall.c:900-905)
         }
@@ -648,7 +711,7 @@ CP_HD void cp_make_interval(const RD *R, int NS, int b, int e, cp_intvl *out)
   out->is_rel = 0;
   out->asgn = CP_N_STATE;
   for (int k = 0; k < 6; k++) out->_pad[k] = 0;
-  out->pe = (idx != -1) ? log(R->eintvl[idx].pe) : CP_NEG_INF;
+  out->pe = (idx != -1) ? log(R->eintvl.pe(idx)) : CP_NEG_INF;
   double d = CP_PERR(R,b,CP_OTHERS,CP_DROP), g = CP_PERR(R,b,CP_OTHERS,CP_GAIN);
   double peob = d > g ? d : g;
   d = CP_PERR(R,e,CP_OTHERS,CP_DROP); g = CP_PERR(R,e,CP_OTHERS,CP_GAIN);
@@ -660,7 +723,6 @@ CP_HD void cp_make_interval(const RD *R, int NS, int b, int e, cp_intvl *out)
 // Sum over i in [lo,hi) of the upward (sgn = +1) or downward (sgn = -1) steps prof[i+1]-prof[i] of a count
 // profile, eight counts per load where that stays inside the read's plen counts (the addresses are only
 // 2-byte aligned; gfx9 global loads take unaligned addresses).  Same terms as the loops of wall.c:972-1001.
-struct __attribute__((packed, aligned(2))) cp_u16x8 { uint16_t v[8]; };
 CP_HD int cp_sum_steps(const uint16_t *prof, int lo, int hi, int plen, int sgn)
 { int acc = 0, i = lo;
   if (lo >= hi) return 0;

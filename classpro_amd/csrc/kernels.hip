@@ -12,7 +12,7 @@
 // Kernels:
 //   k_scan_candidates   streaming pass over the profile (the HBM-roofline kernel): wall.c:590-607
 //   k_count_caps        per-read candidate count -> scratch capacities
-//   k_prefix_caps       exclusive prefix sums of the capacities (single block)
+//   k_prefix_caps_mb    exclusive prefix sums of the capacities (one block per 1024 reads, single pass with look-back)
 //   k_wall_tasks        one wave per read: the read-only part of the candidate walk, wall.c:590-707 (lists + task results to HBM)
 //   k_find_wall         one wave per read: the walk's in-order replay and everything after it, wall.c:639-958
 //   k_find_rel          one wave per read, one lane per interval: wall.c:960-1051
@@ -28,6 +28,7 @@
 // No MFMA anywhere: the path has no dense contraction.  Built with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "cp_wall.h"
 #include "cp_class.h"
 #include "cp_seed.h"
@@ -217,47 +218,86 @@ k_count_caps(const uint64_t *__restrict__ bm, const int64_t *__restrict__ prof_o
     }
 }
 
-// exclusive prefix sums of three int64 arrays, in place, totals appended at [n]; single block.
-// exclusive prefix sum of one value per thread over a 1024-thread block (16 waves): wave scans by shuffle,
-// the 16 wave totals scanned by the first wave; *total gets the block sum.  `tmp` holds 16 values.
+// Exclusive prefix sum of one value per thread over a 256-thread block (4 waves): wave scans by shuffle, the 4 wave
+// totals combined by every thread; *total gets the block sum.  `tmp` holds 4 values.
 template <class T>
-__device__ __forceinline__ T block_scan_excl_1024(T x, T *tmp, T *total)
+__device__ __forceinline__ T block_scan_excl_256(T x, T *tmp, T *total)
 { const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   T inc = x;
   for (int o = 1; o < WAVE; o <<= 1)
     { T y = __shfl_up(inc,o); if (lane >= o) inc += y; }
+  __syncthreads();                                        // (tmp may still be read from an earlier call)
   if (lane == WAVE-1) tmp[wv] = inc;
   __syncthreads();
-  if (wv == 0)
-    { T w = (lane < 16) ? tmp[lane] : (T)0, winc = w;
-      for (int o = 1; o < 16; o <<= 1)
-        { T y = __shfl_up(winc,o); if (lane >= o) winc += y; }
-      if (lane < 16) tmp[lane] = winc-w;                  // exclusive offsets of the waves
-      if (lane == 15) *total = winc;
-    }
-  __syncthreads();
-  return tmp[wv]+inc-x;
+  T base = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++) { const T v = tmp[w]; if (w < wv) base += v; all += v; }
+  *total = all;
+  return base+inc-x;
 }
 
-__global__ void __launch_bounds__(1024)
-k_prefix_caps(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__restrict__ c, int n, int64_t *__restrict__ totals)
-{ __shared__ int64_t tmp[16], tot;                        // totals (may be null): the three sums side by side, one D2H copy
-  const int t = threadIdx.x;
+// Exclusive prefix sums of three int64 arrays, in place, totals appended at [n]; one 256-thread block per 1024 values,
+// four consecutive values per thread (a single 1024-thread block doing all of it sat, for 0.2-2.4 ms, in front of the one
+// host round trip of every sub-batch, starved by the other stream's 50 000-block kernels -- and so did 1024-thread
+// blocks of a multi-block form: 16 free wave slots on one CU are rare beside those kernels; profiles/r03_timeline_*.txt).
+// Single pass: a block scans its tile, publishes its three tile sums in `state` (tagged with this launch's epoch, so the
+// array is never cleared) and then looks back: lane j of its first wave waits for and reads tile j's sums, 64 tiles
+// per round, and a wave reduction gives the block its offset.  A tile only waits for tiles with smaller block ids, which
+// the dispatcher started before it.  The last tile writes the totals.
+#define SCAN_TILE 1024
+struct cp_scan_state { int64_t s[3]; int32_t epoch; int32_t pad_; };
+__global__ void __launch_bounds__(256)
+k_prefix_caps_mb(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__restrict__ c, int n, int64_t *__restrict__ totals,
+                 cp_scan_state *__restrict__ state, int epoch)
+{ __shared__ int64_t tmp[4], pre[3];
+  const int t = threadIdx.x, tile = blockIdx.x, i0 = tile*SCAN_TILE+4*t;
   int64_t *arr[3] = { a, b, c };
+  int64_t x[3][4], off[3], sum[3];
 #pragma unroll
-  for (int q = 0; q < 3; q++)                             // tiles of 1024 consecutive values: coalesced loads and stores
-    { int64_t *v = arr[q];
-      int64_t carry = 0;
-      for (int base = 0; base < n; base += 1024)
-        { const int i = base+t;
-          const int64_t x = (i < n) ? v[i] : 0;
-          const int64_t off = block_scan_excl_1024<int64_t>(x,tmp,&tot);
-          if (i < n) v[i] = carry+off;
-          carry += tot;
-          __syncthreads();
+  for (int q = 0; q < 3; q++)
+    { int64_t s4 = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { x[q][k] = (i0+k < n) ? arr[q][i0+k] : 0; s4 += x[q][k]; }
+      int64_t tot;
+      off[q] = block_scan_excl_256<int64_t>(s4,tmp,&tot);
+      sum[q] = tot;
+    }
+  if (t == 0)
+    { state[tile].s[0] = sum[0]; state[tile].s[1] = sum[1]; state[tile].s[2] = sum[2];
+      __threadfence();
+      __hip_atomic_store(&state[tile].epoch,epoch,__ATOMIC_RELEASE,__HIP_MEMORY_SCOPE_AGENT);
+    }
+  if (t < WAVE)                                           // look back, 64 tiles per round
+    { int64_t p0 = 0, p1 = 0, p2 = 0;
+      for (int base = 0; base < tile; base += WAVE)
+        { const int j = base+t;
+          int64_t v0 = 0, v1 = 0, v2 = 0;
+          if (j < tile)
+            { while (__hip_atomic_load(&state[j].epoch,__ATOMIC_ACQUIRE,__HIP_MEMORY_SCOPE_AGENT) != epoch)
+                __builtin_amdgcn_s_sleep(1);
+              v0 = __hip_atomic_load(&state[j].s[0],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
+              v1 = __hip_atomic_load(&state[j].s[1],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
+              v2 = __hip_atomic_load(&state[j].s[2],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
+            }
+          for (int o = 32; o > 0; o >>= 1)
+            { v0 += __shfl_xor(v0,o); v1 += __shfl_xor(v1,o); v2 += __shfl_xor(v2,o); }
+          p0 += v0; p1 += v1; p2 += v2;
         }
-      if (t == 0) { v[n] = carry; if (totals) totals[q] = carry; }
-      __syncthreads();
+      if (t == 0) { pre[0] = p0; pre[1] = p1; pre[2] = p2; }
+    }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+    { int64_t run = pre[q]+off[q];
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        { if (i0+k < n) arr[q][i0+k] = run;
+          run += x[q][k];
+        }
+      if (tile == (int)gridDim.x-1 && t == 0)
+        { arr[q][n] = pre[q]+sum[q];
+          if (totals) totals[q] = pre[q]+sum[q];
+        }
     }
 }
 
@@ -265,62 +305,152 @@ k_prefix_caps(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__restr
 //  k_order_by_work: perm[] = read ids sorted by a work key (candidates / intervals / reliable
 //  intervals), largest first.  The per-read kernels are latency-bound chains whose length grows with
 //  the key: launching long reads first removes the tail, and reads that share a wave (rel: 2,
-//  unrel: 8) get similar trip counts.  Counting sort in one block: LDS histogram, suffix sums, scatter
-//  (order inside a bin is arbitrary; reads are independent, so results do not depend on it).
+//  unrel: 8) get similar trip counts.  Counting sort: histogram, suffix sums, scatter (order inside a
+//  bin is arbitrary; reads are independent, so results do not depend on it).
 // ---------------------------------------------------------------------------------------------
 #define ORDER_BINS 1024
-__global__ void __launch_bounds__(1024)
-k_order_by_work(const int32_t *__restrict__ key, int n, int shift, int32_t *__restrict__ perm)
+#define ORDER_TILE 1024
+// One 256-thread block per 1024 reads (a single block took 0.2-0.9 ms in front of a 50 000-block kernel, three times
+// per sub-batch): k_order_hist adds every block's LDS histogram to the global one; k_order_scatter turns the global
+// histogram into bin starts (every block for itself: 1024 values), reserves, per block and non-empty bin, a range of
+// the bin with ONE global atomic, and places its reads there.  `ghist` and `gcur` (ORDER_BINS ints each, adjacent) are
+// zero on entry: the launcher clears them.
+__global__ void __launch_bounds__(256)
+k_order_hist(const int32_t *__restrict__ key, int n, int shift, int32_t *__restrict__ ghist)
 { __shared__ int hist[ORDER_BINS];
-  __shared__ int start[ORDER_BINS];
-  const int t = threadIdx.x;
-  hist[t] = 0;
+  const int t = threadIdx.x, i0 = blockIdx.x*ORDER_TILE;
+  for (int k = t; k < ORDER_BINS; k += 256) hist[k] = 0;
   __syncthreads();
-  for (int i = t; i < n; i += 1024)
-    { int b = key[i] >> shift;
+  for (int i = i0+t; i < i0+ORDER_TILE && i < n; i += 256)
+    { const int b = key[i] >> shift;
       atomicAdd(&hist[b < ORDER_BINS ? b : ORDER_BINS-1],1);
     }
   __syncthreads();
-  { __shared__ int tmp[16], tot;                           // descending keys: bin b starts after all larger bins
-    const int rb = ORDER_BINS-1-t;                         // thread t scans bin 1023-t
-    const int off = block_scan_excl_1024<int>(hist[rb],tmp,&tot);
-    start[rb] = off;
+  for (int k = t; k < ORDER_BINS; k += 256)
+    if (hist[k]) atomicAdd(&ghist[k],hist[k]);
+}
+
+__global__ void __launch_bounds__(256)
+k_order_scatter(const int32_t *__restrict__ key, int n, int shift, const int32_t *__restrict__ ghist, int32_t *__restrict__ gcur,
+                int32_t *__restrict__ perm)
+{ __shared__ int hist[ORDER_BINS];                        // this block's count per bin, then its cursor inside the bin
+  __shared__ int start[ORDER_BINS];
+  __shared__ int tmp[4];
+  const int t = threadIdx.x, i0 = blockIdx.x*ORDER_TILE;
+  for (int k = t; k < ORDER_BINS; k += 256) hist[k] = 0;
+  { // descending keys: bin b starts after all larger bins.  Thread t owns the four bins 1023-4t .. 1020-4t
+    int g4[4], s4 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { g4[k] = ghist[ORDER_BINS-1-(4*t+k)]; s4 += g4[k]; }
+    int tot;
+    int run = block_scan_excl_256<int>(s4,tmp,&tot);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { start[ORDER_BINS-1-(4*t+k)] = run; run += g4[k]; }
   }
   __syncthreads();
-  for (int i = t; i < n; i += 1024)
-    { int b = key[i] >> shift;
-      perm[atomicAdd(&start[b < ORDER_BINS ? b : ORDER_BINS-1],1)] = i;
+  int b[4], r[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    { const int i = i0+t+256*k;
+      b[k] = -1; r[k] = 0;
+      if (i < n && i < i0+ORDER_TILE)
+        { int q = key[i] >> shift;
+          if (q >= ORDER_BINS) q = ORDER_BINS-1;
+          b[k] = q;
+          r[k] = atomicAdd(&hist[q],1);                   // rank inside this block's share of the bin
+        }
     }
+  __syncthreads();
+  for (int k = t; k < ORDER_BINS; k += 256)
+    if (hist[k]) start[k] += atomicAdd(&gcur[k],hist[k]); // this block's range of bin k
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (b[k] >= 0) perm[start[b[k]]+r[k]] = i0+t+256*k;
 }
 
 // ---------------------------------------------------------------------------------------------
-//  Stable rank sort of E-intervals by (b,e) across the lanes of a wave (wall.c:519-528,734,875,910).
+//  The E-interval list of k_find_wall.  Every phase after the candidate walk -- sort + dedupe, the multi-error search,
+//  the merge, the interval records -- is a chain of dependent reads of this list (binary searches, rank sorts, a
+//  sequential merge): in HBM each of them is a round trip of a microsecond or more, and a wave waiting on it holds its
+//  registers and LDS all the while (what the pipeline as a whole runs out of: profiles/r03_*).  A read has a few dozen
+//  E-intervals, so the list lives in the wave's LDS (FW_EVL slots) and nothing of it goes to HBM at all; a list that
+//  outgrows the slots moves to the read's HBM array (capacity ecap) and the same code goes on there.
 // ---------------------------------------------------------------------------------------------
-__device__ void wave_sort_eintvl(cp_eintvl *v, int n, cp_eintvl *tmp)
-{ if (n < 2) return;
+#ifndef FW_EVL
+#define FW_EVL 96
+#endif
+struct fw_evl
+  { cp_eintvl *g;                                       // the read's array in HBM
+    CP_LDS_PTR(cp_eintvl) l;                            // the wave's FW_EVL on-chip slots (null: HBM only)
+    int big;                                            // the list is in g[]
+    __device__ __forceinline__ fw_evl(cp_eintvl *q = nullptr) : g(q), l(nullptr), big(1) {}
+    __device__ __forceinline__ int       b(int i) const  { return big ? g[i].b : l[i].b; }
+    __device__ __forceinline__ int       e(int i) const  { return big ? g[i].e : l[i].e; }
+    __device__ __forceinline__ double    pe(int i) const { return big ? g[i].pe : l[i].pe; }
+    __device__ __forceinline__ cp_eintvl get(int i) const { return big ? g[i] : l[i]; }
+    // one lane's append (the walk's replay, the merge): the list moves to HBM when slot i is beyond the on-chip ones
+    __device__ __forceinline__ void put(int i, const cp_eintvl &v)
+    { if (!big && i >= FW_EVL)
+        { for (int k = 0; k < FW_EVL; k++) g[k] = l[k];
+          big = 1;
+        }
+      if (big) g[i] = v; else l[i] = v;
+    }
+    // all lanes together, before slot i is written by one of them
+    __device__ __forceinline__ void wave_grow(int i)
+    { if (!big && i >= FW_EVL)
+        { __syncthreads();
+          for (int k = lane_id(); k < FW_EVL; k += WAVE) g[k] = l[k];
+          big = 1;
+          __syncthreads();
+        }
+    }
+  };
+
+// Stable rank sort by (b,e) across the lanes of a wave (wall.c:519-528,734,875,910), optionally keeping only the first
+// of each run of equal (b,e) (wall.c:548-568).  On-chip list (n <= FW_EVL <= 128): a lane holds up to two elements in
+// registers, ranks them against the whole list (broadcast reads) and writes them back in place.  Returns the new length.
+__device__ int wave_sort_ev_lds(CP_LDS_PTR(cp_eintvl) v, int n, bool dedupe)
+{ static_assert(FW_EVL <= 2*WAVE,"two elements per lane");
+  if (n < 2) return n;
   const int lane = lane_id();
-  for (int k = lane; k < n; k += WAVE)
-    { const cp_eintvl x = v[k];
-      int rank = 0;
-      for (int m = 0; m < n; m++)
-        rank += cp_eintvl_before(v[m],m,x,k) ? 1 : 0;
-      tmp[rank] = x;
+  const uint64_t lt = (1ull << lane)-1;
+  cp_eintvl x0 = { 0, 0, 0. }, x1 = { 0, 0, 0. };
+  if (lane < n) x0 = v[lane];
+  if (lane+WAVE < n) x1 = v[lane+WAVE];
+  int r0 = 0, r1 = 0;
+  for (int m = 0; m < n; m++)
+    { const cp_eintvl y = v[m];
+      r0 += cp_eintvl_before(y,m,x0,lane) ? 1 : 0;
+      r1 += cp_eintvl_before(y,m,x1,lane+WAVE) ? 1 : 0;
     }
   wave_sync();
-  for (int k = lane; k < n; k += WAVE)
-    v[k] = tmp[k];
+  if (lane < n) v[r0] = x0;
+  if (lane+WAVE < n) v[r1] = x1;
   wave_sync();
+  if (!dedupe) return n;
+  bool k0 = false, k1 = false;
+  if (lane < n)
+    { x0 = v[lane];
+      k0 = (lane == 0);
+      if (lane > 0) { const cp_eintvl p = v[lane-1]; k0 = !(p.b == x0.b && p.e == x0.e); }
+    }
+  if (lane+WAVE < n)
+    { x1 = v[lane+WAVE];
+      const cp_eintvl p = v[lane+WAVE-1];
+      k1 = !(p.b == x1.b && p.e == x1.e);
+    }
+  const uint64_t m0 = __ballot(k0), m1 = __ballot(k1);
+  wave_sync();
+  if (k0) v[__popcll(m0 & lt)] = x0;
+  if (k1) v[__popcll(m0)+__popcll(m1 & lt)] = x1;
+  wave_sync();
+  return __popcll(m0)+__popcll(m1);
 }
 
-// clear / set a flag over the positions [b,e) of the wall array with the lanes of the wave
-__device__ __forceinline__ void wave_wall_and(uint8_t *wall, int b, int e, uint8_t mask)
-{ for (int j = b+lane_id(); j < e; j += WAVE) wall[j] &= mask; }
-__device__ __forceinline__ void wave_wall_or(uint8_t *wall, int b, int e, uint8_t mask)
-{ for (int j = b+lane_id(); j < e; j += WAVE) wall[j] |= mask; }
-
-// sort by (b,e) and keep the first of each run of equal (b,e) (wall.c:548-568, 734): rank sort into tmp,
-// then an ordered compaction back into v.  Returns the new length.
-__device__ int wave_sort_dedupe_eintvl(cp_eintvl *v, int n, cp_eintvl *tmp)
+// the same on an HBM list: rank sort into tmp, then a copy / an ordered compaction back into v
+__device__ int wave_sort_ev_hbm(cp_eintvl *v, int n, cp_eintvl *tmp, bool dedupe)
 { if (n < 2) return n;
   const int lane = lane_id();
   for (int k = lane; k < n; k += WAVE)
@@ -338,7 +468,7 @@ __device__ int wave_sort_dedupe_eintvl(cp_eintvl *v, int n, cp_eintvl *tmp)
       cp_eintvl x = { 0, 0, 0. };
       if (k < n)
         { x = tmp[k];
-          keep = (k == 0) || !(tmp[k-1].b == x.b && tmp[k-1].e == x.e);
+          keep = !dedupe || (k == 0) || !(tmp[k-1].b == x.b && tmp[k-1].e == x.e);
         }
       const uint64_t m = __ballot(keep);
       if (keep) v[out+__popcll(m & ((1ull << lane)-1))] = x;
@@ -348,18 +478,21 @@ __device__ int wave_sort_dedupe_eintvl(cp_eintvl *v, int n, cp_eintvl *tmp)
   return out;
 }
 
+__device__ __forceinline__ int wave_sort_ev(fw_evl &ev, int n, cp_eintvl *tmp, bool dedupe)
+{ return ev.big ? wave_sort_ev_hbm(ev.g,n,tmp,dedupe) : wave_sort_ev_lds(ev.l,n,dedupe); }
+
 // wall.c:722-731 / 868-872: clear WALL_O at every position strictly inside one of the E-intervals ev[lo..hi).
 // OTHERS walls only exist at candidate positions, so the lanes test the candidates instead of sweeping
-// the flag array once per interval; the interval ends are staged in LDS (sbuf, 2*scap ints) when they fit.
-__device__ void wave_unwall_inside(uint8_t *wall, const int32_t *clist, int n_c, const cp_eintvl *ev, int lo, int hi,
+// the flag array once per interval (an HBM list: the interval ends are staged in sbuf, 2*scap ints, when they fit).
+__device__ void wave_unwall_inside(uint8_t *wall, const int32_t *clist, int n_c, const fw_evl &ev, int lo, int hi,
                                    int *sbuf, int scap)
 { const int lane = lane_id();
   const int n = hi-lo;
   if (n <= 0) return;
-  const bool staged = n <= scap;
+  const bool staged = ev.big && n <= scap;
   if (staged)
     { for (int k = lane; k < n; k += WAVE)
-        { sbuf[2*k] = ev[lo+k].b; sbuf[2*k+1] = ev[lo+k].e; }
+        { sbuf[2*k] = ev.g[lo+k].b; sbuf[2*k+1] = ev.g[lo+k].e; }
       wave_sync();
     }
   for (int q = lane; q < n_c; q += WAVE)
@@ -370,7 +503,7 @@ __device__ void wave_unwall_inside(uint8_t *wall, const int32_t *clist, int n_c,
           in = (sbuf[2*k] < i && i < sbuf[2*k+1]);
       else
         for (int k = lo; k < hi && !in; k++)
-          in = (ev[k].b < i && i < ev[k].e);
+          in = (ev.b(k) < i && i < ev.e(k));
       if (in)
         { const uint8_t f = wall[i];
           if (f & CP_W_WALL_O) wall[i] = f & (uint8_t)~CP_W_WALL_O;
@@ -390,7 +523,7 @@ __device__ void wave_wall_mult(RD *R, int i, int NS, int *midx)
   uint8_t *wall = R->wall;
   const uint8_t *wall_s = R->wall_s;
   const int plen = R->plen;
-  cp_eintvl *ev = R->eintvl;
+  fw_evl &ev = R->eintvl;
   for (int w = CP_DROP; w <= CP_GAIN; w++)
     { const double pe_i = CP_PERR(R,i,CP_SELF,w);
       if (pe_i < CP_PE_THRES_FINAL)
@@ -417,8 +550,10 @@ __device__ void wave_wall_mult(RD *R, int i, int NS, int *midx)
                   if (pe < CP_PE_THRES_FINAL)
                     continue;
                   if (*midx >= R->ecap) { R->overflow = 1; return; }
+                  ev.wave_grow(*midx);
                   if (lane == 0)
-                    { ev[*midx].b = right ? i : 0; ev[*midx].e = right ? plen : i; ev[*midx].pe = pe;
+                    { cp_eintvl x; x.b = right ? i : 0; x.e = right ? plen : i; x.pe = pe;
+                      ev.put(*midx,x);
                       wall[i] |= CP_W_PAIRED_M;
                     }
                   (*midx)++;
@@ -431,8 +566,10 @@ __device__ void wave_wall_mult(RD *R, int i, int NS, int *midx)
                   const double pe = pe_i * pe_j;
                   if (pe >= CP_PE_THRES_FINAL)
                     { if (*midx >= R->ecap) { R->overflow = 1; return; }
+                      ev.wave_grow(*midx);
                       if (lane == 0)
-                        { ev[*midx].b = right ? i : jj; ev[*midx].e = right ? jj : i; ev[*midx].pe = pe;
+                        { cp_eintvl x; x.b = right ? i : jj; x.e = right ? jj : i; x.pe = pe;
+                          ev.put(*midx,x);
                           wall[i] |= CP_W_PAIRED_M;
                           wall[jj] |= CP_W_PAIRED_M;
                         }
@@ -528,7 +665,7 @@ __device__ __forceinline__ void fr_seq_win_load(cp_seq_lwin &sq, char *row, int 
 }
 
 #ifndef FW_WAVES_PER_EU
-#define FW_WAVES_PER_EU 5
+#define FW_WAVES_PER_EU 4
 #endif
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FW_WAVES_PER_EU)))
 k_wall_tasks(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, const int64_t *__restrict__ seq_off,
@@ -636,7 +773,7 @@ k_wall_tasks(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, 
 }
 
 #ifndef FW2_WAVES_PER_EU
-#define FW2_WAVES_PER_EU 7
+#define FW2_WAVES_PER_EU 6        // (LDS, 7.4 KB per wave with the on-chip interval list, allows 5.5)
 #endif
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FW2_WAVES_PER_EU)))
 k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, const int64_t *__restrict__ seq_off,
@@ -657,7 +794,8 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   constexpr int LCAP0 = 256, LCAP1 = 64;                 // on-chip memo slots of the SELF / OTHERS pass
   __shared__ int32_t s_mkey[LCAP0+LCAP1];
   __shared__ double  s_mval[LCAP0+LCAP1];
-  cp_read_t<cp_perr_hybrid> R;
+  __shared__ cp_eintvl s_ev[FW_EVL];                     // the E-interval list while it is short (fw_evl)
+  cp_read_t<cp_perr_hybrid,const char *,const uint16_t *,const double *,fw_evl> R;
   R.P = P; R.prof = prof+po; R.seq = seq+seq_off[r]; R.lf = P->logfact; R.plen = plen; R.rlen = rlen;
   R.wall = wall_all+po+r;
   R.wall_s = walls_all+po+r;
@@ -672,8 +810,9 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   }
   for (int k = lane; k < LCAP0+LCAP1; k += WAVE)
     s_mkey[k] = -1;
-  R.eintvl = eintvl_all+eoff[r];
-  R.ointvl = ointvl_all+eoff[r];
+  R.eintvl.g = eintvl_all+eoff[r];
+  R.eintvl.l = (CP_LDS_PTR(cp_eintvl))s_ev;
+  R.ointvl.g = ointvl_all+eoff[r];                      // the O-pairs (a handful; only their ends are read back) stay in HBM
   R.ecap = (int)(eoff[r+1]-eoff[r]);
   R.eidx = R.oidx = 0; R.overflow = 0;
   cp_intvl *intvl = intvl_all+ioff[r];
@@ -691,6 +830,8 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
 #endif
   // a pass memoises at most two entries per live candidate (its own and its low-complexity partner's)
   R.perror.use_lds = ((8*n_live0 <= 3*LCAP0) ? 1 : 0) | ((8*(n_t-n_live0) <= 3*LCAP1) ? 2 : 0);
+  // the SELF pass appends at most one E-interval per live task: with that many slots on chip the replay never moves the list
+  R.eintvl.big = (n_live0 > FW_EVL || R.ecap < FW_EVL) ? 1 : 0;
   // a pass whose memo does not fit on chip uses its table in HBM: empty it here (the few reads that need one), instead
   // of a memset over every read's tables per batch
   { const int hc = (int)R.perror.g.mask+1;
@@ -741,26 +882,35 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
 
   // ---- un-wall positions explained by O-pairs / inside E-intervals (wall.c:722-731) --------
   // From here on the lists of the walk are dead except the candidate positions (clist, second quarter of
-  // wl); s_res is reused as an int buffer for short lists.
+  // wl); s_res is reused for the short lists of the phases below.
   int *sbuf = reinterpret_cast<int *>(s_res);
   constexpr int SBUF = (int)(sizeof(task_res)*WAVE/sizeof(int));      // 512 ints
+  constexpr int SCOMP = 64;                             // components of the error regions kept on chip
+  constexpr int U16 = 2*(SBUF-2*SCOMP);                 // 16-bit list slots in front of the component arrays
+  uint16_t *s16 = reinterpret_cast<uint16_t *>(sbuf);
+  int *s_cb = sbuf+SBUF-2*SCOMP, *s_ce = sbuf+SBUF-SCOMP;
+  // positions fit 16 bits and the lists of this read fit the slots: O-only walls (<= n_c) during the multi-error search,
+  // then the walls outside error regions (<= n_c) followed by the boundaries (<= n_c + 2*SCOMP + 1)
+  const bool on16 = plen <= 65535 && 2*n_c+2*SCOMP+1 <= U16;
+  R.eintvl.big = __shfl(R.eintvl.big,0);                // (the replay's lanes cannot have moved it: see above)
   // (the "paired by OTHERS" bit goes too: nothing reads it after the walk, and an O-pair partner that is no candidate
   //  must be left clean for the next batch -- the O-interval list is reused as sort scratch below)
   if (lane == 0)
     for (int k = 0; k < NO; k++)
-      { wall[R.ointvl[k].b] &= ~(CP_W_WALL_O|CP_W_PAIRED_O);
-        wall[R.ointvl[k].e] &= ~(CP_W_WALL_O|CP_W_PAIRED_O);
+      { const cp_eintvl o = R.ointvl.g[k];
+        wall[o.b] &= ~(CP_W_WALL_O|CP_W_PAIRED_O);
+        wall[o.e] &= ~(CP_W_WALL_O|CP_W_PAIRED_O);
       }
   wave_sync();
   wave_unwall_inside(wall,clist,n_c,R.eintvl,0,NS,sbuf,SBUF/2);
 
   // ---- sort + dedupe E-intervals (wall.c:734); the O list is not used again ------------------
-  NS = wave_sort_dedupe_eintvl(R.eintvl,NS,R.ointvl);
+  NS = wave_sort_ev(R.eintvl,NS,R.ointvl.g,true);
 
   // ---- multi-error / boundary E-intervals (wall.c:760-861) -----------------------------------
   // The reference scans every position for O-only walls; OTHERS walls are only ever set at wall
   // candidates, so the lanes test the candidates and compact the qualifying positions, in order, into a
-  // short list that one lane then processes sequentially (processing a wall can mark later ones as
+  // short list that the wave then processes one by one (processing a wall can mark later ones as
   // paired, wall.c:766-767).
   int32_t *olist = wl, *compB = wl+2*(int64_t)icap, *compE = compB+(icap >> 1), *bnd = wl+3*(int64_t)icap;
   const int ccap = icap >> 1;                           // components <= candidates+1 <= icap/2
@@ -773,14 +923,17 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
           keep = (wall[i] & CP_W_WALL_O) && !(wall_s[i] & CP_W_WALL_S);
         }
       const uint64_t m = __ballot(keep);
-      if (keep) olist[n_o+__popcll(m & ((1ull << lane)-1))] = i;     // n_o < n_c <= icap
+      if (keep)
+        { const int o = n_o+__popcll(m & ((1ull << lane)-1));           // n_o < n_c <= icap
+          if (on16) s16[o] = (uint16_t)i; else olist[o] = i;
+        }
       n_o += __popcll(m);
     }
   wave_sync();
   PH_STAMP(2);
   int midx = NS;
   for (int q = 0; q < n_o; q++)                        // all lanes together, see wave_wall_mult
-    { const int ii = olist[q];
+    { const int ii = on16 ? (int)s16[q] : olist[q];
       wave_sync();                                     // lane 0's flag stores of the previous wall
       if (wall[ii] & CP_W_PAIRED_M)                    // may have been set by an earlier i
         continue;
@@ -792,14 +945,15 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   wave_unwall_inside(wall,clist,n_c,R.eintvl,NS,midx,sbuf,SBUF/2);      // wall.c:868-872
   if (NS < midx)                                       // wall.c:873-876
     { NS = midx;
-      wave_sort_eintvl(R.eintvl,NS,R.ointvl);
+      wave_sort_ev(R.eintvl,NS,R.ointvl.g,false);
     }
   if (lane == 0)                                       // wall.c:878-909
     NS = cp_merge_eintvl(&R,NS);
   NS = __shfl(NS,0);
   overflow |= __shfl(R.overflow,0);
+  R.eintvl.big = __shfl(R.eintvl.big,0);               // lane 0's appends may have moved the list to HBM
   wave_sync();
-  wave_sort_eintvl(R.eintvl,NS,R.ointvl);              // wall.c:910
+  wave_sort_ev(R.eintvl,NS,R.ointvl.g,false);          // wall.c:910
   PH_STAMP(4);
 
   // ---- interval boundaries (wall.c:917-948) without per-position passes -----------------------
@@ -808,26 +962,17 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   //   error regions  = connected components of the union of the sorted E-intervals,
   //   boundaries     = component starts (>= 1) and ends, OTHERS walls (candidate positions) outside
   //                    every component, and plen; merged in increasing order.
-  // Short lists (the usual case) are staged in LDS, so that the one-lane loops below step through
-  // on-chip memory instead of paying a global-memory round trip per element:
-  //   sbuf[0..2*NS)  = E-interval ends while the components are built, then the walls (<= SBUF-2*SCOMP)
-  //   sbuf[SBUF-2*SCOMP..) = component starts / ends
-  constexpr int SCOMP = 64;
-  const bool small = (2*NS <= SBUF-2*SCOMP) && (n_c <= SBUF-2*SCOMP);
-  int *s_cb = sbuf+SBUF-2*SCOMP, *s_ce = sbuf+SBUF-SCOMP;
+  // Short lists (the usual case) stay in LDS, so that the one-lane loops below step through on-chip memory instead of
+  // paying a global-memory round trip per element: the walls in s16[0..n_w), the boundaries in s16[n_c..), the
+  // component starts / ends in s_cb / s_ce.
   int C = 0;
-  if (small)
-    { for (int k = lane; k < NS; k += WAVE)
-        { sbuf[2*k] = R.eintvl[k].b; sbuf[2*k+1] = R.eintvl[k].e; }
-      wave_sync();
-    }
   if (lane == 0)
     { int k = 0;
       while (k < NS)
-        { int cb = small ? sbuf[2*k] : R.eintvl[k].b, ce = small ? sbuf[2*k+1] : R.eintvl[k].e;
+        { int cb = R.eintvl.b(k), ce = R.eintvl.e(k);
           k++;
-          while (k < NS && (small ? sbuf[2*k] : R.eintvl[k].b) <= ce)
-            { const int e2 = small ? sbuf[2*k+1] : R.eintvl[k].e;
+          while (k < NS && R.eintvl.b(k) <= ce)
+            { const int e2 = R.eintvl.e(k);
               if (e2 > ce) ce = e2;
               k++;
             }
@@ -838,7 +983,8 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
     }
   C = __shfl(C,0);
   if (C > ccap) { overflow |= 2; C = ccap; }
-  const bool smallc = small && C <= SCOMP;              // components and walls both on chip
+  const bool smallc = on16 && C <= SCOMP;               // components, walls and boundaries all on chip
+  uint16_t *s_bnd = s16+n_c;
   wave_sync();
   int n_w = 0;                                         // OTHERS walls outside error regions, in order
   for (int base = 0; base < n_c; base += WAVE)
@@ -861,8 +1007,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
       const uint64_t m = __ballot(keep);
       if (keep)
         { const int o = n_w+__popcll(m & ((1ull << lane)-1));
-          olist[o] = i;                                // n_w < n_c <= icap
-          if (smallc) sbuf[o] = i;
+          if (smallc) s16[o] = (uint16_t)i; else olist[o] = i;       // n_w < n_c <= icap
         }
       n_w += __popcll(m);
     }
@@ -877,23 +1022,25 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
               if (v >= 1 && v < plen && v > last) { tpos = v; break; }
               if (phase) { ci++; phase = 0; } else phase = 1;
             }
-          int wpos = (wi < n_w) ? (smallc ? sbuf[wi] : olist[wi]) : plen;
+          int wpos = (wi < n_w) ? (smallc ? (int)s16[wi] : olist[wi]) : plen;
           int nb = tpos < wpos ? tpos : wpos;
           if (nb >= plen) break;
-          if (N < icap) bnd[N] = nb;
+          if (N < icap) { if (smallc) s_bnd[N] = (uint16_t)nb; else bnd[N] = nb; }
           N++;
           last = nb;
           if (wpos == nb) wi++;
           if (tpos == nb) { if (phase) { ci++; phase = 0; } else phase = 1; }
         }
-      if (N < icap) bnd[N] = plen;
+      if (N < icap) { if (smallc) s_bnd[N] = (uint16_t)plen; else bnd[N] = plen; }
       N++;
     }
   N = __shfl(N,0);
   if (N > icap) overflow |= 2;
   wave_sync();
   for (int k = lane; k < N && k < icap; k += WAVE)     // wall.c:928-946, one lane per interval
-    cp_make_interval(&R,NS,k ? bnd[k-1] : 0,bnd[k],&intvl[k]);
+    { const int b0 = k ? (smallc ? (int)s_bnd[k-1] : bnd[k-1]) : 0, e0 = smallc ? (int)s_bnd[k] : bnd[k];
+      cp_make_interval(&R,NS,b0,e0,&intvl[k]);
+    }
   PH_STAMP(5);
   // Leave the flag arrays all zero (capi.hip fills them only when they are allocated): every cell the walk and the
   // multi-error phase wrote is a candidate position or an end of an E-interval of the final list (the ends of O-pairs
@@ -905,7 +1052,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
     { for (int q = lane; q < n_c; q += WAVE)
         { const int i = clist[q]; wall[i] = 0; R.wall_s[i] = 0; }
       for (int k = lane; k < NS; k += WAVE)
-        { const int b = R.eintvl[k].b, e = R.eintvl[k].e;
+        { const int b = R.eintvl.b(k), e = R.eintvl.e(k);
           wall[b] = 0; wall[e] = 0; R.wall_s[b] = 0; R.wall_s[e] = 0;
         }
     }
@@ -1082,22 +1229,39 @@ k_classify_unrel(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__re
 //  recurrence.  Interval fields (16-bit), DP cells, back-pointers and both assignments live in LDS;
 //  HBM is touched for pe (once per step) and for the results.
 // ---------------------------------------------------------------------------------------------
+// LDS record of a wave (G reads).  Sized for waves: with MAXM = 128, G = 4 it is 11 KB (14 waves per CU), so the
+// kernel's 168 VGPRs (3 waves per SIMD), not its LDS, set the occupancy:
+//   * `eff` (index of the interval whose data stands in for path index k) and the "absolutely repeat" flag rpos share
+//     one element: the index in the low bits, the flag in the top bit (one byte while MAXM <= 128);
+//   * the traceback overwrites a back-pointer byte with the assignment of the same interval once it has read it, so
+//     `asgn` is the `parent` array seen after the traceback.
+#ifndef REL_CELL_PAD
+#define REL_CELL_PAD 2
+#define REL_ROW_PAD  2
+#define REL_TR_PAD   2
+#endif
 template <int MAXM, int G>
 struct rel_grp_lds
-  { uint16_t b[G][MAXM], e[G][MAXM], ccb[G][MAXM], cce[G][MAXM];
-    uint8_t  parent[G][2][MAXM];         // back-pointers of the 4 cells of an interval, 2 bits each
-    int16_t  eff[G][2][MAXM];
-    uint8_t  rpos[G][2][MAXM];
-    int8_t   asgn[G][2][MAXM];
-    cp_cell  cell[G][2][2][4];           // [read][direction][buffer][state]
-    double   tr[G][2][16];               // [read][direction][s*4+t]
+  { typedef typename std::conditional<(MAXM <= 128),uint8_t,uint16_t>::type eff_t;
+    static constexpr int RPOS = (MAXM <= 128) ? 0x80 : 0x8000;
+    // Bank layout (64 banks of 4 B; a 32-lane half holds 4 (read, direction) groups): rows and records are padded so
+    // that the groups' copies of one field fall on different banks -- unpadded, the 64-byte cells of the 16 (group,
+    // state) pairs of a half shared 2-4 banks and 58 % of the kernel's LDS cycles were conflict cycles
+    // (profiles/r03_sq_counters.txt: SQ_LDS_BANK_CONFLICT 3.3e8 of SQ_LDS_IDX_ACTIVE 5.7e8 per sub-batch).
+    struct cell_t : cp_cell { int pad_[REL_CELL_PAD]; };                          // 72-byte stride
+    uint16_t b[G][MAXM+REL_ROW_PAD], e[G][MAXM+REL_ROW_PAD], ccb[G][MAXM+REL_ROW_PAD], cce[G][MAXM+REL_ROW_PAD];
+    uint8_t  parent[G][2][MAXM];         // back-pointers of the 4 cells of an interval, 2 bits each; then the assignment
+    eff_t    eff[G][2][MAXM];            // eff | RPOS flag
+    cell_t   cell[G][2][2][4];           // [read][direction][buffer][state]
+    double   tr[G][2][16+REL_TR_PAD];    // [read][direction][s*4+t]
+    __device__ __forceinline__ int8_t *asgn(int g, int d) { return reinterpret_cast<int8_t *>(parent[g][d]); }
   };
 
 template <int MAXM, int G>
 struct rel_grp_view                      // path index -> hot fields through `eff`
   { const rel_grp_lds<MAXM,G> *S; int g, d;
     __device__ __forceinline__ cp_riv operator()(int k) const
-    { int j = S->eff[g][d][k];
+    { int j = S->eff[g][d][k] & (rel_grp_lds<MAXM,G>::RPOS-1);
       cp_riv r; r.b = S->b[g][j]; r.e = S->e[g][j]; r.ccb = S->ccb[g][j]; r.cce = S->cce[g][j]; r.pe = 0.;
       return r;
     }
@@ -1142,12 +1306,11 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
       I.pe = rintvl[i].pe;
       cp_cell c;
       cp_rel_init_cell(P,ld,I,i,plen,F,COV,&c);
-      S.cell[g][d][0][ld] = c;
+      static_cast<cp_cell &>(S.cell[g][d][0][ld]) = c;
       S.tr[g][d][ld] = exp(c.dp);
       if (ld == 0)
         { S.parent[g][d][i] = 0xe4;                        // each state its own parent: 3,2,1,0
-          S.rpos[g][d][i] = 0;
-          S.eff[g][d][i] = (int16_t)i;
+          S.eff[g][d][i] = (typename rel_grp_lds<MAXM,G>::eff_t)i;            // (rpos flag clear)
         }
     }
   wave_sync();
@@ -1272,9 +1435,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
             { c = S.cell[g][d][cur][l16];
               cp_rel_only_r_cell(l16,i,&c);
               if (l16 == 0)
-                { S.rpos[g][d][i] = 1;
-                  S.eff[g][d][i] = S.eff[g][d][i_pred];
-                }
+                S.eff[g][d][i] = (typename rel_grp_lds<MAXM,G>::eff_t)(S.eff[g][d][i_pred] | rel_grp_lds<MAXM,G>::RPOS);
             }
           else
             { double dummy, max_logp = -INFINITY;
@@ -1295,12 +1456,10 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
                 }
               pv = (max_s == CP_N_STATE) ? l16 : max_s;
               if (l16 == 0)
-                { S.rpos[g][d][i] = 0;
-                  S.eff[g][d][i] = (int16_t)i;
-                }
+                S.eff[g][d][i] = (typename rel_grp_lds<MAXM,G>::eff_t)i;
               cp_rel_target_cell(P,l16,i,I,F,COV,max_s,max_logp,&S.cell[g][d][cur][0],view,&c);
             }
-          S.cell[g][d][cur^1][l16] = c;
+          static_cast<cp_cell &>(S.cell[g][d][cur^1][l16]) = c;
           const int l0 = lane-l16;                         // pack the four back-pointers into one byte
           const int pk = pv | (__shfl(pv,l0+1) << 2) | (__shfl(pv,l0+2) << 4) | (__shfl(pv,l0+3) << 6);
           if (l16 == 0)
@@ -1319,15 +1478,19 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
           { max_logp = S.cell[g][d][fin][x].dp;
             st = x;
           }
+      // (the assignment of interval k replaces its back-pointer byte, which has just been read)
+      int8_t *as = S.asgn(g,d);
       if (F)
         for (int k = M-1; k >= 0; k--)
-          { S.asgn[g][d][k] = S.rpos[g][d][k] ? (int8_t)CP_REPEAT : (int8_t)st;
-            st = (S.parent[g][d][k] >> (2*st)) & 3;
+          { const int pk = S.parent[g][d][k];
+            as[k] = (S.eff[g][d][k] & rel_grp_lds<MAXM,G>::RPOS) ? (int8_t)CP_REPEAT : (int8_t)st;
+            st = (pk >> (2*st)) & 3;
           }
       else
         for (int k = 0; k < M; k++)
-          { S.asgn[g][d][k] = S.rpos[g][d][k] ? (int8_t)CP_REPEAT : (int8_t)st;
-            st = (S.parent[g][d][k] >> (2*st)) & 3;
+          { const int pk = S.parent[g][d][k];
+            as[k] = (S.eff[g][d][k] & rel_grp_lds<MAXM,G>::RPOS) ? (int8_t)CP_REPEAT : (int8_t)st;
+            st = (pk >> (2*st)) & 3;
           }
     }
   wave_sync();
@@ -1354,12 +1517,15 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
 #ifndef UNREL_SMALL_MAXN
 #define UNREL_SMALL_MAXN 256
 #endif
+#ifndef REL_EXTRA_ATTR
+#define REL_EXTRA_ATTR
+#endif
 #ifndef REL_WAVES_PER_EU
-#define REL_WAVES_PER_EU 1
+#define REL_WAVES_PER_EU 3
 #endif
 
 template <int MINM, int MAXM, int G>
-__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(REL_WAVES_PER_EU)))
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(REL_WAVES_PER_EU))) REL_EXTRA_ATTR
 k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ prof_off, int nreads,
                    cp_intvl *__restrict__ intvl_all, cp_intvl *__restrict__ rintvl_all, const int32_t *__restrict__ relmap_all,
                    const int64_t *__restrict__ ioff, const int32_t *__restrict__ nrel,
@@ -1400,7 +1566,7 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
 
   int rerun = 0;                                           // class_rel.c:629-650
   if (lead)
-    rerun = cp_rel_post1(P,rv,M,F,S.asgn[g][d],COV) ? 1 : 0;
+    rerun = cp_rel_post1(P,rv,M,F,S.asgn(g,d),COV) ? 1 : 0;
   rerun = __shfl(rerun,leadlane);
   COV[CP_HAPLO] = __shfl(COV[CP_HAPLO],leadlane);
   COV[CP_DIPLO] = __shfl(COV[CP_DIPLO],leadlane);
@@ -1409,13 +1575,13 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
     rel_grp_pass<MAXM,G>(P,S,rintvl,M,plen,rerun != 0,COV);
   double hdrr = 1.;
   if (lead)
-    hdrr = cp_rel_post2(P,rv,M,F,S.asgn[g][d],rerun != 0);
+    hdrr = cp_rel_post2(P,rv,M,F,S.asgn(g,d),rerun != 0);
   const double hf = __shfl(hdrr,g*L), hb = __shfl(hdrr,g*L+LD);
   wave_sync();
 
   int take_bw = 0;                                         // class_rel.c:904-938
   if (M > 0 && ql == 0)
-    { const int8_t *fw = S.asgn[g][0], *bw = S.asgn[g][1];
+    { const int8_t *fw = S.asgn(g,0), *bw = S.asgn(g,1);
       bool eq = true;
       for (int i = 0; i < M; i++)
         if (fw[i] != bw[i]) { eq = false; break; }
@@ -1443,7 +1609,7 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
   const int32_t *relmap = relmap_all+o;
   int8_t *gfw = asgn_all+o, *gbw = asgn_all+totalI+o;
   for (int i = ql; i < M; i += L)                          // class_rel.c:949-960
-    { int8_t f = S.asgn[g][0][i], w = S.asgn[g][1][i];
+    { int8_t f = S.asgn(g,0)[i], w = S.asgn(g,1)[i];
       int8_t a = take_bw ? w : f;
       gfw[i] = f; gbw[i] = w;
       rintvl[i].asgn = a;
@@ -1893,6 +2059,40 @@ k_unpack_bases(const uint8_t *__restrict__ packed, const int64_t *__restrict__ p
       for (int q = 0; q < 4; q++)
         if (p+q < rlen)
           dst[p+q] = "ACGT"[(b >> (6-2*q)) & 3];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+//  k_pack_labels: the label string of a read as 2-bit codes, four per byte, first label in the top bits --
+//  ctos (const.c:21-36: N, E -> 0, R -> 1, H -> 2, D -> 3) followed by Compress_Read (gene_core.c:235-254), i.e. the
+//  read's payload of the .class.data track (ClassPro.c:291-300): labels then cross PCIe at 0.25 B/base instead of 1.
+//  One block per read, one output byte (four labels, one unaligned 4-byte load) per thread and step.
+// ---------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(1))) cp_u8x4 { uint32_t v; };
+__device__ __forceinline__ unsigned cp_label_code(unsigned c) { return c == 'R' ? 1u : c == 'H' ? 2u : c == 'D' ? 3u : 0u; }
+__global__ void __launch_bounds__(256)
+k_pack_labels(const char *__restrict__ labels, const int64_t *__restrict__ seq_off, const int64_t *__restrict__ pack_off,
+              int nreads, uint8_t *__restrict__ packed)
+{ const int r = blockIdx.x;
+  if (r >= nreads) return;
+  const char *src = labels+seq_off[r];
+  uint8_t *dst = packed+pack_off[r];
+  const int rlen = (int)(seq_off[r+1]-seq_off[r]);
+  const int clen = (rlen+3) >> 2;
+  for (int k = threadIdx.x; k < clen; k += blockDim.x)
+    { const int p = 4*k;
+      unsigned b;
+      if (p+4 <= rlen)
+        { const unsigned w = reinterpret_cast<const cp_u8x4 *>(src+p)->v;
+          b = (cp_label_code(w & 0xff) << 6) | (cp_label_code((w >> 8) & 0xff) << 4) | (cp_label_code((w >> 16) & 0xff) << 2)
+              | cp_label_code(w >> 24);
+        }
+      else
+        { b = 0;
+          for (int q = 0; q < 4; q++)
+            if (p+q < rlen) b |= cp_label_code((unsigned char)src[p+q]) << (6-2*q);
+        }
+      dst[k] = (uint8_t)b;
     }
 }
 

@@ -140,6 +140,19 @@ int cp_decode_profiles(cp_workspace *ws, const uint8_t *d_codes, const int64_t *
 int  cp_unpack_bases(const uint8_t *d_packed, const int64_t *d_pack_off, const int64_t *d_seq_off,
                      int nreads, char *d_seq, void *stream);
 
+/* 2-bit payloads across PCIe for FASTX inputs too.  Bases: cp_pack_bases (host) packs one read in
+ * the layout cp_unpack_bases expands, when it holds upper-case A, C, G, T only (returns 1; 0 = another letter: send the
+ * batch as characters -- calc_seq_context compares raw characters, context.c:8-108).  Labels: cp_pack_labels (device)
+ * turns the label string of every read into 2-bit codes, four per byte, first label in the top bits: ctos (const.c:21-36:
+ * N, E -> 0, R -> 1, H -> 2, D -> 3) + Compress_Read (gene_core.c:235-254), i.e. exactly the read's payload of the
+ * .class.data track (ClassPro.c:291-300); read r's (rlen_r+3)/4 bytes start at d_packed[d_pack_off[r]] (the offsets of
+ * cp_unpack_bases).  cp_unpack_labels (host) is the inverse for one read: K-1 'N', then E/R/H/D (stoc, const.c:19).
+ * A batch then crosses PCIe at about 0.52 B/base in (bases + FASTK codes) and 0.25 B/base out instead of 1.27 and 1. */
+int cp_pack_bases(const char *seq, int rlen, uint8_t *packed);
+int cp_pack_labels(const char *d_labels, const int64_t *d_seq_off, const int64_t *d_pack_off, int nreads,
+                   uint8_t *d_packed, void *stream);
+int cp_unpack_labels(const uint8_t *packed, int rlen, int K, char *labels);
+
 /* -s: replaces find_seeds (src/seed.c:966-1032; call site ClassPro.c:281-282) for every read of a batch that
  * cp_classify_batch has labelled.  d_labels is that call's output; d_seeds[total_bases] receives, in the same layout,
  * 'N' for the first K-1 bases of a read and per k-mer 'E' (no seed) or the class of the seed, 'H' / 'D' / 'R' (a seed

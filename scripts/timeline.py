@@ -43,23 +43,62 @@ def main():
     def product(n):
         return n.startswith("k_") and not n.startswith("k_sg_") and not n.endswith("_table")
 
-    subs = []                                             # (stream, [(start,end,name), ...])
+    # A call's head (scan, count, prefix sums) may run on the workspace's own high-priority stream and its body (ordering
+    # ... paint) on the caller's: heads and bodies are collected per stream, a head stream is paired with the body stream
+    # whose first k_wall_tasks starts soonest after its first head ends, and the two lists are zipped in order.
+    HEAD = ("k_scan_candidates", "k_count_caps", "k_prefix_caps", "k_prefix_caps_mb")
+    heads, bodies = collections.defaultdict(list), collections.defaultdict(list)
     for st, lst in by_stream.items():
         i = 0
+        cur = []
         while i < len(lst):
-            if lst[i][3] == "k_scan_candidates":
+            n = lst[i][3]
+            if n == "k_scan_candidates":
                 j = i + 1
-                while j < len(lst) and not product(lst[j][3]):          # memsets / copies of the call sit between its kernels
+                while j < len(lst) and not product(lst[j][3]):
                     j += 1
                 if j < len(lst) and lst[j][3] == "k_count_caps":
                     k = j
-                    while k < len(lst) and lst[k][3] != "k_paint_labels":
+                    while k < len(lst) and not lst[k][3].startswith("k_prefix_caps"):
                         k += 1
                     if k < len(lst):
-                        subs.append((st, [(a, b, n) for a, b, _, n in lst[i:k + 1]]))
+                        heads[st].append([(a, b, n2) for a, b, _, n2 in lst[i:k + 1]])
                         i = k + 1
+                        cur = []
                         continue
+                i += 1                                      # a scan-only launch (bench.py's roofline loop)
+                continue
+            if cur or product(n) or n.startswith("__amd_rocclr"):
+                cur.append((lst[i][0], lst[i][1], n))
+            if n == "k_paint_labels":
+                if any(x[2] == "k_wall_tasks" for x in cur):
+                    while cur and not product(cur[0][2]) and cur[0][2] != "__amd_rocclr_copyBuffer":
+                        cur.pop(0)
+                    bodies[st].append(cur)
+                cur = []
             i += 1
+    subs = []                                             # (stream of the body, [(start,end,name), ...])
+    used = set()
+    for hs in sorted(heads, key=lambda h: heads[h][0][0][0]):
+        h_end = heads[hs][0][-1][1]
+        best = None
+        for bs in bodies:
+            if bs in used:
+                continue
+            wt = next(x[0] for x in bodies[bs][0] if x[2] == "k_wall_tasks")
+            if wt >= h_end and (best is None or wt < best[0]):
+                best = (wt, bs)
+        if best is None:
+            continue
+        used.add(best[1])
+        bl, bi = bodies[best[1]], 0
+        for h in heads[hs]:                                 # a head's body: the next one whose k_wall_tasks starts after the head ended
+            while bi < len(bl) and next(x[0] for x in bl[bi] if x[2] == "k_wall_tasks") < h[-1][1]:
+                bi += 1
+            if bi == len(bl):
+                break
+            subs.append((best[1], h + bl[bi]))
+            bi += 1
     per_stream = collections.Counter()
     kept = []
     for st, ks in sorted(subs, key=lambda x: x[1][0][0]):
@@ -86,10 +125,10 @@ def main():
             acc.setdefault(key, []).append(((a - t0) / 1e3, (b - t0) / 1e3, (b - a) / 1e3, (a - prev_end) / 1e3 if prev_end else 0.0))
             prev_end = b if prev_end is None else max(prev_end, b)
         names = [n for _, _, n in ks]
-        pc = next((x for x in ks if x[2] == "k_prefix_caps"), None)
+        pc = next((x for x in ks if x[2].startswith("k_prefix_caps")), None)
         if pc:
             head["scan start -> k_prefix_caps end"].append((pc[1] - t0) / 1e3)
-            nxt = next((x for x in ks if x[0] >= pc[1] and product(x[2]) and x[2] != "k_prefix_caps"), None)
+            nxt = next((x for x in ks if x[0] >= pc[1] and product(x[2]) and not x[2].startswith("k_prefix_caps")), None)
             if nxt:
                 head["host round trip: k_prefix_caps end -> next kernel start (%s)" % nxt[2]].append((nxt[0] - pc[1]) / 1e3)
         wt = next((x for x in ks if x[2] == "k_wall_tasks"), None)
@@ -134,8 +173,8 @@ def main():
         w("  %-44s %5.1f %%  (%.3f ms per sub-batch)\n" % (n[:44], 100.0 * v / sum(busy.values()), v / 1e6 / len(kept)))
     # ---- idle time per stream ----
     w("\nper stream: time with no product kernel of that stream running, as a fraction of the span\n")
-    for st in sorted(per_stream):
-        iv = sorted((a, b) for s2, ks in kept if s2 == st for a, b, n in ks if product(n))
+    for st in sorted(by_stream):
+        iv = sorted((a, b) for a, b, s2, n in rows if s2 == st and product(n) and a >= span0 and b <= span1)
         if not iv:
             continue
         covered, ce = 0, iv[0][0]

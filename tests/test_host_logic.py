@@ -232,3 +232,32 @@ def test_device_functions_vs_oracle_adversarial(harness):
         n += 1
     assert n > 60
     harness.hh_params_free(C.c_void_p(P))
+
+
+def test_pack_bases_and_unpack_labels_host(built):
+    """cp_pack_bases == Compress_Read's layout (gene_core.c:235-254; classpro_amd.dazz.pack_2bit restates it for the
+    database writer) for pure upper-case ACGT and refuses anything else; cp_unpack_labels inverts the track payload."""
+    from classpro_amd import dazz
+    from classpro_amd.api import pack_bases, unpack_labels
+    rng = np.random.default_rng(7)
+    seqs = [bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)]) for n in (1, 2, 3, 4, 5, 63, 64, 65, 1000, 4099)]
+    packed, off = pack_bases(seqs)
+    code = np.zeros(256, np.uint8)
+    code[ord("C")], code[ord("G")], code[ord("T")] = 1, 2, 3
+    for i, s in enumerate(seqs):
+        want = dazz.pack_2bit(code[np.frombuffer(s, np.uint8)])
+        assert np.array_equal(packed[off[i]:off[i + 1]], want), i
+    for bad in (b"ACGN", b"acgt", b"ACGTACGU", b"AC-T", b"ACG\x00"):
+        assert pack_bases([seqs[5], bad]) is None
+    assert pack_bases([b""])[1].tolist() == [0, 0]
+    # labels: K-1 'N', then E/R/H/D from the 2-bit codes (0,1,2,3), whatever sits in the N part and the padding
+    K = 7
+    for n in (1, 5, 6, 7, 8, 9, 100, 1001):
+        lab = np.frombuffer(b"ERHD", np.uint8)[rng.integers(0, 4, n)].copy()
+        lab[:min(K - 1, n)] = ord("N")
+        codes = np.zeros(n, np.uint8)
+        for ch, v in ((b"R", 1), (b"H", 2), (b"D", 3)):
+            codes[lab == ch[0]] = v
+        pk = dazz.pack_2bit(codes)
+        got = unpack_labels(pk, [0], [n], K)
+        assert got.tobytes() == lab.tobytes(), n
