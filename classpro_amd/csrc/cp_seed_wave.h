@@ -33,7 +33,8 @@
 #pragma once
 #include "cp_seed.h"
 
-#define SW_DQ    64
+#define SW_RING  512                             // segments (begin, count) of the window-count pass kept on chip
+#define SW_BACK  128                             // ... of which this many lie behind the tile being worked on
 #define SW_MI    256
 #define SW_PEND  64
 #define SW_REP   64
@@ -41,7 +42,7 @@
 #define SW_STEP  4                               // chunks of 64 positions per load step
 
 struct cp_seedw_lds
-  { int4     dq[SW_DQ];                          // deque ring: (segment, count, begin, end)
+  { int2     ring[SW_RING];                      // (begin, count or -1) of the segments around the tile being worked on
     int32_t  mi_b[SW_MI], mi_e[SW_MI];           // masked-interval list while it fits
     int32_t  cval[SW_STEP*WAVE];                 // per position: the count if the k-mer is valid, else -1; base classes for the hash
     int32_t  bins[32];
@@ -233,92 +234,42 @@ __device__ __attribute__((noinline)) void sw_mark(const char *seq, const char *c
     }
 }
 
-// an entry of a deque that moved to HBM.  Out of line on purpose: the chain's own code then holds no HBM load, so the
-// compiler puts no wait for memory into it, and the chain's stores (window counts, segment records) stay in flight
-__device__ __attribute__((noinline)) int4 sw_dq_far(const int4 *a, int p) { return a[p]; }
-
 // ---- one selection (seed.c:190-476 with C = 'H'/'D'; seed.c:667-951 with C = 0) --------------------------------------
+// The window counts WITHOUT the deque.  The reference feeds the segments to a monotone deque one by one (seed.c:218-324 /
+// :694-810) and a segment's "number of windows" is decided when it leaves the deque.  When and how it leaves follows from
+// the segments around it alone (scripts/proto/seed_windows.py checks the restatement below against
+// the literal loop on random inputs).  With b(i) the begin of segment i, c(i) its count, W the window, "beats" = larger
+// count (H/D) or smaller count (repeats), x(i) the first later segment that begins at or beyond b(i)+W:
+//   * segment i is BEATEN if a valid segment g in (i, x(i)] beats it (the first such one counts).  Its value is the
+//     reference's stand-in (count, or W_REP - count), unless no segment that beats i and begins beyond b(g-1)-W precedes
+//     it -- then i shared the front's count when the deque was wiped and gets min(b(g)-b(i), W);
+//   * otherwise i EXPIRES from the front at step x(i) (or at the end of the read) with W, or with
+//     min(b(i) - last_oor_pos + 1, W) when "last_oor" holds: the previous expiring segment exists and no WIPE (a valid
+//     segment k that beats everything still in the deque: some valid segment begins beyond b(k-1)-W before k, and none
+//     of those is as good as k) happened after that segment's expiry step and up to i.  last_oor_pos is the end of the
+//     last expiring segment before i that was followed in (q, x(q)] by a valid segment and by none of its own count.
+// So every segment needs one forward and one backward search over a window of W positions, and the expiring ones two
+// prefix operations ("last such segment before me") over the segment order.  A wave takes 64 segments at a time, a lane
+// each: short searches run per lane (most segments have a better neighbour a few segments away), the few long ones are
+// done one by one by the whole wave, 64 window segments per step (ballots); the prefix operations are ballots with three
+// carried scalars.  The segments' (begin, count) sit in an LDS ring around the tile; a window that reaches beyond it is
+// read from the records in HBM.
 template <bool rep>
 __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, int C, int nrep, bool rep_big, int lane
                                           SW_PROF_ARGS)
 { const int W = rep ? CP_SEED_W_REP : CP_SEED_W;
   const int plen = R.plen, Km1 = R.K-1;
   const uint64_t lt = (1ull << lane)-1;
-  // ---- the sequential chain: the monotone deque over the segments (seed.c:218-324 / :694-810) ----
-  // Run by lane 0 on wave-uniform values (scalar registers, scalar branches).  Entries are addressed by their
-  // running number p (qf .. qf+qn-1): ring slot p % SW_DQ, or, once the deque got deeper than the ring, slot p of an
-  // idle HBM array.  The front entry and the back entry's (segment, count) sit in registers.
-  int n = 0, M = 0, nbig = 0;
-  int qf = 0, qn = 0; bool last_oor = false; int last_oor_pos = 0;
-  bool spilled = false, grow = false, full = false;
-  int4 F = make_int4(0,0,0,0); int Bn = 0, Bc = 0;
-  auto dq_get = [&](int p) -> int4
-    { const int4 t = spilled ? sw_dq_far(R.orec,p) : sw_S.dq[p & (SW_DQ-1)];
-      return make_int4(sw_first(t.x),sw_first(t.y),sw_first(t.z),sw_first(t.w));
-    };
-  auto dq_put = [&](int p, int4 v)
-    { if (spilled) R.orec[p] = v; else sw_S.dq[p & (SW_DQ-1)] = v; };
-  auto set_nw = [&](int seg, int v) { ((int32_t *)(R.rec+seg))[2] = v; };
   auto beats = [&](int a, int c) -> bool { return rep ? (a < c) : (a > c); };
-  // a displaced segment that was not the front gets its count (H/D) or W_REP - count (repeats) as a stand-in
-  auto standin = [&](int c) -> int { const int v = rep ? (CP_SEED_W_REP-c > 0 ? CP_SEED_W_REP-c : 0) : c; nbig += v > 1000; return v; };
-  auto expire = [&]() -> int4                                // the front leaves the window (or the read ends): its count of windows
-    { int v = W;
-      if (last_oor) { v = F.z-last_oor_pos+1; if (v > W) v = W; }
-      set_nw(F.x,v);
-      return qn > 1 ? dq_get(qf+1) : F;
-    };
-  auto feed = [&](int sb, int se, int sc)                    // segment n = [sb,se), count sc (-1: a skipped stretch)
-    { if (n >= R.cap) { full = true; return; }             // (k_seed_caps sizes the scratch; reported, never written past)
-      R.rec[n] = make_int4(sb,se,(sc < 0) ? -10 : 0,0);
-      if (sc < 0)                                            // skipped stretches are masked from the start
-        { if (!Lm.big && M+4 >= SW_MI) grow = true;          // no room on chip: they are listed again, in HBM, after the pass
-          if (!grow) Lm.set(M,sb,se);
-          M++;
-        }
-      else
-        { if (qn > 0 && beats(sc,F.y))                       // the whole deque goes
-            { last_oor = false;
-              for (int j = 0; j < qn; j++)
-                { const int4 t = dq_get(qf+j);
-                  int v;
-                  if (t.y == F.y) { v = sb-t.z; if (v > W) v = W; }
-                  else v = standin(t.y);
-                  set_nw(t.x,v);
-                }
-              qn = 0;
-            }
-          else
-            while (qn > 0 && beats(sc,Bc))
-              { set_nw(Bn,standin(Bc));
-                qn--;
-                if (qn > 0) { const int4 t = dq_get(qf+qn-1); Bn = t.x; Bc = t.y; }
-              }
-          if (!spilled && qn >= SW_DQ)                       // deeper than the ring: the deque moves to HBM
-            { for (int j = 0; j < qn; j++) R.orec[qf+j] = sw_S.dq[(qf+j) & (SW_DQ-1)];
-              spilled = true;
-            }
-          const int4 t = make_int4(n,sc,sb,se);
-          dq_put(qf+qn,t);
-          if (qn == 0) F = t;
-          Bn = n; Bc = sc;
-          qn++;
-        }
-      while (qn > 0 && F.z <= sb-W)
-        { const int4 nx = expire();
-          if (qn > 1 && beats(F.y,nx.y)) last_oor_pos = F.w;
-          F = nx; qf++; qn--;
-          last_oor = true;
-        }
-      n++;
-    };
-  // ---- segments (all lanes; seed.c:61-110 / :599-665 in closed form) handed to the deque (lane 0) ----
+  int n = 0, M = 0, nbig = 0, endpos = plen;
+  bool grow = false, full = false;
+  // ---- segments (all lanes; seed.c:61-110 / :599-665 in closed form): record i = (begin, -, -, count+1) ----
   // valid(i): the k-mer takes part in this selection.  A valid segment is a run of equal counts from its first valid
-  // k-mer on (it may run on over k-mers of other classes); the k-mers skipped between segments form invalid ones.
-  // A segment that would start at the last k-mer is never made (the reference's loop ends first).
+  // k-mer on (it may run on over k-mers of other classes); the k-mers skipped between segments form invalid ones
+  // (count -1).  A segment that would start at the last k-mer is never made (the reference's loop ends first).
   { bool carry = false;                                      // the run entering the chunk already holds a valid k-mer
-    int ob = 0, oc = 0; bool open = false;                   // the segment whose end is not known yet
-    // the loads of a step are issued one step ahead, so that they are in flight while lane 0 runs the chain
+    int last_start = -1;
+    // the loads of a step are issued one step ahead
     int ncnt[SW_STEP], ncpv[SW_STEP]; char ncl[SW_STEP], nst[SW_STEP];
     auto load_step = [&](int e0)
       {
@@ -338,7 +289,6 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
 #pragma unroll
         for (int u = 0; u < SW_STEP; u++) { cnt[u] = ncnt[u]; cpv[u] = ncpv[u]; cl[u] = ncl[u]; st[u] = nst[u]; }
         if (e0+SW_STEP*WAVE < plen) load_step(e0+SW_STEP*WAVE);
-        uint64_t sm[SW_STEP];
 #pragma unroll
         for (int u = 0; u < SW_STEP; u++)
           { const int p = e0+u*WAVE+lane;
@@ -370,40 +320,191 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
                 if (bb) { const int rb = 63-__clzll((long long)bb); prev_has = (vm & lt & ~((1ull << rb)-1)) != 0; }
                 else prev_has = carry || (vm & lt) != 0;
               }
-            sm[u] = __ballot(in && (p == 0 || first_valid || (bnd && prev_has)));
+            const bool start = in && (p == 0 || first_valid || (bnd && prev_has));
+            const uint64_t sm = __ballot(start);
             if (bm) { const int top = 63-__clzll((long long)bm); carry = (vm & ~((1ull << top)-1)) != 0; }
             else carry = carry || vm != 0;
-            sw_S.cval[u*WAVE+lane] = v ? cnt[u] : -1;
+            if (start)                                       // the segment that starts here: its number is a popcount away
+              { const int idx = n+__popcll(sm & lt);
+                if (idx < R.cap) R.rec[idx] = make_int4(p,0,0,(v ? cnt[u] : -1)+1);
+              }
+            if (sm) last_start = e0+u*WAVE+63-__clzll((long long)sm);
+            n += __popcll(sm);
           }
-        __syncthreads();
-        if (lane == 0)
-          for (int u = 0; u < SW_STEP; u++)                  // (one copy of the chain's code: the masks are picked, not unrolled)
-            { uint64_t m = sm[0];
-#pragma unroll
-              for (int w = 1; w < SW_STEP; w++) if (u == w) m = sm[w];
-              while (m)
-                { const int j = __ffsll((long long)m)-1;
-                  m &= m-1;
-                  const int s = e0+u*WAVE+j;
-                  if (open) feed(ob,s,oc);
-                  ob = s; oc = sw_first(sw_S.cval[u*WAVE+j]); open = true;
-                }
-            }
-        __syncthreads();
       }
-    if (lane == 0)
-      { if (open && ob < plen-1) feed(ob,plen,oc);
-        while (qn > 0)                                       // end of the read; both selections compare with `>` here
-          { const int4 nx = expire();
-            if (qn > 1 && F.y > nx.y) last_oor_pos = F.w;
-            F = nx; qf++; qn--;
-            last_oor = true;
+    if (n > 0 && last_start >= plen-1) { n--; endpos = plen-1; }   // a segment at the last k-mer is never made: it only ends its predecessor
+    full = n > R.cap;                                        // (k_seed_caps sizes the scratch; reported, never written past)
+  }
+  __syncthreads();                                           // the records are visible to the wave
+  if (full) { if (lane == 0) atomicOr(R.err,4); return; }
+  SW_STAMP(1);
+  // ---- window counts, 64 segments at a time ----
+  { int ring_hi = 0;                                         // segments [ring_hi-SW_RING, ring_hi) are in the ring
+    auto seg = [&](int j) -> int2                            // (begin, count) of segment j; j == n: the end of the read
+      { if (j >= n) return make_int2(endpos,-1);
+        if (j < ring_hi && j >= ring_hi-SW_RING) return sw_S.ring[j & (SW_RING-1)];
+        const int4 t = R.rec[j];
+        return make_int2(t.x,t.w-1);
+      };
+    bool c_have = false; int c_x = 0, c_lw = -1, c_pos = 0;  // carried: the last expiring segment's x, the last wipe, last_oor_pos
+    for (int t0 = 0; t0 < n; t0 += WAVE)
+      { { int upto = t0+SW_RING-SW_BACK;                     // the ring covers [t0-SW_BACK, t0+SW_RING-SW_BACK)
+          if (upto > n) upto = n;
+          if (ring_hi < upto)
+            { __syncthreads();                               // (the slots being replaced are no longer read)
+              while (ring_hi < upto)
+                { const int j = ring_hi+lane;
+                  if (j < upto) { const int4 t = R.rec[j]; sw_S.ring[j & (SW_RING-1)] = make_int2(t.x,t.w-1); }
+                  ring_hi = ring_hi+WAVE < upto ? ring_hi+WAVE : upto;
+                }
+              __syncthreads();
+            }
+        }
+        const int i = t0+lane;
+        const bool act = i < n;
+        const int2 me = act ? seg(i) : make_int2(endpos,-1);
+        const int bi = me.x, ci = me.y;
+        const bool valid = act && ci >= 0;
+        const int ei = act ? seg(i+1).x : endpos;            // the segment's end = the next one's begin
+        // -- forward: the first valid segment in (i, x] that beats i; else x, and what else (i, x] holds --
+        int g = -1, bg = 0, bgm1 = 0, x = n;
+        bool eq = false, nonempty = false, fdone = !valid;
+        { int j = i+1, pb = bi;                              // pb: begin of segment j-1
+          for (int step = 0; step < 8 && !fdone; step++)
+            { if (j >= n) { x = n; fdone = true; break; }
+              const int2 s = seg(j);
+              if (s.y >= 0)
+                { if (beats(s.y,ci)) { g = j; bg = s.x; bgm1 = pb; fdone = true; break; }
+                  nonempty = true;
+                  if (s.y == ci) eq = true;
+                }
+              if (s.x >= bi+W) { x = j; fdone = true; break; }
+              pb = s.x; j++;
+            }
+          // the long searches, one at a time, 64 window segments per step
+          for (uint64_t um = __ballot(!fdone); um; um &= um-1)
+            { const int src = __ffsll((long long)um)-1;
+              const int si = __shfl(i,src), sb = __shfl(bi,src), sc = __shfl(ci,src);
+              int j0 = __shfl(j,src);
+              bool seq = __shfl(eq ? 1 : 0,src) != 0, sne = __shfl(nonempty ? 1 : 0,src) != 0;
+              int rg = -1, rbg = 0, rbgm1 = 0, rx = n;
+              (void)si;
+              while (true)
+                { const int jj = j0+lane;
+                  const int2 s = seg(jj);                    // (plen, -1) from n on
+                  const bool vj = jj < n && s.y >= 0;
+                  const uint64_t mB = __ballot(vj && beats(s.y,sc));
+                  const uint64_t mL = __ballot(jj >= n || s.x >= sb+W);
+                  const uint64_t mV = __ballot(vj), mE = __ballot(vj && s.y == sc);
+                  const int fb = mB ? __ffsll((long long)mB)-1 : WAVE, fl = mL ? __ffsll((long long)mL)-1 : WAVE;
+                  if (fb <= fl && fb < WAVE)                 // beaten first (a beater AT x still beats: it is pushed before the expiry)
+                    { rg = j0+fb;
+                      rbg = __shfl(s.x,fb);
+                      rbgm1 = fb > 0 ? __shfl(s.x,fb-1) : seg(j0-1).x;
+                      break;
+                    }
+                  if (fl < WAVE)
+                    { const uint64_t upto = fl == 63 ? ~0ull : ((2ull << fl)-1);
+                      rx = j0+fl < n ? j0+fl : n;
+                      sne = sne || (mV & upto) != 0; seq = seq || (mE & upto) != 0;
+                      break;
+                    }
+                  sne = sne || mV != 0; seq = seq || mE != 0;
+                  j0 += WAVE;
+                }
+              if (lane == src) { g = rg; bg = rbg; bgm1 = rbgm1; x = rx; eq = seq; nonempty = sne; fdone = true; }
+            }
+        }
+        // -- backward: what the deque holds when segment i arrives (segments beginning beyond b(i-1)-W): does any of
+        //    them match or beat i (then i wipes nothing), and where does the nearest one that beats i begin --
+        bool blocked = false, bnon = false, bdone = !valid || i == 0, havep = false;
+        int pbeg = 0;
+        const int limw = (act && i > 0) ? seg(i-1).x-W : 0;
+        { int j = i-1;
+          for (int step = 0; step < 8 && !bdone; step++)
+            { if (j < 0) { bdone = true; break; }
+              const int2 s = seg(j);
+              if (s.x <= limw) { bdone = true; break; }
+              if (s.y >= 0)
+                { bnon = true;
+                  if (!beats(ci,s.y)) blocked = true;
+                  if (beats(s.y,ci)) { havep = true; pbeg = s.x; bdone = true; break; }
+                  if (blocked && g < 0) { bdone = true; break; }         // an expiring segment only needs to know that it wipes nothing
+                }
+              j--;
+            }
+          for (uint64_t um = __ballot(!bdone); um; um &= um-1)
+            { const int src = __ffsll((long long)um)-1;
+              const int sc = __shfl(ci,src), slim = __shfl(limw,src), sg = __shfl(g,src);
+              int j0 = __shfl(j,src);
+              bool sbl = __shfl(blocked ? 1 : 0,src) != 0, sbn = __shfl(bnon ? 1 : 0,src) != 0, shp = false;
+              int spb = 0;
+              while (true)
+                { const int jj = j0-lane;
+                  int2 s = make_int2(0,-1);
+                  if (jj >= 0) s = seg(jj);
+                  const bool out = jj < 0 || s.x <= slim;
+                  const bool vj = !out && s.y >= 0;
+                  const uint64_t mO = __ballot(out), mS = __ballot(vj && beats(s.y,sc));
+                  const uint64_t mN = __ballot(vj && !beats(sc,s.y)), mV = __ballot(vj);
+                  const int fo = mO ? __ffsll((long long)mO)-1 : WAVE, fs = mS ? __ffsll((long long)mS)-1 : WAVE;
+                  if (fs < fo)                               // the nearest segment that beats i is still in the deque
+                    { shp = true; spb = __shfl(s.x,fs); sbl = true; sbn = true; break; }
+                  if (fo < WAVE)
+                    { const uint64_t upto = (1ull << fo)-1;
+                      sbn = sbn || (mV & upto) != 0; sbl = sbl || (mN & upto) != 0;
+                      break;
+                    }
+                  sbn = sbn || mV != 0; sbl = sbl || mN != 0;
+                  if (sbl && sg < 0) break;
+                  j0 -= WAVE;
+                }
+              if (lane == src) { blocked = sbl; bnon = sbn; havep = shp; pbeg = spb; bdone = true; }
+            }
+        }
+        // -- values --
+        const bool wipe = valid && bnon && !blocked;
+        const bool isexp = valid && g < 0;
+        const bool flag = isexp && nonempty && !eq && !(rep && x == n);
+        int nw = -10;
+        bool big = false;
+        if (valid && g >= 0)
+          { if (havep && pbeg > bgm1-W)
+              { nw = rep ? (CP_SEED_W_REP-ci > 0 ? CP_SEED_W_REP-ci : 0) : ci; big = nw > 1000; }
+            else { nw = bg-bi; if (nw > W) nw = W; }
           }
+        const uint64_t EM = __ballot(isexp), WM = __ballot(wipe), FM = __ballot(flag);
+        { const uint64_t pe = EM & lt, pw = WM & (lt | (1ull << lane)), pf = FM & lt;
+          const int se = pe ? 63-__clzll((long long)pe) : 0, sf = pf ? 63-__clzll((long long)pf) : 0;
+          const int xprev = __shfl(x,se), eprev = __shfl(ei,sf);
+          if (isexp)
+            { const bool have = pe ? true : c_have;
+              const int xp = pe ? xprev : c_x;
+              const int lw = pw ? t0+63-__clzll((long long)pw) : c_lw;
+              const int pos = pf ? eprev : c_pos;
+              const bool oor = have && !(lw > xp);
+              nw = W;
+              if (oor) { nw = bi-pos+1; if (nw > W) nw = W; }
+            }
+          if (EM) { c_have = true; c_x = __shfl(x,63-__clzll((long long)EM)); }
+          if (WM) c_lw = t0+63-__clzll((long long)WM);
+          if (FM) c_pos = __shfl(ei,63-__clzll((long long)FM));
+        }
+        nbig += __popcll(__ballot(big));
+        if (act) R.rec[i] = make_int4(bi,ei,nw,ci+1);
+        // -- skipped stretches are masked from the start (seed.c: the list before the selection's takes) --
+        { const bool inv = act && !valid;
+          const uint64_t IM = __ballot(inv);
+          const int m = M+__popcll(IM & lt);
+          const bool ok = Lm.big || m+4 < SW_MI;             // no room on chip: they are listed again, in HBM, after the pass
+          if (__ballot(inv && !ok)) grow = true;
+          if (inv && ok) Lm.set(m,bi,ei);
+          M += __popcll(IM);
+        }
       }
   }
-  __syncthreads();                                           // lane 0's segment records are visible to the wave
-  n = sw_first(n); nbig = sw_first(nbig); M = sw_first(M);   // wave-uniform from here on
-  if (sw_first(full ? 1 : 0)) { if (lane == 0) atomicOr(R.err,4); return; }
+  __syncthreads();                                           // the segment records are visible to the wave
+  n = sw_first(n); nbig = sw_first(nbig); M = sw_first(M);   // (wave-uniform already)
   if (sw_first(grow ? 1 : 0))                                // the skipped stretches did not fit on chip: the list moves to HBM
     { sw_mi_grow(Lm,R.cap+3,lane);                           // (slots not yet rewritten keep the earlier selections' leftovers)
       int k = 0;
@@ -418,9 +519,9 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
         }
       __syncthreads();
     }
-  SW_STAMP(1);
+  SW_STAMP(5);
 #ifdef CP_SEED_PROF
-  if (lane == 0) { sw_t[5] += n; sw_t[6] += M; sw_t[7] += (plen+SW_STEP*WAVE-1)/(SW_STEP*WAVE); }
+  if (lane == 0) { sw_t[6] += n; sw_t[7] += (plen+SW_STEP*WAVE-1)/(SW_STEP*WAVE); }
 #endif
   if (M > 0 && Lm.b(0) == 0 && Lm.e(0) == plen) return;
   // ---- stable order by decreasing window count (the reference's qsort is glibc's stable merge sort): two 5-bit radix

@@ -27,9 +27,9 @@ for it in range(3):
     if hasattr(L, "cp_debug_seed_prof"):
         out = (C.c_ulonglong * 8)()
         L.cp_debug_seed_prof(out)
-        print("   lane-0 ms per read (100 MHz ticks): anno %.3f  segments+deque %.3f  sort %.3f  whole-window takes %.3f  group walk %.3f" %
-              tuple(out[k] / b4.nreads / 1e5 for k in range(5)), flush=True)
-        print("   per read, summed over the three selections: segments %.0f  skipped stretches %.0f  load steps %.0f" %
-              tuple(out[k] / b4.nreads for k in (5, 6, 7)), flush=True)
+        print("   lane-0 ms per read (100 MHz ticks): anno %.3f  segments %.3f  window counts %.3f  sort %.3f  whole-window takes %.3f  group walk %.3f" %
+              tuple(out[k] / b4.nreads / 1e5 for k in (0, 1, 5, 2, 3, 4)), flush=True)
+        print("   per read, summed over the three selections: segments %.0f  load steps %.0f" %
+              tuple(out[k] / b4.nreads for k in (6, 7)), flush=True)
     print("seeds pass %d: %.1f ms, %.1f Gbases/s (%d reads, %d bases); seeds %.4f" % (it, dt * 1e3, b4.total_bases / dt / 1e9, b4.nreads, b4.total_bases,
           float((seeds != ord("E")).float().mean())), flush=True)
