@@ -33,8 +33,10 @@
 #pragma once
 #include "cp_seed.h"
 
+#ifndef SW_RING
 #define SW_RING  512                             // segments (begin, count) of the window-count pass kept on chip
 #define SW_BACK  128                             // ... of which this many lie behind the tile being worked on
+#endif
 #define SW_MI    256
 #define SW_PEND  64
 #define SW_REP   64
