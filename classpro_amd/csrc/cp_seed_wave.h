@@ -236,6 +236,83 @@ __device__ __attribute__((noinline)) void sw_mark(const char *seq, const char *c
     }
 }
 
+// ---- the marks of ALL segments a selection took, at its end ---------------------------------------------------------
+// A take has two halves: the masked-interval list, which later takes of the same selection depend on, and the marks --
+// the segment's k-mers with the smallest canonical hash -- which nothing reads before the next selection starts.  Marked
+// one take at a time, a segment of a dozen k-mers costs the wave a cold load of its bases and a 40-step hash loop with
+// a fifth of the lanes working.  Here the takes only append (begin, end) to a list; at the end of the selection the
+// k-mers of all taken segments are laid side by side, a lane each whatever segment they belong to: 64 segments per
+// round, their lengths prefix-summed in LDS, a lane finds its segment by binary search, hashes its k-mer from the bases
+// directly (a 256-entry letter table, then the rotated-seed table) and joins its segment's minimum with an LDS atomic;
+// a second sweep marks the k-mers that attain it.
+struct sw_code_tab { uint8_t v[256]; };
+constexpr sw_code_tab sw_make_codes()
+{ sw_code_tab t{};
+  for (int c = 0; c < 256; c++)
+    { int f = 4, r = 4;                                      // seedTab / seedTab[c & cpOff], nthash.h:17,26-59,226-235
+      if (c == 'A' || c == 'a' || c == 4 || c == 5) f = 0;
+      else if (c == 'C' || c == 'c' || c == 7) f = 1;
+      else if (c == 'G' || c == 'g' || c == 3) f = 2;
+      else if (c == 'T' || c == 't' || c == 'U' || c == 'u' || c == 1) f = 3;
+      const int l = c & 7;
+      if (l == 1) r = 3; else if (l == 3) r = 2; else if (l == 4 || l == 5) r = 0; else if (l == 7) r = 1;
+      t.v[c] = (uint8_t)(f | (r << 3));
+    }
+  return t;
+}
+__device__ const sw_code_tab sw_CODE = sw_make_codes();
+
+__device__ __forceinline__ int sw_hash_at(const char *seq, int j, int K)
+{ if (K > SW_KMAX) return cp_kmer_hash(seq,j,K);
+  uint64_t fh = 0, rh = 0;
+  for (int t = 0; t < K; t++)
+    { const int code = sw_CODE.v[(unsigned char)seq[j+t]];
+      fh ^= sw_ROT.v[(code & 7)*SW_KMAX+(K-1-t)];
+      rh ^= sw_ROT.v[(code >> 3)*SW_KMAX+t];
+    }
+  return (int)((rh < fh ? rh : fh) % CP_SEED_MOD);
+}
+
+__device__ __attribute__((noinline)) void sw_mark_all(const char *seq, const char *cls, char *state, int K, const int32_t *takes,
+                                                      int ntake, bool rep, int lane)
+{ int32_t *s_pre = sw_S.pend_b, *s_min = sw_S.pend_e;        // (the pending-take buffers are idle here; SW_PEND >= 64)
+  static_assert(SW_PEND >= WAVE,"one slot per segment of a round");
+  for (int base = 0; base < ntake; base += WAVE)
+    { const int ns = ntake-base < WAVE ? ntake-base : WAVE;
+      int b = 0, len = 0;
+      if (lane < ns) { b = takes[2*(base+lane)]; len = takes[2*(base+lane)+1]-b; }
+      int incl = len;
+      for (int o = 1; o < WAVE; o <<= 1) { const int x = __shfl_up(incl,o); if (lane >= o) incl += x; }
+      const int total = __shfl(incl,WAVE-1);
+      __syncthreads();
+      s_pre[lane] = incl-len;                                // first k-mer slot of segment `lane`
+      s_min[lane] = CP_SEED_MOD;
+      __syncthreads();
+      // two sweeps: the segments' minima, then the marks
+      for (int pass = 0; pass < 2; pass++)
+        { for (int q0 = 0; q0 < total; q0 += WAVE)
+            { const int q = q0+lane;
+              const bool on = q < total;
+              int lo = 0;
+              if (on)
+                {
+#pragma unroll
+                  for (int step = WAVE/2; step > 0; step >>= 1)
+                    if (lo+step < ns && s_pre[lo+step] <= q) lo += step;
+                }
+              const int sb = __shfl(b,lo), so = on ? q-s_pre[lo] : 0;
+              if (on)
+                { const int j = sb+so;
+                  const int h = sw_hash_at(seq,j,K);
+                  if (pass == 0) atomicMin(&s_min[lo],h);
+                  else if (h == s_min[lo]) state[j] = rep ? 'R' : cls[j];
+                }
+            }
+          __syncthreads();
+        }
+    }
+}
+
 // ---- one selection (seed.c:190-476 with C = 'H'/'D'; seed.c:667-951 with C = 0) --------------------------------------
 // The window counts WITHOUT the deque.  The reference feeds the segments to a monotone deque one by one (seed.c:218-324 /
 // :694-810) and a segment's "number of windows" is decided when it leaves the deque.  When and how it leaves follows from
@@ -523,7 +600,7 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
     }
   SW_STAMP(5);
 #ifdef CP_SEED_PROF
-  if (lane == 0) { sw_t[6] += n; sw_t[7] += (plen+SW_STEP*WAVE-1)/(SW_STEP*WAVE); }
+  if (lane == 0) { sw_t[7] += n; }
 #endif
   if (M > 0 && Lm.b(0) == 0 && Lm.e(0) == plen) return;
   // ---- stable order by decreasing window count (the reference's qsort is glibc's stable merge sort): two 5-bit radix
@@ -581,10 +658,15 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
     }
   SW_STAMP(2);
   // ---- selection (wave-uniform control flow) ----
+  int ntake = 0;                                             // taken segments, listed in R.tmp (idle after the sort) and marked at the end
   auto take = [&](int b, int e)                              // mask the segment with a margin of W, mark its hash minimizers
     { if (!Lm.big && M+4 >= SW_MI) sw_mi_grow(Lm,R.cap+3,lane);
       M = sw_mi_add(Lm,M,b-W > 0 ? b-W : 0,e+W < plen ? e+W : plen,lane);
-      sw_mark(R.seq,R.cls,R.state,plen+Km1,R.K,b,e,rep,lane);
+      if (2*ntake+2 <= R.cap)
+        { if (lane == 0) { R.tmp[2*ntake] = b; R.tmp[2*ntake+1] = e; }
+          ntake++;
+        }
+      else sw_mark(R.seq,R.cls,R.state,plen+Km1,R.K,b,e,rep,lane);         // (no room in the list: marked on the spot)
     };
   int pos = 0;
   for (; pos < n; pos++)                                     // every segment that is extreme over a whole window
@@ -645,6 +727,15 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
       flush(pos);
     }
   SW_STAMP(4);
+  __syncthreads();                                           // lane 0's list of taken segments is visible to the wave
+  sw_mark_all(R.seq,R.cls,R.state,R.K,R.tmp,ntake,rep,lane);
+#ifdef CP_SEED_PROF
+  { int tk = 0; for (int q = lane; q < ntake; q += WAVE) tk += R.tmp[2*q+1]-R.tmp[2*q];
+    for (int o = 32; o > 0; o >>= 1) tk += __shfl_xor(tk,o);
+    if (lane == 0) { sw_t[6] += tk; }
+  }
+#endif
+  SW_STAMP(3);
   __syncthreads();                                           // the marks are visible to the next selection
 }
 

@@ -29,7 +29,7 @@ for it in range(3):
         L.cp_debug_seed_prof(out)
         print("   lane-0 ms per read (100 MHz ticks): anno %.3f  segments %.3f  window counts %.3f  sort %.3f  whole-window takes %.3f  group walk %.3f" %
               tuple(out[k] / b4.nreads / 1e5 for k in (0, 1, 5, 2, 3, 4)), flush=True)
-        print("   per read, summed over the three selections: segments %.0f  load steps %.0f" %
+        print("   per read, summed over the three selections: k-mers of taken segments %.0f  segments %.0f" %
               tuple(out[k] / b4.nreads for k in (6, 7)), flush=True)
     print("seeds pass %d: %.1f ms, %.1f Gbases/s (%d reads, %d bases); seeds %.4f" % (it, dt * 1e3, b4.total_bases / dt / 1e9, b4.nreads, b4.total_bases,
           float((seeds != ord("E")).float().mean())), flush=True)
