@@ -781,6 +781,16 @@ extern "C" int cp_seq_context(const char *d_seq, const int64_t *d_seq_off, int n
   return CP_OK;
 }
 
+#if defined(CP_SEED_DEBUG) || defined(CP_SEED_DEBUG_TAKES)
+extern "C" int cp_debug_seed_set(int read)
+{ HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_seed_dbg_read),&read,sizeof(int))); return CP_OK; }
+extern "C" int cp_debug_seed_get(int *out4, int *recs)
+{ HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out4,HIP_SYMBOL(g_seed_dbg_n),16));
+  HIPCHK(hipMemcpyFromSymbol(recs,HIP_SYMBOL(g_seed_dbg),8192*16));
+  return CP_OK;
+}
+#endif
 #ifdef CP_SEED_PROF
 // diagnostic builds only: wall-clock ticks (100 MHz) of lane 0 of every wave of k_find_seeds_fast per phase, then reset
 extern "C" int cp_debug_seed_prof(unsigned long long *out8)

@@ -34,8 +34,8 @@
 #include "cp_seed.h"
 
 #ifndef SW_RING
-#define SW_RING  512                             // segments (begin, count) of the window-count pass kept on chip
-#define SW_BACK  128                             // ... of which this many lie behind the tile being worked on
+#define SW_RING  256                             // records of the window-count pass kept on chip
+#define SW_BACK  64                              // ... of which this many lie behind the tile being worked on
 #endif
 #define SW_MI    256
 #define SW_PEND  64
@@ -44,7 +44,7 @@
 #define SW_STEP  4                               // chunks of 64 positions per load step
 
 struct cp_seedw_lds
-  { int2     ring[SW_RING];                      // (begin, count or -1) of the segments around the tile being worked on
+  { int4     ring[SW_RING];                      // records (begin, end, -, key+1) of the valid segments around the tile being worked on
     int32_t  mi_b[SW_MI], mi_e[SW_MI];           // masked-interval list while it fits
     int32_t  cval[SW_STEP*WAVE];                 // per position: the count if the k-mer is valid, else -1; base classes for the hash
     int32_t  bins[32];
@@ -63,6 +63,7 @@ struct cp_seedw_read
     int32_t *gmi_b, *gmi_e;                                             // cap+3 slots each
     int32_t *rep_pairs;
     int32_t *err;                                                       // bit 4: a read needed more segments than its scratch holds
+    int dbg_read;                                                       // (diagnostic builds) this is the read to dump
   };
 
 #ifdef CP_SEED_PROF
@@ -339,17 +340,23 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
 { const int W = rep ? CP_SEED_W_REP : CP_SEED_W;
   const int plen = R.plen, Km1 = R.K-1;
   const uint64_t lt = (1ull << lane)-1;
-  auto beats = [&](int a, int c) -> bool { return rep ? (a < c) : (a > c); };
-  int n = 0, M = 0, nbig = 0, endpos = plen;
-  bool grow = false, full = false;
-  // ---- segments (all lanes; seed.c:61-110 / :599-665 in closed form): record i = (begin, -, -, count+1) ----
+  int n = 0, M = 0, nbig = 0, endpos = plen, b_last = 0;
+  // ---- segments (seed.c:61-110 / :599-665 in closed form) ----
   // valid(i): the k-mer takes part in this selection.  A valid segment is a run of equal counts from its first valid
-  // k-mer on (it may run on over k-mers of other classes); the k-mers skipped between segments form invalid ones
-  // (count -1).  A segment that would start at the last k-mer is never made (the reference's loop ends first).
+  // k-mer on (it may run on over k-mers of other classes); the k-mers skipped between segments form invalid ones.  A
+  // segment that would start at the last k-mer is never made (the reference's loop ends first).
+  // Per 64 k-mers the lanes only produce two masks -- run boundaries, valid k-mers -- and the segment starts come out of
+  // them with scalar bit operations, the same for every lane: a segmented OR-scan ("this run already holds a valid
+  // k-mer") in six shift-and-mask steps.  The VALID segments get records of their own, (begin, end, -, key+1) at
+  // R.rec[0..n), the skipped stretches go to a side list (R.orec) and from there to the masked-interval list: the window
+  // counts, the sort and the walk then only see valid segments.  Two skipped stretches are never adjacent, so a valid
+  // segment's predecessor of either kind is known from its valid predecessor's begin and end.
   { bool carry = false;                                      // the run entering the chunk already holds a valid k-mer
-    int last_start = -1;
-    // the loads of a step are issued one step ahead
-    int ncnt[SW_STEP], ncpv[SW_STEP]; char ncl[SW_STEP], nst[SW_STEP];
+    int nv = 0, ni = 0;                                      // valid / skipped segments so far
+    int lpos = -1, ltype = 0, lidx = 0;                      // the last segment start so far: position, valid?, its index
+    int ri = 0;                                              // (repeats) first repetitive stretch that ends beyond the chunk start
+    int prevc = -1;                                          // count of the k-mer before the chunk
+    int ncnt[SW_STEP]; char ncl[SW_STEP], nst[SW_STEP];      // a step's loads are issued one step ahead
     auto load_step = [&](int e0)
       {
 #pragma unroll
@@ -357,75 +364,116 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
           { const int p = e0+u*WAVE+lane;
             const bool in = p < plen;
             ncnt[u] = in ? (int)R.prof[p] : 0;
-            ncpv[u] = (in && p > 0) ? (int)R.prof[p-1] : -1;
             ncl[u] = in ? R.cls[p] : (char)0;
             nst[u] = (in && rep) ? R.state[p] : (char)'E';
           }
       };
     load_step(0);
     for (int e0 = 0; e0 < plen; e0 += SW_STEP*WAVE)
-      { int cnt[SW_STEP], cpv[SW_STEP]; char cl[SW_STEP], st[SW_STEP];
+      { int cnt[SW_STEP]; char cl[SW_STEP], st[SW_STEP];
 #pragma unroll
-        for (int u = 0; u < SW_STEP; u++) { cnt[u] = ncnt[u]; cpv[u] = ncpv[u]; cl[u] = ncl[u]; st[u] = nst[u]; }
+        for (int u = 0; u < SW_STEP; u++) { cnt[u] = ncnt[u]; cl[u] = ncl[u]; st[u] = nst[u]; }
         if (e0+SW_STEP*WAVE < plen) load_step(e0+SW_STEP*WAVE);
 #pragma unroll
         for (int u = 0; u < SW_STEP; u++)
-          { const int p = e0+u*WAVE+lane;
+          { const int c0 = e0+u*WAVE, p = c0+lane;
+            if (c0 >= plen) break;
             const bool in = p < plen;
-            const bool bnd = in && cnt[u] != cpv[u];
-            bool v = false;
-            if (in)
-              { if (!rep) v = cl[u] == (char)C;
-                else if (cl[u] != 'E' && st[u] == 'E')       // a non-E k-mer without a seed yet, inside a repetitive stretch
-                  { int lo = 0, hi = nrep;                   // first stretch that ends beyond p
-                    while (lo < hi)
-                      { const int m = (lo+hi) >> 1;
-                        const int re = rep_big ? R.rep_pairs[2*m+1]-Km1 : sw_S.rep[2*m+1];
-                        if (re <= p) lo = m+1; else hi = m;
-                      }
-                    v = lo < nrep && (rep_big ? R.rep_pairs[2*lo]-Km1 : sw_S.rep[2*lo]) <= p;
+            int cpv = __shfl_up(cnt[u],1);
+            if (lane == 0) cpv = prevc;
+            prevc = __shfl(cnt[u],WAVE-1);
+            uint64_t rmask = ~0ull;
+            if (rep)                                         // the chunk's k-mers inside repetitive stretches (scalar: the stretches are sorted)
+              { rmask = 0;
+                while (ri < nrep)
+                  { const int rb = rep_big ? R.rep_pairs[2*ri]-Km1 : sw_S.rep[2*ri], re = rep_big ? R.rep_pairs[2*ri+1]-Km1 : sw_S.rep[2*ri+1];
+                    if (rb >= c0+WAVE) break;
+                    const int lo = rb > c0 ? rb-c0 : 0, hi = re < c0+WAVE ? re-c0 : WAVE;      // [lo,hi) of the chunk
+                    if (hi > lo) rmask |= (hi == WAVE ? ~0ull : ((1ull << hi)-1)) & ~((1ull << lo)-1);
+                    if (re <= c0+WAVE) ri++; else break;
                   }
               }
+            const bool bnd = in && cnt[u] != cpv;
+            const bool v = in && (rep ? (cl[u] != 'E' && st[u] == 'E' && ((rmask >> lane) & 1)) : cl[u] == (char)C);
+            const uint64_t inm = plen-c0 >= WAVE ? ~0ull : ((1ull << (plen-c0))-1);
             const uint64_t bm = __ballot(bnd), vm = __ballot(v);
-            const uint64_t le = lt | (1ull << lane);
-            bool first_valid = false, prev_has = false;
-            if (v)
-              { const uint64_t bb = bm & le;                 // my run starts at the highest boundary at or below me
-                if (bb) { const int rb = 63-__clzll((long long)bb); first_valid = (vm & lt & ~((1ull << rb)-1)) == 0; }
-                else first_valid = !carry && (vm & lt) == 0;
+            // hv: the run of a k-mer holds a valid k-mer at or before it (segmented OR-scan of vm, runs start at bm)
+            uint64_t hv = vm;
+            if (carry) hv |= bm ? ((bm & (0-bm))-1) : ~0ull;
+            { uint64_t B = ~bm;
+              hv |= (hv << 1) & B;  B &= B << 1;
+              hv |= (hv << 2) & B;  B &= B << 2;
+              hv |= (hv << 4) & B;  B &= B << 4;
+              hv |= (hv << 8) & B;  B &= B << 8;
+              hv |= (hv << 16) & B; B &= B << 16;
+              hv |= (hv << 32) & B;
+            }
+            const uint64_t hvs = (hv << 1) | (carry ? 1ull : 0ull);       // the same one k-mer earlier
+            // a k-mer starts a segment iff it is the first valid one of its run, or it begins a run whose predecessor run
+            // held a valid k-mer, or it is the read's first
+            const uint64_t sm = inm & ((vm & ~(hvs & ~bm)) | (bm & hvs) | (c0 == 0 ? 1ull : 0ull));
+            carry = (hv >> 63) != 0;
+            const uint64_t vs = sm & vm, is = sm & ~vm;      // valid / skipped segments starting here
+            if ((sm >> lane) & 1)
+              { const bool mv = (vm >> lane) & 1;
+                const int idx = mv ? nv+__popcll(vs & lt) : ni+__popcll(is & lt);
+                // the segment before mine ends where mine begins
+                const uint64_t below = sm & lt;
+                int ptype = ltype, pidx = lidx, ppos = lpos;
+                if (below)
+                  { const int pl = 63-__clzll((long long)below);
+                    const uint64_t blt = (1ull << pl)-1;
+                    ptype = (int)((vm >> pl) & 1);
+                    pidx = ptype ? nv+__popcll(vs & blt) : ni+__popcll(is & blt);
+                    ppos = c0+pl;
+                  }
+                if (ppos >= 0 && pidx < R.cap) { if (ptype) R.rec[pidx].y = p; else R.orec[pidx].y = p; }
+                if (idx < R.cap)
+                  { if (mv) { R.rec[idx].x = p; R.rec[idx].w = (rep ? 32767-cnt[u] : cnt[u])+1; }
+                    else R.orec[idx].x = p;
+                  }
               }
-            if (bnd)
-              { const uint64_t bb = bm & lt;                 // the run before mine
-                if (bb) { const int rb = 63-__clzll((long long)bb); prev_has = (vm & lt & ~((1ull << rb)-1)) != 0; }
-                else prev_has = carry || (vm & lt) != 0;
+            if (sm)
+              { const int top = 63-__clzll((long long)sm);
+                const uint64_t blt = (1ull << top)-1;
+                lpos = c0+top; ltype = (int)((vm >> top) & 1);
+                lidx = ltype ? nv+__popcll(vs & blt) : ni+__popcll(is & blt);
+                nv += __popcll(vs); ni += __popcll(is);
               }
-            const bool start = in && (p == 0 || first_valid || (bnd && prev_has));
-            const uint64_t sm = __ballot(start);
-            if (bm) { const int top = 63-__clzll((long long)bm); carry = (vm & ~((1ull << top)-1)) != 0; }
-            else carry = carry || vm != 0;
-            if (start)                                       // the segment that starts here: its number is a popcount away
-              { const int idx = n+__popcll(sm & lt);
-                if (idx < R.cap) R.rec[idx] = make_int4(p,0,0,(v ? cnt[u] : -1)+1);
-              }
-            if (sm) last_start = e0+u*WAVE+63-__clzll((long long)sm);
-            n += __popcll(sm);
           }
       }
-    if (n > 0 && last_start >= plen-1) { n--; endpos = plen-1; }   // a segment at the last k-mer is never made: it only ends its predecessor
-    full = n > R.cap;                                        // (k_seed_caps sizes the scratch; reported, never written past)
+    if (lpos >= 0 && lpos >= plen-1)                         // a segment at the last k-mer is never made: it only ends its predecessor
+      { if (ltype) nv--; else ni--;
+        endpos = plen-1;
+      }
+    else if (lpos >= 0 && lane == 0 && lidx < R.cap)         // the last segment runs to the end of the read
+      { if (ltype) R.rec[lidx].y = plen; else R.orec[lidx].y = plen; }
+    n = nv; M = ni;
+    b_last = lpos >= plen-1 ? -1 : lpos;                     // begin of the last segment of either kind (-1: see below)
+    __syncthreads();                                         // the records are visible to the wave
+    if (nv > R.cap || ni > R.cap) { if (lane == 0) atomicOr(R.err,4); return; }   // (k_seed_caps sizes the scratch; reported, never written past)
+    if (lpos >= plen-1)                                      // the dropped start's predecessor is the last segment
+      { int bl = -1;
+        if (nv > 0) bl = R.rec[nv-1].x;
+        if (ni > 0) { const int x = R.orec[ni-1].x; bl = x > bl ? x : bl; }
+        b_last = bl;
+      }
+    // the skipped stretches are masked from the start: slots 0..M-1 of the list (on chip while M+3 < SW_MI)
+    if (!Lm.big && M+3 >= SW_MI) sw_mi_grow(Lm,R.cap+3,lane);
+    for (int q = lane; q < M; q += WAVE) { const int4 t = R.orec[q]; Lm.set(q,t.x,t.y); }
+    __syncthreads();
   }
-  __syncthreads();                                           // the records are visible to the wave
-  if (full) { if (lane == 0) atomicOr(R.err,4); return; }
   SW_STAMP(1);
-  // ---- window counts, 64 segments at a time ----
-  { int ring_hi = 0;                                         // segments [ring_hi-SW_RING, ring_hi) are in the ring
-    auto seg = [&](int j) -> int2                            // (begin, count) of segment j; j == n: the end of the read
-      { if (j >= n) return make_int2(endpos,-1);
-        if (j < ring_hi && j >= ring_hi-SW_RING) return sw_S.ring[j & (SW_RING-1)];
-        const int4 t = R.rec[j];
-        return make_int2(t.x,t.w-1);
+  // ---- window counts, 64 valid segments at a time ----
+  // key = count (H/D) or 32767 - count (repeats): both selections look for the larger key.  pb(j): the begin of j's
+  // predecessor of either kind; j is still within reach of i (j <= x(i)) iff pb(j) < b(i)+W.
+  { constexpr int NONE = -(1 << 30);
+    int ring_hi = 0;                                         // records [ring_hi-SW_RING, ring_hi) are in the ring: (begin, end, -, key+1)
+    auto seg = [&](int j) -> int4
+      { if (j < ring_hi && j >= ring_hi-SW_RING) return sw_S.ring[j & (SW_RING-1)];
+        return R.rec[j];
       };
-    bool c_have = false; int c_x = 0, c_lw = -1, c_pos = 0;  // carried: the last expiring segment's x, the last wipe, last_oor_pos
+    bool c_have = false, c_wipe = false; int c_expb = 0, c_wpb = 0, c_pos = 0;   // carried: begin of the last expiring segment, pb of the last wipe, last_oor_pos
     for (int t0 = 0; t0 < n; t0 += WAVE)
       { { int upto = t0+SW_RING-SW_BACK;                     // the ring covers [t0-SW_BACK, t0+SW_RING-SW_BACK)
           if (upto > n) upto = n;
@@ -433,7 +481,7 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
             { __syncthreads();                               // (the slots being replaced are no longer read)
               while (ring_hi < upto)
                 { const int j = ring_hi+lane;
-                  if (j < upto) { const int4 t = R.rec[j]; sw_S.ring[j & (SW_RING-1)] = make_int2(t.x,t.w-1); }
+                  if (j < upto) sw_S.ring[j & (SW_RING-1)] = R.rec[j];
                   ring_hi = ring_hi+WAVE < upto ? ring_hi+WAVE : upto;
                 }
               __syncthreads();
@@ -441,163 +489,143 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
         }
         const int i = t0+lane;
         const bool act = i < n;
-        const int2 me = act ? seg(i) : make_int2(endpos,-1);
-        const int bi = me.x, ci = me.y;
-        const bool valid = act && ci >= 0;
-        const int ei = act ? seg(i+1).x : endpos;            // the segment's end = the next one's begin
-        // -- forward: the first valid segment in (i, x] that beats i; else x, and what else (i, x] holds --
-        int g = -1, bg = 0, bgm1 = 0, x = n;
-        bool eq = false, nonempty = false, fdone = !valid;
-        { int j = i+1, pb = bi;                              // pb: begin of segment j-1
-          for (int step = 0; step < 8 && !fdone; step++)
-            { if (j >= n) { x = n; fdone = true; break; }
-              const int2 s = seg(j);
-              if (s.y >= 0)
-                { if (beats(s.y,ci)) { g = j; bg = s.x; bgm1 = pb; fdone = true; break; }
-                  nonempty = true;
-                  if (s.y == ci) eq = true;
-                }
-              if (s.x >= bi+W) { x = j; fdone = true; break; }
-              pb = s.x; j++;
+        int4 me = make_int4(0,0,0,0);
+        if (act) me = seg(i);
+        const int bi = me.x, ei = me.y, ki = me.w-1;
+        int pbi = NONE;                                      // begin of my predecessor of either kind
+        if (act) { if (i > 0) { const int4 q = seg(i-1); pbi = q.y == bi ? q.x : q.y; } else if (bi > 0) pbi = 0; }
+        // -- forward: the first segment within reach that beats me; else what the reach holds --
+        int g = -1, bg = 0, pbg = 0;
+        bool eq = false, nonempty = false, fdone = !act;
+        { int pbv = bi, pev = ei;                            // begin / end of segment j-1
+          for (int step = 1; step <= 16; step++)
+            { const int j = i+step;
+              const bool more = !fdone && j < n;
+              int4 sj = make_int4(0,0,0,0);
+              if (more) sj = seg(j);
+              const int pbj = pev == sj.x ? pbv : pev;
+              const bool reach = more && pbj < bi+W;
+              const bool beat = reach && sj.w-1 > ki;
+              if (beat) { g = j; bg = sj.x; pbg = pbj; }
+              if (reach && !beat) { nonempty = true; eq = eq || sj.w-1 == ki; }
+              fdone = fdone || !reach || beat;
+              pbv = sj.x; pev = sj.y;
+              if (__ballot(!fdone) == 0) break;
             }
-          // the long searches, one at a time, 64 window segments per step
+          // searches still open, one at a time, 64 segments per step
           for (uint64_t um = __ballot(!fdone); um; um &= um-1)
             { const int src = __ffsll((long long)um)-1;
-              const int si = __shfl(i,src), sb = __shfl(bi,src), sc = __shfl(ci,src);
-              int j0 = __shfl(j,src);
+              const int si = __shfl(i,src), sb = __shfl(bi,src), sk = __shfl(ki,src);
               bool seq = __shfl(eq ? 1 : 0,src) != 0, sne = __shfl(nonempty ? 1 : 0,src) != 0;
-              int rg = -1, rbg = 0, rbgm1 = 0, rx = n;
-              (void)si;
-              while (true)
+              int rg = -1, rbg = 0, rpbg = 0;
+              for (int j0 = si+17; ; j0 += WAVE)
                 { const int jj = j0+lane;
-                  const int2 s = seg(jj);                    // (plen, -1) from n on
-                  const bool vj = jj < n && s.y >= 0;
-                  const uint64_t mB = __ballot(vj && beats(s.y,sc));
-                  const uint64_t mL = __ballot(jj >= n || s.x >= sb+W);
-                  const uint64_t mV = __ballot(vj), mE = __ballot(vj && s.y == sc);
-                  const int fb = mB ? __ffsll((long long)mB)-1 : WAVE, fl = mL ? __ffsll((long long)mL)-1 : WAVE;
-                  if (fb <= fl && fb < WAVE)                 // beaten first (a beater AT x still beats: it is pushed before the expiry)
-                    { rg = j0+fb;
-                      rbg = __shfl(s.x,fb);
-                      rbgm1 = fb > 0 ? __shfl(s.x,fb-1) : seg(j0-1).x;
+                  int4 sj = make_int4(0,0,0,0), sp = make_int4(0,0,0,0);
+                  if (jj < n) { sj = seg(jj); sp = seg(jj-1); }
+                  const int pbj = sp.y == sj.x ? sp.x : sp.y;
+                  const bool reach = jj < n && pbj < sb+W;   // (monotone: begins grow)
+                  const uint64_t mR = __ballot(reach), mB = __ballot(reach && sj.w-1 > sk), mE = __ballot(reach && sj.w-1 == sk);
+                  if (mB)
+                    { const int fb = __ffsll((long long)mB)-1;
+                      const uint64_t blt = (1ull << fb)-1;
+                      rg = j0+fb; rbg = __shfl(sj.x,fb); rpbg = __shfl(pbj,fb);
+                      sne = sne || (mR & blt) != 0; seq = seq || (mE & blt) != 0;
                       break;
                     }
-                  if (fl < WAVE)
-                    { const uint64_t upto = fl == 63 ? ~0ull : ((2ull << fl)-1);
-                      rx = j0+fl < n ? j0+fl : n;
-                      sne = sne || (mV & upto) != 0; seq = seq || (mE & upto) != 0;
-                      break;
-                    }
-                  sne = sne || mV != 0; seq = seq || mE != 0;
-                  j0 += WAVE;
+                  sne = sne || mR != 0; seq = seq || mE != 0;
+                  if (mR != ~0ull) break;                    // the reach ended inside these 64
                 }
-              if (lane == src) { g = rg; bg = rbg; bgm1 = rbgm1; x = rx; eq = seq; nonempty = sne; fdone = true; }
+              if (lane == src) { g = rg; bg = rbg; pbg = rpbg; eq = seq; nonempty = sne; fdone = true; }
             }
         }
-        // -- backward: what the deque holds when segment i arrives (segments beginning beyond b(i-1)-W): does any of
-        //    them match or beat i (then i wipes nothing), and where does the nearest one that beats i begin --
-        bool blocked = false, bnon = false, bdone = !valid || i == 0, havep = false;
+        // -- backward: what the deque holds when I arrive (segments beginning beyond pb(me)-W): does any of them match
+        //    or beat me (then I wipe nothing), and where does the nearest one that beats me begin --
+        bool blocked = false, bnon = false, havep = false, bdone = !act || pbi == NONE;
         int pbeg = 0;
-        const int limw = (act && i > 0) ? seg(i-1).x-W : 0;
-        { int j = i-1;
-          for (int step = 0; step < 8 && !bdone; step++)
-            { if (j < 0) { bdone = true; break; }
-              const int2 s = seg(j);
-              if (s.x <= limw) { bdone = true; break; }
-              if (s.y >= 0)
-                { bnon = true;
-                  if (!beats(ci,s.y)) blocked = true;
-                  if (beats(s.y,ci)) { havep = true; pbeg = s.x; bdone = true; break; }
-                  if (blocked && g < 0) { bdone = true; break; }         // an expiring segment only needs to know that it wipes nothing
-                }
-              j--;
+        const int limw = pbi-W;
+        { for (int step = 1; step <= 16; step++)
+            { const int j = i-step;
+              const bool more = !bdone && j >= 0;
+              int4 sj = make_int4(0,0,0,0);
+              if (more) sj = seg(j);
+              const bool inw = more && sj.x > limw;
+              const bool better = inw && sj.w-1 > ki;
+              if (inw) { bnon = true; blocked = blocked || sj.w-1 >= ki; }
+              if (better) { havep = true; pbeg = sj.x; }
+              bdone = bdone || !inw || better || (blocked && g < 0);   // an expiring segment only needs to know that it wipes nothing
+              if (__ballot(!bdone) == 0) break;
             }
           for (uint64_t um = __ballot(!bdone); um; um &= um-1)
             { const int src = __ffsll((long long)um)-1;
-              const int sc = __shfl(ci,src), slim = __shfl(limw,src), sg = __shfl(g,src);
-              int j0 = __shfl(j,src);
+              const int si = __shfl(i,src), sk = __shfl(ki,src), slim = __shfl(limw,src), sg = __shfl(g,src);
               bool sbl = __shfl(blocked ? 1 : 0,src) != 0, sbn = __shfl(bnon ? 1 : 0,src) != 0, shp = false;
               int spb = 0;
-              while (true)
+              for (int j0 = si-17; ; j0 -= WAVE)
                 { const int jj = j0-lane;
-                  int2 s = make_int2(0,-1);
-                  if (jj >= 0) s = seg(jj);
-                  const bool out = jj < 0 || s.x <= slim;
-                  const bool vj = !out && s.y >= 0;
-                  const uint64_t mO = __ballot(out), mS = __ballot(vj && beats(s.y,sc));
-                  const uint64_t mN = __ballot(vj && !beats(sc,s.y)), mV = __ballot(vj);
-                  const int fo = mO ? __ffsll((long long)mO)-1 : WAVE, fs = mS ? __ffsll((long long)mS)-1 : WAVE;
-                  if (fs < fo)                               // the nearest segment that beats i is still in the deque
-                    { shp = true; spb = __shfl(s.x,fs); sbl = true; sbn = true; break; }
-                  if (fo < WAVE)
-                    { const uint64_t upto = (1ull << fo)-1;
-                      sbn = sbn || (mV & upto) != 0; sbl = sbl || (mN & upto) != 0;
+                  int4 sj = make_int4(0,0,0,0);
+                  if (jj >= 0) sj = seg(jj);
+                  const bool inw = jj >= 0 && sj.x > slim;   // (monotone)
+                  const uint64_t mI = __ballot(inw), mS = __ballot(inw && sj.w-1 > sk), mN = __ballot(inw && sj.w-1 >= sk);
+                  if (mS)
+                    { const int fs = __ffsll((long long)mS)-1;
+                      shp = true; spb = __shfl(sj.x,fs); sbl = true; sbn = true;
                       break;
                     }
-                  sbn = sbn || mV != 0; sbl = sbl || mN != 0;
-                  if (sbl && sg < 0) break;
-                  j0 -= WAVE;
+                  sbn = sbn || mI != 0; sbl = sbl || mN != 0;
+                  if (mI != ~0ull || (sbl && sg < 0)) break;
                 }
               if (lane == src) { blocked = sbl; bnon = sbn; havep = shp; pbeg = spb; bdone = true; }
             }
         }
         // -- values --
-        const bool wipe = valid && bnon && !blocked;
-        const bool isexp = valid && g < 0;
-        const bool flag = isexp && nonempty && !eq && !(rep && x == n);
-        int nw = -10;
+        const bool wipe = act && bnon && !blocked;
+        const bool isexp = act && g < 0;
+        const bool flag = isexp && nonempty && !eq && !(rep && b_last < bi+W);
+        int nw = 0;
         bool big = false;
-        if (valid && g >= 0)
-          { if (havep && pbeg > bgm1-W)
-              { nw = rep ? (CP_SEED_W_REP-ci > 0 ? CP_SEED_W_REP-ci : 0) : ci; big = nw > 1000; }
+        if (act && g >= 0)
+          { if (havep && pbeg > pbg-W)
+              { const int ci = rep ? 32767-ki : ki;
+                nw = rep ? (CP_SEED_W_REP-ci > 0 ? CP_SEED_W_REP-ci : 0) : ci; big = nw > 1000;
+              }
             else { nw = bg-bi; if (nw > W) nw = W; }
           }
         const uint64_t EM = __ballot(isexp), WM = __ballot(wipe), FM = __ballot(flag);
         { const uint64_t pe = EM & lt, pw = WM & (lt | (1ull << lane)), pf = FM & lt;
-          const int se = pe ? 63-__clzll((long long)pe) : 0, sf = pf ? 63-__clzll((long long)pf) : 0;
-          const int xprev = __shfl(x,se), eprev = __shfl(ei,sf);
+          const int se = pe ? 63-__clzll((long long)pe) : 0, sw = pw ? 63-__clzll((long long)pw) : 0, sf = pf ? 63-__clzll((long long)pf) : 0;
+          const int bprev = __shfl(bi,se), wpb = __shfl(pbi,sw), eprev = __shfl(ei,sf);
           if (isexp)
             { const bool have = pe ? true : c_have;
-              const int xp = pe ? xprev : c_x;
-              const int lw = pw ? t0+63-__clzll((long long)pw) : c_lw;
+              const int xb = pe ? bprev : c_expb;            // begin of the previous expiring segment
+              const bool hw = pw ? true : c_wipe;
+              const int lwpb = pw ? wpb : c_wpb;             // pb of the last wipe up to me
               const int pos = pf ? eprev : c_pos;
-              const bool oor = have && !(lw > xp);
+              const bool oor = have && !(hw && lwpb >= xb+W);    // no wipe after that segment's expiry step
               nw = W;
               if (oor) { nw = bi-pos+1; if (nw > W) nw = W; }
             }
-          if (EM) { c_have = true; c_x = __shfl(x,63-__clzll((long long)EM)); }
-          if (WM) c_lw = t0+63-__clzll((long long)WM);
+          if (EM) { c_have = true; c_expb = __shfl(bi,63-__clzll((long long)EM)); }
+          if (WM) { c_wipe = true; c_wpb = __shfl(pbi,63-__clzll((long long)WM)); }
           if (FM) c_pos = __shfl(ei,63-__clzll((long long)FM));
         }
         nbig += __popcll(__ballot(big));
-        if (act) R.rec[i] = make_int4(bi,ei,nw,ci+1);
-        // -- skipped stretches are masked from the start (seed.c: the list before the selection's takes) --
-        { const bool inv = act && !valid;
-          const uint64_t IM = __ballot(inv);
-          const int m = M+__popcll(IM & lt);
-          const bool ok = Lm.big || m+4 < SW_MI;             // no room on chip: they are listed again, in HBM, after the pass
-          if (__ballot(inv && !ok)) grow = true;
-          if (inv && ok) Lm.set(m,bi,ei);
-          M += __popcll(IM);
-        }
+        if (act) R.rec[i].z = nw;
       }
   }
-  __syncthreads();                                           // the segment records are visible to the wave
-  n = sw_first(n); nbig = sw_first(nbig); M = sw_first(M);   // (wave-uniform already)
-  if (sw_first(grow ? 1 : 0))                                // the skipped stretches did not fit on chip: the list moves to HBM
-    { sw_mi_grow(Lm,R.cap+3,lane);                           // (slots not yet rewritten keep the earlier selections' leftovers)
-      int k = 0;
-      for (int base = 0; base < n; base += WAVE)             // and every skipped stretch is listed again, in order
-        { const int q = base+lane;
-          int4 t = make_int4(0,0,0,0);
-          if (q < n) t = R.rec[q];
-          const bool inv = q < n && t.z == -10;
-          const uint64_t im = __ballot(inv);
-          if (inv) { const int s = k+__popcll(im & lt); Lm.gb[s] = t.x; Lm.ge[s] = t.y; }
-          k += __popcll(im);
-        }
-      __syncthreads();
+  // The skipped stretches join the records after all, behind the valid segments, with the reference's -10: the sort
+  // puts them last (in their own order: it is stable), and the walk does reach them when the read is still uncovered --
+  // the reference then tests them against its list like any segment, and its search of that list, one slot past the
+  // live part, can miss the very interval they were masked with (tests/golden/seeds.npz holds such reads).
+  if (n+M > R.cap) { if (lane == 0) atomicOr(R.err,4); return; }
+  for (int q = lane; q < M; q += WAVE) { const int4 t = R.orec[q]; R.rec[n+q] = make_int4(t.x,t.y,-10,0); }
+  n += M;
+  __syncthreads();                                           // the window counts are visible to the wave
+#ifdef CP_SEED_DEBUG
+  if (R.dbg_read && rep)                                     // diagnostic builds: the repeat selection's records of one read
+    { for (int q = lane; q < n && q < 8192; q += WAVE) g_seed_dbg[q] = R.rec[q];
+      if (lane == 0) { g_seed_dbg_n[0] = n; g_seed_dbg_n[1] = M; g_seed_dbg_n[2] = b_last; g_seed_dbg_n[3] = nrep; }
     }
+#endif
   SW_STAMP(5);
 #ifdef CP_SEED_PROF
   if (lane == 0) { sw_t[7] += n; }
@@ -728,6 +756,13 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
     }
   SW_STAMP(4);
   __syncthreads();                                           // lane 0's list of taken segments is visible to the wave
+#ifdef CP_SEED_DEBUG_TAKES
+  if (R.dbg_read && rep)
+    { int *d = (int *)g_seed_dbg;
+      for (int q = lane; q < 2*ntake && q < 4*8192; q += WAVE) d[q] = R.tmp[q];
+      if (lane == 0) { g_seed_dbg_n[0] = ntake; g_seed_dbg_n[1] = M; g_seed_dbg_n[2] = n; g_seed_dbg_n[3] = 0; }
+    }
+#endif
   sw_mark_all(R.seq,R.cls,R.state,R.K,R.tmp,ntake,rep,lane);
 #ifdef CP_SEED_PROF
   { int tk = 0; for (int q = lane; q < ntake; q += WAVE) tk += R.tmp[2*q+1]-R.tmp[2*q];

@@ -2197,6 +2197,11 @@ k_seed_prefix(const int64_t *__restrict__ seq_off, int K, int nreads, char *__re
 #ifdef CP_SEED_PROF
 __device__ unsigned long long g_seed_prof[8];
 #endif
+#if defined(CP_SEED_DEBUG) || defined(CP_SEED_DEBUG_TAKES)
+__device__ int4 g_seed_dbg[8192];
+__device__ int g_seed_dbg_n[4];
+__device__ int g_seed_dbg_read;
+#endif
 #include "cp_seed_wave.h"
 // One wave per read (cp_seed_wave.h).
 #ifndef SW_WAVES
@@ -2218,6 +2223,10 @@ k_find_seeds(const char *__restrict__ seq, const int64_t *__restrict__ seq_off, 
   R.rec = (int4 *)seg+o; R.orec = (int4 *)seg+totalS+o; R.tmp = aux+o;
   R.gmi_b = mi+2*(o+3*(int64_t)r); R.gmi_e = R.gmi_b+R.cap+3;
   R.rep_pairs = rep_pairs+2*roff[r]; R.rep_cap = (int)(roff[r+1]-roff[r]); R.err = err;
+  R.dbg_read = 0;
+#if defined(CP_SEED_DEBUG) || defined(CP_SEED_DEBUG_TAKES)
+  R.dbg_read = (r == g_seed_dbg_read) ? 1 : 0;
+#endif
 #ifdef CP_SEED_PROF
   unsigned long long sw_t[8] = {0,0,0,0,0,0,0,0}, sw_last = wall_clock64();
   const int n = sw_find_seeds(R,lane,sw_t,sw_last);

@@ -116,6 +116,77 @@ def closed_form(b, c, plen, W, rep):
     return nw
 
 
+def closed_form_compact(b, c, plen, W, rep):
+    """the same on the VALID segments alone (what the device does): a valid segment carries its begin, its end (= the
+    begin of the next segment of either kind) and its key; the begin of its predecessor of either kind follows from its
+    valid predecessor (two skipped stretches are never adjacent); every index comparison of closed_form becomes a
+    comparison of begins."""
+    N = len(b)
+    bb = b + [plen]
+    key = (lambda v: 32767 - v) if rep else (lambda v: v)
+    standin = (lambda v: max(W - v, 0)) if rep else (lambda v: v)
+    V = [i for i in range(N) if c[i] >= 0]
+    vb, ve, vk = [b[i] for i in V], [bb[i + 1] for i in V], [key(c[i]) for i in V]
+    nv = len(V)
+    b_last = b[N - 1] if N else 0
+    NONE = -10 ** 9
+
+    def pb(v):                                  # begin of the predecessor segment of either kind, NONE if there is none
+        if v > 0:
+            return vb[v - 1] if ve[v - 1] == vb[v] else ve[v - 1]
+        return 0 if vb[0] > 0 else NONE
+    out = [None] * N
+    is_exp, flag, wipe, nwv = [False] * nv, [False] * nv, [False] * nv, [None] * nv
+    for v in range(nv):
+        g, eq, nonempty = -1, False, False
+        j = v + 1
+        while j < nv and pb(j) < vb[v] + W:      # j <= x(v)
+            if vk[j] > vk[v]:
+                g = j
+                break
+            nonempty = True
+            if vk[j] == vk[v]:
+                eq = True
+            j += 1
+        blocked, back_nonempty, p_b = False, False, None
+        if pb(v) != NONE:
+            lim = pb(v) - W
+            j = v - 1
+            while j >= 0 and vb[j] > lim:
+                back_nonempty = True
+                if vk[j] >= vk[v]:
+                    blocked = True
+                if vk[j] > vk[v]:
+                    p_b = vb[j]
+                    break
+                j -= 1
+        wipe[v] = back_nonempty and not blocked
+        if g >= 0:
+            nwv[v] = standin(c[V[v]]) if (p_b is not None and p_b > pb(g) - W) else min(vb[g] - vb[v], W)
+        else:
+            is_exp[v] = True
+            endflush = b_last < vb[v] + W
+            flag[v] = nonempty and not eq and not (rep and endflush)
+    have, last_exp_b, last_wipe_pb, pos = False, 0, None, 0
+    for v in range(nv):
+        if wipe[v]:
+            last_wipe_pb = pb(v)
+        if is_exp[v]:
+            oor = have and not (last_wipe_pb is not None and last_wipe_pb >= last_exp_b + W)
+            nwv[v] = min(vb[v] - pos + 1, W) if oor else W
+            have, last_exp_b = True, vb[v]
+            if flag[v]:
+                pos = ve[v]
+    for v in range(nv):
+        out[V[v]] = nwv[v]
+    return out
+
+
+def device_like(c):
+    """the device's segment sequences never hold two skipped stretches in a row"""
+    return all(not (c[i] < 0 and c[i + 1] < 0) for i in range(len(c) - 1))
+
+
 def trial(rng, N, W, rep):
     b, p = [], 0
     for _ in range(N):
@@ -124,10 +195,20 @@ def trial(rng, N, W, rep):
     plen = p
     hi = rng.choice([2, 3, 5, 40, 2000])
     c = [(-1 if rng.random() < rng.choice([0.0, 0.1, 0.5]) else rng.randrange(hi)) for _ in range(N)]
+    if rng.random() < 0.7:                       # mostly sequences as the device makes them: no two skipped stretches in a row
+        for i in range(1, N):
+            if c[i] < 0 and c[i - 1] < 0:
+                c[i] = rng.randrange(hi)
     a, z = simulate(b, c, plen, W, rep), closed_form(b, c, plen, W, rep)
+    if a == z and device_like(c):
+        z = closed_form_compact(b, c, plen, W, rep)
+        trial.compact += 1
     if a != z:
         k = next(i for i in range(N) if a[i] != z[i])
         raise SystemExit("MISMATCH at segment %d: reference %r, closed form %r\n b=%r\n c=%r\n W=%d rep=%r" % (k, a[k], z[k], b, c, W, rep))
+
+
+trial.compact = 0
 
 
 if __name__ == "__main__":
@@ -135,4 +216,4 @@ if __name__ == "__main__":
     rng = random.Random(12345)
     for t in range(n):
         trial(rng, rng.choice([1, 2, 3, 5, 8, 13, 30, 80]), rng.choice([1, 2, 4, 10, 50, 200, 1000]), rng.random() < 0.5)
-    print("closed form == reference loop on %d random segment sequences" % n)
+    print("closed form == reference loop on %d random segment sequences (%d of them also through the compacted form)" % (n, trial.compact))
