@@ -34,8 +34,8 @@
 #include "cp_seed.h"
 
 #ifndef SW_RING
-#define SW_RING  256                             // records of the window-count pass kept on chip
-#define SW_BACK  64                              // ... of which this many lie behind the tile being worked on
+#define SW_RING  512                             // segments of the window-count pass kept on chip (10 bytes each)
+#define SW_BACK  192                             // ... of which this many lie behind the tile being worked on
 #endif
 #define SW_MI    256
 #define SW_PEND  64
@@ -44,7 +44,8 @@
 #define SW_STEP  4                               // chunks of 64 positions per load step
 
 struct cp_seedw_lds
-  { int4     ring[SW_RING];                      // records (begin, end, -, key+1) of the valid segments around the tile being worked on
+  { int32_t  rb[SW_RING], rpb[SW_RING];          // begin / predecessor's begin of the valid segments around the tile being worked on
+    int16_t  rkey[SW_RING];                      // ... and their keys
     int32_t  mi_b[SW_MI], mi_e[SW_MI];           // masked-interval list while it fits
     int32_t  cval[SW_STEP*WAVE];                 // per position: the count if the k-mer is valid, else -1; base classes for the hash
     int32_t  bins[32];
@@ -263,18 +264,36 @@ constexpr sw_code_tab sw_make_codes()
 }
 __device__ const sw_code_tab sw_CODE = sw_make_codes();
 
-__device__ __forceinline__ int sw_hash_at(const char *seq, int j, int K)
+// the k-mer's bases come in with four 16-byte loads issued together (a byte load per step made the 40 steps 40 memory
+// round trips); `rlen` bounds them: a k-mer within 64 bases of the read's end is read byte by byte
+__device__ __forceinline__ int sw_hash_at(const char *seq, int j, int K, int rlen)
 { if (K > SW_KMAX) return cp_kmer_hash(seq,j,K);
   uint64_t fh = 0, rh = 0;
-  for (int t = 0; t < K; t++)
-    { const int code = sw_CODE.v[(unsigned char)seq[j+t]];
-      fh ^= sw_ROT.v[(code & 7)*SW_KMAX+(K-1-t)];
-      rh ^= sw_ROT.v[(code >> 3)*SW_KMAX+t];
+  if (j+SW_KMAX <= rlen)
+    { uint32_t w[SW_KMAX/4];
+#pragma unroll
+      for (int q = 0; q < SW_KMAX/16; q++)
+        { const cp_u8x16 x = *reinterpret_cast<const cp_u8x16 *>(seq+j+16*q);
+          w[4*q] = x.v[0]; w[4*q+1] = x.v[1]; w[4*q+2] = x.v[2]; w[4*q+3] = x.v[3];
+        }
+#pragma unroll
+      for (int t = 0; t < SW_KMAX; t++)
+        if (t < K)
+          { const int code = sw_CODE.v[(w[t >> 2] >> (8*(t & 3))) & 0xff];
+            fh ^= sw_ROT.v[(code & 7)*SW_KMAX+(K-1-t)];
+            rh ^= sw_ROT.v[(code >> 3)*SW_KMAX+t];
+          }
     }
+  else
+    for (int t = 0; t < K; t++)
+      { const int code = sw_CODE.v[(unsigned char)seq[j+t]];
+        fh ^= sw_ROT.v[(code & 7)*SW_KMAX+(K-1-t)];
+        rh ^= sw_ROT.v[(code >> 3)*SW_KMAX+t];
+      }
   return (int)((rh < fh ? rh : fh) % CP_SEED_MOD);
 }
 
-__device__ __attribute__((noinline)) void sw_mark_all(const char *seq, const char *cls, char *state, int K, const int32_t *takes,
+__device__ __attribute__((noinline)) void sw_mark_all(const char *seq, const char *cls, char *state, int K, int rlen, const int32_t *takes,
                                                       int ntake, bool rep, int lane)
 { int32_t *s_pre = sw_S.pend_b, *s_min = sw_S.pend_e;        // (the pending-take buffers are idle here; SW_PEND >= 64)
   static_assert(SW_PEND >= WAVE,"one slot per segment of a round");
@@ -304,7 +323,7 @@ __device__ __attribute__((noinline)) void sw_mark_all(const char *seq, const cha
               const int sb = __shfl(b,lo), so = on ? q-s_pre[lo] : 0;
               if (on)
                 { const int j = sb+so;
-                  const int h = sw_hash_at(seq,j,K);
+                  const int h = sw_hash_at(seq,j,K,rlen);
                   if (pass == 0) atomicMin(&s_min[lo],h);
                   else if (h == s_min[lo]) state[j] = rep ? 'R' : cls[j];
                 }
@@ -428,8 +447,8 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
                     ppos = c0+pl;
                   }
                 if (ppos >= 0 && pidx < R.cap) { if (ptype) R.rec[pidx].y = p; else R.orec[pidx].y = p; }
-                if (idx < R.cap)
-                  { if (mv) { R.rec[idx].x = p; R.rec[idx].w = (rep ? 32767-cnt[u] : cnt[u])+1; }
+                if (idx < R.cap)                             // (z: the begin of my predecessor of either kind, until the window count replaces it)
+                  { if (mv) { R.rec[idx].x = p; R.rec[idx].z = ppos >= 0 ? ppos : -(1 << 30); R.rec[idx].w = (rep ? 32767-cnt[u] : cnt[u])+1; }
                     else R.orec[idx].x = p;
                   }
               }
@@ -466,12 +485,16 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
   SW_STAMP(1);
   // ---- window counts, 64 valid segments at a time ----
   // key = count (H/D) or 32767 - count (repeats): both selections look for the larger key.  pb(j): the begin of j's
-  // predecessor of either kind; j is still within reach of i (j <= x(i)) iff pb(j) < b(i)+W.
+  // predecessor of either kind (record field z until the window count replaces it); j is still within reach of i
+  // (j <= x(i)) iff pb(j) < b(i)+W.
   { constexpr int NONE = -(1 << 30);
-    int ring_hi = 0;                                         // records [ring_hi-SW_RING, ring_hi) are in the ring: (begin, end, -, key+1)
-    auto seg = [&](int j) -> int4
-      { if (j < ring_hi && j >= ring_hi-SW_RING) return sw_S.ring[j & (SW_RING-1)];
-        return R.rec[j];
+    struct sg { int b, pb, key; };
+    int ring_hi = 0;                                         // segments [ring_hi-SW_RING, ring_hi) are in the ring
+    auto seg = [&](int j) -> sg                              // (a segment whose window count is written already: pb is gone, nobody asks)
+      { sg r;
+        if (j < ring_hi && j >= ring_hi-SW_RING) { r.b = sw_S.rb[j & (SW_RING-1)]; r.pb = sw_S.rpb[j & (SW_RING-1)]; r.key = sw_S.rkey[j & (SW_RING-1)]; }
+        else { const int4 t = R.rec[j]; r.b = t.x; r.pb = t.z; r.key = t.w-1; }
+        return r;
       };
     bool c_have = false, c_wipe = false; int c_expb = 0, c_wpb = 0, c_pos = 0;   // carried: begin of the last expiring segment, pb of the last wipe, last_oor_pos
     for (int t0 = 0; t0 < n; t0 += WAVE)
@@ -481,7 +504,10 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
             { __syncthreads();                               // (the slots being replaced are no longer read)
               while (ring_hi < upto)
                 { const int j = ring_hi+lane;
-                  if (j < upto) sw_S.ring[j & (SW_RING-1)] = R.rec[j];
+                  if (j < upto)
+                    { const int4 t = R.rec[j];
+                      sw_S.rb[j & (SW_RING-1)] = t.x; sw_S.rpb[j & (SW_RING-1)] = t.z; sw_S.rkey[j & (SW_RING-1)] = (int16_t)(t.w-1);
+                    }
                   ring_hi = ring_hi+WAVE < upto ? ring_hi+WAVE : upto;
                 }
               __syncthreads();
@@ -489,27 +515,27 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
         }
         const int i = t0+lane;
         const bool act = i < n;
-        int4 me = make_int4(0,0,0,0);
+        sg me; me.b = 0; me.pb = NONE; me.key = -1;
         if (act) me = seg(i);
-        const int bi = me.x, ei = me.y, ki = me.w-1;
-        int pbi = NONE;                                      // begin of my predecessor of either kind
-        if (act) { if (i > 0) { const int4 q = seg(i-1); pbi = q.y == bi ? q.x : q.y; } else if (bi > 0) pbi = 0; }
+        const int bi = me.b, ki = me.key, pbi = me.pb;
+        int ei = 0;                                          // my end = the begin of my successor of either kind
+        if (act)
+          { if (i+1 < n) { const sg nx = seg(i+1); ei = nx.pb == bi ? nx.b : nx.pb; }
+            else ei = R.rec[i].y;
+          }
         // -- forward: the first segment within reach that beats me; else what the reach holds --
         int g = -1, bg = 0, pbg = 0;
         bool eq = false, nonempty = false, fdone = !act;
-        { int pbv = bi, pev = ei;                            // begin / end of segment j-1
-          for (int step = 1; step <= 16; step++)
+        { for (int step = 1; step <= 16; step++)
             { const int j = i+step;
               const bool more = !fdone && j < n;
-              int4 sj = make_int4(0,0,0,0);
+              sg sj; sj.b = 0; sj.pb = 0; sj.key = -1;
               if (more) sj = seg(j);
-              const int pbj = pev == sj.x ? pbv : pev;
-              const bool reach = more && pbj < bi+W;
-              const bool beat = reach && sj.w-1 > ki;
-              if (beat) { g = j; bg = sj.x; pbg = pbj; }
-              if (reach && !beat) { nonempty = true; eq = eq || sj.w-1 == ki; }
+              const bool reach = more && sj.pb < bi+W;
+              const bool beat = reach && sj.key > ki;
+              if (beat) { g = j; bg = sj.b; pbg = sj.pb; }
+              if (reach && !beat) { nonempty = true; eq = eq || sj.key == ki; }
               fdone = fdone || !reach || beat;
-              pbv = sj.x; pev = sj.y;
               if (__ballot(!fdone) == 0) break;
             }
           // searches still open, one at a time, 64 segments per step
@@ -520,15 +546,14 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
               int rg = -1, rbg = 0, rpbg = 0;
               for (int j0 = si+17; ; j0 += WAVE)
                 { const int jj = j0+lane;
-                  int4 sj = make_int4(0,0,0,0), sp = make_int4(0,0,0,0);
-                  if (jj < n) { sj = seg(jj); sp = seg(jj-1); }
-                  const int pbj = sp.y == sj.x ? sp.x : sp.y;
-                  const bool reach = jj < n && pbj < sb+W;   // (monotone: begins grow)
-                  const uint64_t mR = __ballot(reach), mB = __ballot(reach && sj.w-1 > sk), mE = __ballot(reach && sj.w-1 == sk);
+                  sg sj; sj.b = 0; sj.pb = 0; sj.key = -1;
+                  if (jj < n) sj = seg(jj);
+                  const bool reach = jj < n && sj.pb < sb+W;   // (monotone: begins grow)
+                  const uint64_t mR = __ballot(reach), mB = __ballot(reach && sj.key > sk), mE = __ballot(reach && sj.key == sk);
                   if (mB)
                     { const int fb = __ffsll((long long)mB)-1;
                       const uint64_t blt = (1ull << fb)-1;
-                      rg = j0+fb; rbg = __shfl(sj.x,fb); rpbg = __shfl(pbj,fb);
+                      rg = j0+fb; rbg = __shfl(sj.b,fb); rpbg = __shfl(sj.pb,fb);
                       sne = sne || (mR & blt) != 0; seq = seq || (mE & blt) != 0;
                       break;
                     }
@@ -546,33 +571,33 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
         { for (int step = 1; step <= 16; step++)
             { const int j = i-step;
               const bool more = !bdone && j >= 0;
-              int4 sj = make_int4(0,0,0,0);
+              sg sj; sj.b = 0; sj.pb = 0; sj.key = -1;
               if (more) sj = seg(j);
-              const bool inw = more && sj.x > limw;
-              const bool better = inw && sj.w-1 > ki;
-              if (inw) { bnon = true; blocked = blocked || sj.w-1 >= ki; }
-              if (better) { havep = true; pbeg = sj.x; }
+              const bool inw = more && sj.b > limw;
+              const bool better = inw && sj.key > ki;
+              if (inw) { bnon = true; blocked = blocked || sj.key >= ki; }
+              if (better) { havep = true; pbeg = sj.b; }
               bdone = bdone || !inw || better || (blocked && g < 0);   // an expiring segment only needs to know that it wipes nothing
               if (__ballot(!bdone) == 0) break;
             }
           for (uint64_t um = __ballot(!bdone); um; um &= um-1)
             { const int src = __ffsll((long long)um)-1;
-              const int si = __shfl(i,src), sk = __shfl(ki,src), slim = __shfl(limw,src), sg = __shfl(g,src);
+              const int si = __shfl(i,src), sk = __shfl(ki,src), slim = __shfl(limw,src), sgi = __shfl(g,src);
               bool sbl = __shfl(blocked ? 1 : 0,src) != 0, sbn = __shfl(bnon ? 1 : 0,src) != 0, shp = false;
               int spb = 0;
               for (int j0 = si-17; ; j0 -= WAVE)
                 { const int jj = j0-lane;
-                  int4 sj = make_int4(0,0,0,0);
+                  sg sj; sj.b = 0; sj.pb = 0; sj.key = -1;
                   if (jj >= 0) sj = seg(jj);
-                  const bool inw = jj >= 0 && sj.x > slim;   // (monotone)
-                  const uint64_t mI = __ballot(inw), mS = __ballot(inw && sj.w-1 > sk), mN = __ballot(inw && sj.w-1 >= sk);
+                  const bool inw = jj >= 0 && sj.b > slim;   // (monotone)
+                  const uint64_t mI = __ballot(inw), mS = __ballot(inw && sj.key > sk), mN = __ballot(inw && sj.key >= sk);
                   if (mS)
                     { const int fs = __ffsll((long long)mS)-1;
-                      shp = true; spb = __shfl(sj.x,fs); sbl = true; sbn = true;
+                      shp = true; spb = __shfl(sj.b,fs); sbl = true; sbn = true;
                       break;
                     }
                   sbn = sbn || mI != 0; sbl = sbl || mN != 0;
-                  if (mI != ~0ull || (sbl && sg < 0)) break;
+                  if (mI != ~0ull || (sbl && sgi < 0)) break;
                 }
               if (lane == src) { blocked = sbl; bnon = sbn; havep = shp; pbeg = spb; bdone = true; }
             }
@@ -763,7 +788,7 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
       if (lane == 0) { g_seed_dbg_n[0] = ntake; g_seed_dbg_n[1] = M; g_seed_dbg_n[2] = n; g_seed_dbg_n[3] = 0; }
     }
 #endif
-  sw_mark_all(R.seq,R.cls,R.state,R.K,R.tmp,ntake,rep,lane);
+  sw_mark_all(R.seq,R.cls,R.state,R.K,plen+Km1,R.tmp,ntake,rep,lane);
 #ifdef CP_SEED_PROF
   { int tk = 0; for (int q = lane; q < ntake; q += WAVE) tk += R.tmp[2*q+1]-R.tmp[2*q];
     for (int o = 32; o > 0; o >>= 1) tk += __shfl_xor(tk,o);
