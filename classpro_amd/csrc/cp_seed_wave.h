@@ -37,6 +37,9 @@
 #define SW_RING  512                             // segments of the window-count pass kept on chip (10 bytes each)
 #define SW_BACK  192                             // ... of which this many lie behind the tile being worked on
 #endif
+#ifndef SW_IND
+#define SW_IND   32                              // segments a lane searches on its own in each direction before the wave takes over
+#endif
 #define SW_MI    256
 #define SW_PEND  64
 #define SW_REP   64
@@ -526,16 +529,25 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
         // -- forward: the first segment within reach that beats me; else what the reach holds --
         int g = -1, bg = 0, pbg = 0;
         bool eq = false, nonempty = false, fdone = !act;
-        { for (int step = 1; step <= 16; step++)
-            { const int j = i+step;
-              const bool more = !fdone && j < n;
-              sg sj; sj.b = 0; sj.pb = 0; sj.key = -1;
-              if (more) sj = seg(j);
-              const bool reach = more && sj.pb < bi+W;
-              const bool beat = reach && sj.key > ki;
-              if (beat) { g = j; bg = sj.b; pbg = sj.pb; }
-              if (reach && !beat) { nonempty = true; eq = eq || sj.key == ki; }
-              fdone = fdone || !reach || beat;
+        { // 32 segments ahead, eight at a time: the eight reads are issued together, then evaluated in order
+          for (int s0 = 1; s0 <= SW_IND; s0 += 8)
+            { sg sj[8];
+#pragma unroll
+              for (int q = 0; q < 8; q++)
+                { const int j = i+s0+q;
+                  sj[q].b = 0; sj[q].pb = 0; sj[q].key = -1;
+                  if (!fdone && j < n) sj[q] = seg(j);
+                }
+#pragma unroll
+              for (int q = 0; q < 8; q++)
+                { const int j = i+s0+q;
+                  const bool more = !fdone && j < n;
+                  const bool reach = more && sj[q].pb < bi+W;
+                  const bool beat = reach && sj[q].key > ki;
+                  if (beat) { g = j; bg = sj[q].b; pbg = sj[q].pb; }
+                  if (reach && !beat) { nonempty = true; eq = eq || sj[q].key == ki; }
+                  fdone = fdone || !reach || beat;
+                }
               if (__ballot(!fdone) == 0) break;
             }
           // searches still open, one at a time, 64 segments per step
@@ -544,7 +556,7 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
               const int si = __shfl(i,src), sb = __shfl(bi,src), sk = __shfl(ki,src);
               bool seq = __shfl(eq ? 1 : 0,src) != 0, sne = __shfl(nonempty ? 1 : 0,src) != 0;
               int rg = -1, rbg = 0, rpbg = 0;
-              for (int j0 = si+17; ; j0 += WAVE)
+              for (int j0 = si+SW_IND+1; ; j0 += WAVE)
                 { const int jj = j0+lane;
                   sg sj; sj.b = 0; sj.pb = 0; sj.key = -1;
                   if (jj < n) sj = seg(jj);
@@ -568,16 +580,24 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
         bool blocked = false, bnon = false, havep = false, bdone = !act || pbi == NONE;
         int pbeg = 0;
         const int limw = pbi-W;
-        { for (int step = 1; step <= 16; step++)
-            { const int j = i-step;
-              const bool more = !bdone && j >= 0;
-              sg sj; sj.b = 0; sj.pb = 0; sj.key = -1;
-              if (more) sj = seg(j);
-              const bool inw = more && sj.b > limw;
-              const bool better = inw && sj.key > ki;
-              if (inw) { bnon = true; blocked = blocked || sj.key >= ki; }
-              if (better) { havep = true; pbeg = sj.b; }
-              bdone = bdone || !inw || better || (blocked && g < 0);   // an expiring segment only needs to know that it wipes nothing
+        { for (int s0 = 1; s0 <= SW_IND; s0 += 8)
+            { sg sj[8];
+#pragma unroll
+              for (int q = 0; q < 8; q++)
+                { const int j = i-s0-q;
+                  sj[q].b = 0; sj[q].pb = 0; sj[q].key = -1;
+                  if (!bdone && j >= 0) sj[q] = seg(j);
+                }
+#pragma unroll
+              for (int q = 0; q < 8; q++)
+                { const int j = i-s0-q;
+                  const bool more = !bdone && j >= 0;
+                  const bool inw = more && sj[q].b > limw;
+                  const bool better = inw && sj[q].key > ki;
+                  if (inw) { bnon = true; blocked = blocked || sj[q].key >= ki; }
+                  if (better) { havep = true; pbeg = sj[q].b; }
+                  bdone = bdone || !inw || better || (blocked && g < 0);   // an expiring segment only needs to know that it wipes nothing
+                }
               if (__ballot(!bdone) == 0) break;
             }
           for (uint64_t um = __ballot(!bdone); um; um &= um-1)
@@ -585,7 +605,7 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
               const int si = __shfl(i,src), sk = __shfl(ki,src), slim = __shfl(limw,src), sgi = __shfl(g,src);
               bool sbl = __shfl(blocked ? 1 : 0,src) != 0, sbn = __shfl(bnon ? 1 : 0,src) != 0, shp = false;
               int spb = 0;
-              for (int j0 = si-17; ; j0 -= WAVE)
+              for (int j0 = si-SW_IND-1; ; j0 -= WAVE)
                 { const int jj = j0-lane;
                   sg sj; sj.b = 0; sj.pb = 0; sj.key = -1;
                   if (jj >= 0) sj = seg(jj);
@@ -711,15 +731,28 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
     }
   SW_STAMP(2);
   // ---- selection (wave-uniform control flow) ----
-  int ntake = 0;                                             // taken segments, listed in R.tmp (idle after the sort) and marked at the end
+  // taken segments are listed in R.tmp (idle after the sort) and marked at the end; the list is written 64 takes at a
+  // time from an LDS buffer (cval), so that the list update of a take -- a chain of wave barriers -- never waits for a
+  // global store of the take before it
+  int ntake = 0, nbuf = 0;
+  auto flush_takes = [&]()
+    { __syncthreads();
+      for (int q = lane; q < 2*nbuf; q += WAVE) R.tmp[2*(ntake-nbuf)+q] = sw_S.cval[q];
+      nbuf = 0;
+      __syncthreads();
+    };
   auto take = [&](int b, int e)                              // mask the segment with a margin of W, mark its hash minimizers
     { if (!Lm.big && M+4 >= SW_MI) sw_mi_grow(Lm,R.cap+3,lane);
       M = sw_mi_add(Lm,M,b-W > 0 ? b-W : 0,e+W < plen ? e+W : plen,lane);
       if (2*ntake+2 <= R.cap)
-        { if (lane == 0) { R.tmp[2*ntake] = b; R.tmp[2*ntake+1] = e; }
-          ntake++;
+        { if (nbuf == WAVE) flush_takes();
+          if (lane == 0) { sw_S.cval[2*nbuf] = b; sw_S.cval[2*nbuf+1] = e; }
+          nbuf++; ntake++;
         }
-      else sw_mark(R.seq,R.cls,R.state,plen+Km1,R.K,b,e,rep,lane);         // (no room in the list: marked on the spot)
+      else                                                   // (no room in the list: marked on the spot)
+        { flush_takes();
+          sw_mark(R.seq,R.cls,R.state,plen+Km1,R.K,b,e,rep,lane);
+        }
     };
   int pos = 0;
   for (; pos < n; pos++)                                     // every segment that is extreme over a whole window
@@ -780,7 +813,7 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
       flush(pos);
     }
   SW_STAMP(4);
-  __syncthreads();                                           // lane 0's list of taken segments is visible to the wave
+  flush_takes();                                             // the list of taken segments is complete and visible to the wave
 #ifdef CP_SEED_DEBUG_TAKES
   if (R.dbg_read && rep)
     { int *d = (int *)g_seed_dbg;
