@@ -584,6 +584,107 @@ __device__ void wave_wall_mult(RD *R, int i, int NS, int *midx)
 }
 
 // ---------------------------------------------------------------------------------------------
+//  Candidate flags on chip.  After the walk a flag byte is non-zero only at wall candidates and at the ends of E-intervals,
+//  and in all but a few reads those ends are candidates too (the partner of an error's DROP is the GAIN K-1 positions on;
+//  the exceptions: a partner at the read's boundary, or one whose count change is below the scan's threshold).  The
+//  phases after the walk then never need the flag ARRAYS: the wave loads the candidates' two flag bytes once and works
+//  on (position, flags) of the candidates in LDS -- the multi-error search becomes a walk over the neighbouring
+//  candidates instead of 64-byte loads of both arrays around every O-only wall, each a round trip to HBM.
+//  c_pos[q] = position of candidate q (16 bits), c_fo[q] / c_fs[q] = its byte of the OTHERS / SELF array.
+// ---------------------------------------------------------------------------------------------
+struct fw_cflags { uint16_t *pos; uint8_t *fo, *fs; int n; };
+
+__device__ __forceinline__ int cf_find(const fw_cflags &F, int x)        // index of the candidate at position x, or -1
+{ int lo = 0, hi = F.n-1;
+  while (lo <= hi)
+    { const int m = (lo+hi) >> 1, v = F.pos[m];
+      if (v == x) return m;
+      if (v < x) lo = m+1; else hi = m-1;
+    }
+  return -1;
+}
+
+// wall.c:722-731 / 868-872 on the on-chip flags
+__device__ void cf_unwall_inside(const fw_cflags &F, const fw_evl &ev, int lo, int hi)
+{ if (hi <= lo) return;
+  for (int q = lane_id(); q < F.n; q += WAVE)
+    if (F.fo[q] & CP_W_WALL_O)
+      { const int i = F.pos[q];
+        bool in = false;
+        for (int k = lo; k < hi && !in; k++)
+          in = (ev.b(k) < i && i < ev.e(k));
+        if (in) F.fo[q] &= (uint8_t)~CP_W_WALL_O;
+      }
+  wave_sync();
+}
+
+// cp_wall_mult (wall.c:763-860) for the O-only wall at candidate q, all lanes together: the walls the reference meets
+// within 200 positions are the flagged candidates after (DROP) / before (GAIN) q, 64 of them per step, in order; the read's
+// boundary (plen / 0), when it lies within reach, comes last.  Same values on every lane, stores by lane 0.
+template <class RD>
+__device__ void cf_wall_mult(RD *R, const fw_cflags &F, int q, int NS, int *midx)
+{ const int lane = lane_id();
+  const int plen = R->plen, i = F.pos[q];
+  fw_evl &ev = R->eintvl;
+  for (int w = CP_DROP; w <= CP_GAIN; w++)
+    { const double pe_i = CP_PERR(R,i,CP_SELF,w);
+      if (pe_i < CP_PE_THRES_FINAL)
+        continue;
+      const bool right = (w == CP_DROP);
+      const int jend = right ? ((i+CP_MULT_WINDOW < plen+1) ? i+CP_MULT_WINDOW : plen+1)
+                             : ((i-CP_MULT_WINDOW > 0) ? i-CP_MULT_WINDOW : 0);
+      bool done = false;
+      for (int c0 = 0; !done; c0 += WAVE)
+        { const int qq = right ? q+1+c0+lane : q-1-c0-lane;
+          int pj = 0, fo = 0, fs = 0;
+          bool valid = qq >= 0 && qq < F.n;
+          if (valid) { pj = F.pos[qq]; valid = right ? (pj < jend) : (pj >= jend); }
+          if (valid) { fo = F.fo[qq]; fs = F.fs[qq]; }
+          const uint64_t mv = __ballot(valid);
+          const uint64_t mw = __ballot(valid && (((fo & CP_W_WALL_O) | (fs & CP_W_WALL_S)) != 0));
+          const uint64_t ms = __ballot(valid && (fo & CP_W_WALL_O));
+          for (uint64_t t = mw; t; t &= t-1)
+            { const int b = __ffsll((long long)t)-1;
+              const int jj = __shfl(pj,b), qj = right ? q+1+c0+b : q-1-c0-b;
+              if (cp_bs_eintvl(ev,0,NS-1,right ? i : jj,right ? jj : i) == -1)
+                { const double pe_j = CP_PERR(R,jj,CP_SELF,right ? CP_GAIN : CP_DROP);
+                  const double pe = pe_i * pe_j;
+                  if (pe >= CP_PE_THRES_FINAL)
+                    { if (*midx >= R->ecap) { R->overflow = 1; return; }
+                      ev.wave_grow(*midx);
+                      if (lane == 0)
+                        { cp_eintvl x; x.b = right ? i : jj; x.e = right ? jj : i; x.pe = pe;
+                          ev.put(*midx,x);
+                          F.fo[q] |= CP_W_PAIRED_M;
+                          F.fo[qj] |= CP_W_PAIRED_M;
+                        }
+                      (*midx)++;
+                      if (*midx >= plen) { R->overflow = 8; return; }
+                    }
+                }
+              if ((ms >> b) & 1) { done = true; break; }
+            }
+          if (mv != ~0ull) break;                          // the candidates within reach end inside these 64
+        }
+      if (!done && (right ? plen < jend : jend == 0))     // the boundary is within reach: wall.c:772-789 / 816-833
+        { const double pe = pe_i * pe_i;
+          if (pe >= CP_PE_THRES_FINAL)
+            { if (*midx >= R->ecap) { R->overflow = 1; return; }
+              ev.wave_grow(*midx);
+              if (lane == 0)
+                { cp_eintvl x; x.b = right ? i : 0; x.e = right ? plen : i; x.pe = pe;
+                  ev.put(*midx,x);
+                  F.fo[q] |= CP_W_PAIRED_M;
+                }
+              (*midx)++;
+              if (*midx >= plen) { R->overflow = 8; return; }      // the reference exits here: "# E-intvls >= plen" (wall.c:783-788)
+            }
+        }
+      wave_sync();                                         // lane 0's flag updates before the other direction reads them
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 //  k_find_wall: wall.c:570-958, one wave per read.
 // ---------------------------------------------------------------------------------------------
 #ifdef CP_PROF_WALK
@@ -902,7 +1003,24 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
         wall[o.e] &= ~(CP_W_WALL_O|CP_W_PAIRED_O);
       }
   wave_sync();
-  wave_unwall_inside(wall,clist,n_c,R.eintvl,0,NS,sbuf,SBUF/2);
+  // ---- the candidates' flags on chip (fw_cflags): positions in s16[0..n_c), the two flag bytes behind them, the
+  //      boundaries from s16[2*n_c) on; possible when the read's lists fit and every flagged position is a candidate ----
+  fw_cflags F;
+  F.pos = s16; F.fo = reinterpret_cast<uint8_t *>(s16+n_c); F.fs = F.fo+n_c; F.n = n_c;
+  bool cf = plen <= 65535 && n_c <= 255 && 3*n_c+2*SCOMP+1 <= U16 && !R.eintvl.big;
+  if (cf)
+    { for (int q = lane; q < n_c; q += WAVE)
+        { const int i = clist[q];
+          F.pos[q] = (uint16_t)i; F.fo[q] = wall[i]; F.fs[q] = wall_s[i];
+        }
+      wave_sync();
+      bool miss = false;                               // an E-interval that ends off the candidates (a boundary pair, a partner below the scan's threshold)
+      for (int k = lane; k < NS; k += WAVE)
+        miss = miss || cf_find(F,R.eintvl.b(k)) < 0 || cf_find(F,R.eintvl.e(k)) < 0;
+      cf = __ballot(miss) == 0;
+    }
+  if (cf) cf_unwall_inside(F,R.eintvl,0,NS);
+  else    wave_unwall_inside(wall,clist,n_c,R.eintvl,0,NS,sbuf,SBUF/2);
 
   // ---- sort + dedupe E-intervals (wall.c:734); the O list is not used again ------------------
   NS = wave_sort_ev(R.eintvl,NS,R.ointvl.g,true);
@@ -914,35 +1032,52 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   // paired, wall.c:766-767).
   int32_t *olist = wl, *compB = wl+2*(int64_t)icap, *compE = compB+(icap >> 1), *bnd = wl+3*(int64_t)icap;
   const int ccap = icap >> 1;                           // components <= candidates+1 <= icap/2
-  int n_o = 0;
-  for (int base = 0; base < n_c; base += WAVE)
-    { const int q = base+lane;
-      int i = 0; bool keep = false;
-      if (q < n_c)
-        { i = clist[q];
-          keep = (wall[i] & CP_W_WALL_O) && !(wall_s[i] & CP_W_WALL_S);
-        }
-      const uint64_t m = __ballot(keep);
-      if (keep)
-        { const int o = n_o+__popcll(m & ((1ull << lane)-1));           // n_o < n_c <= icap
-          if (on16) s16[o] = (uint16_t)i; else olist[o] = i;
-        }
-      n_o += __popcll(m);
-    }
-  wave_sync();
-  PH_STAMP(2);
   int midx = NS;
-  for (int q = 0; q < n_o; q++)                        // all lanes together, see wave_wall_mult
-    { const int ii = on16 ? (int)s16[q] : olist[q];
-      wave_sync();                                     // lane 0's flag stores of the previous wall
-      if (wall[ii] & CP_W_PAIRED_M)                    // may have been set by an earlier i
-        continue;
-      wave_wall_mult(&R,ii,NS,&midx);
+  if (cf)                                              // the O-only walls are met candidate by candidate, in order
+    { PH_STAMP(2);
+      for (int base = 0; base < n_c; base += WAVE)
+        { const int q = base+lane;
+          const uint64_t m = __ballot(q < n_c && (F.fo[q] & CP_W_WALL_O) && !(F.fs[q] & CP_W_WALL_S));
+          for (uint64_t t = m; t; t &= t-1)
+            { const int qq = base+__ffsll((long long)t)-1;
+              wave_sync();                             // lane 0's flag updates of the previous wall
+              if (F.fo[qq] & CP_W_PAIRED_M)            // may have been set by an earlier wall
+                continue;
+              cf_wall_mult(&R,F,qq,NS,&midx);
+            }
+        }
+    }
+  else
+    { int n_o = 0;
+      for (int base = 0; base < n_c; base += WAVE)
+        { const int q = base+lane;
+          int i = 0; bool keep = false;
+          if (q < n_c)
+            { i = clist[q];
+              keep = (wall[i] & CP_W_WALL_O) && !(wall_s[i] & CP_W_WALL_S);
+            }
+          const uint64_t m = __ballot(keep);
+          if (keep)
+            { const int o = n_o+__popcll(m & ((1ull << lane)-1));       // n_o < n_c <= icap
+              if (on16) s16[o] = (uint16_t)i; else olist[o] = i;
+            }
+          n_o += __popcll(m);
+        }
+      wave_sync();
+      PH_STAMP(2);
+      for (int q = 0; q < n_o; q++)                    // all lanes together, see wave_wall_mult
+        { const int ii = on16 ? (int)s16[q] : olist[q];
+          wave_sync();                                 // lane 0's flag stores of the previous wall
+          if (wall[ii] & CP_W_PAIRED_M)                // may have been set by an earlier i
+            continue;
+          wave_wall_mult(&R,ii,NS,&midx);
+        }
     }
   overflow |= R.overflow;
   wave_sync();
   PH_STAMP(3);
-  wave_unwall_inside(wall,clist,n_c,R.eintvl,NS,midx,sbuf,SBUF/2);      // wall.c:868-872
+  if (cf) cf_unwall_inside(F,R.eintvl,NS,midx);        // wall.c:868-872
+  else    wave_unwall_inside(wall,clist,n_c,R.eintvl,NS,midx,sbuf,SBUF/2);
   if (NS < midx)                                       // wall.c:873-876
     { NS = midx;
       wave_sort_ev(R.eintvl,NS,R.ointvl.g,false);
@@ -984,15 +1119,18 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   C = __shfl(C,0);
   if (C > ccap) { overflow |= 2; C = ccap; }
   const bool smallc = on16 && C <= SCOMP;               // components, walls and boundaries all on chip
-  uint16_t *s_bnd = s16+n_c;
+  // (with the flags on chip the walls are kept as candidate numbers, a byte each, where the SELF flags were -- those
+  //  are dead after the multi-error search -- and the boundaries follow the flags; else: walls from s16[0), boundaries behind)
+  uint16_t *s_bnd = cf ? s16+2*n_c : s16+n_c;
+  uint8_t *s_wq = F.fs;
   wave_sync();
   int n_w = 0;                                         // OTHERS walls outside error regions, in order
   for (int base = 0; base < n_c; base += WAVE)
     { const int q = base+lane;
       int i = 0; bool keep = false;
       if (q < n_c)
-        { i = clist[q];
-          if (wall[i] & CP_W_WALL_O)
+        { i = cf ? (int)F.pos[q] : clist[q];
+          if ((cf ? F.fo[q] : wall[i]) & CP_W_WALL_O)
             { int a = 0, z = C-1, in = 0;              // inside a component?  compB sorted, disjoint
               while (a <= z)
                 { int m = (a+z) >> 1;
@@ -1007,7 +1145,9 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
       const uint64_t m = __ballot(keep);
       if (keep)
         { const int o = n_w+__popcll(m & ((1ull << lane)-1));
-          if (smallc) s16[o] = (uint16_t)i; else olist[o] = i;       // n_w < n_c <= icap
+          if (cf && smallc) s_wq[o] = (uint8_t)q;
+          else if (smallc) s16[o] = (uint16_t)i;
+          else olist[o] = i;                           // n_w < n_c <= icap
         }
       n_w += __popcll(m);
     }
@@ -1022,7 +1162,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
               if (v >= 1 && v < plen && v > last) { tpos = v; break; }
               if (phase) { ci++; phase = 0; } else phase = 1;
             }
-          int wpos = (wi < n_w) ? (smallc ? (int)s16[wi] : olist[wi]) : plen;
+          int wpos = (wi < n_w) ? (smallc ? (cf ? (int)F.pos[s_wq[wi]] : (int)s16[wi]) : olist[wi]) : plen;
           int nb = tpos < wpos ? tpos : wpos;
           if (nb >= plen) break;
           if (N < icap) { if (smallc) s_bnd[N] = (uint16_t)nb; else bnd[N] = nb; }
