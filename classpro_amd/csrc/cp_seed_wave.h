@@ -34,8 +34,12 @@
 #include "cp_seed.h"
 
 #ifndef SW_RING
-#define SW_RING  512                             // segments of the window-count pass kept on chip (10 bytes each)
-#define SW_BACK  192                             // ... of which this many lie behind the tile being worked on
+#define SW_RING  256                             // segments of the window-count pass kept on chip (10 bytes each; beyond: read from HBM)
+#define SW_BACK  64                              // ... of which this many lie behind the tile being worked on
+                                                 // (512 / 192: 59.4 ms on the 60x set against 57.6 -- the LDS is worth more as a sixth wave per SIMD)
+#endif
+#ifndef SW_BATCH
+#define SW_BATCH 8                               // ... that many at a time (their reads are issued together)
 #endif
 #ifndef SW_IND
 #define SW_IND   32                              // segments a lane searches on its own in each direction before the wave takes over
@@ -44,7 +48,9 @@
 #define SW_PEND  64
 #define SW_REP   64
 #define SW_KMAX  64                              // k-mer lengths served by the rotated-seed table (longer: byte-wise fold)
-#define SW_STEP  4                               // chunks of 64 positions per load step
+#ifndef SW_STEP
+#define SW_STEP  2                               // chunks of 64 positions per load step (4: 57.6 ms against 55.6)
+#endif
 
 struct cp_seedw_lds
   { int32_t  rb[SW_RING], rpb[SW_RING];          // begin / predecessor's begin of the valid segments around the tile being worked on
@@ -530,16 +536,16 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
         int g = -1, bg = 0, pbg = 0;
         bool eq = false, nonempty = false, fdone = !act;
         { // 32 segments ahead, eight at a time: the eight reads are issued together, then evaluated in order
-          for (int s0 = 1; s0 <= SW_IND; s0 += 8)
-            { sg sj[8];
+          for (int s0 = 1; s0 <= SW_IND; s0 += SW_BATCH)
+            { sg sj[SW_BATCH];
 #pragma unroll
-              for (int q = 0; q < 8; q++)
+              for (int q = 0; q < SW_BATCH; q++)
                 { const int j = i+s0+q;
                   sj[q].b = 0; sj[q].pb = 0; sj[q].key = -1;
                   if (!fdone && j < n) sj[q] = seg(j);
                 }
 #pragma unroll
-              for (int q = 0; q < 8; q++)
+              for (int q = 0; q < SW_BATCH; q++)
                 { const int j = i+s0+q;
                   const bool more = !fdone && j < n;
                   const bool reach = more && sj[q].pb < bi+W;
@@ -580,16 +586,16 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
         bool blocked = false, bnon = false, havep = false, bdone = !act || pbi == NONE;
         int pbeg = 0;
         const int limw = pbi-W;
-        { for (int s0 = 1; s0 <= SW_IND; s0 += 8)
-            { sg sj[8];
+        { for (int s0 = 1; s0 <= SW_IND; s0 += SW_BATCH)
+            { sg sj[SW_BATCH];
 #pragma unroll
-              for (int q = 0; q < 8; q++)
+              for (int q = 0; q < SW_BATCH; q++)
                 { const int j = i-s0-q;
                   sj[q].b = 0; sj[q].pb = 0; sj[q].key = -1;
                   if (!bdone && j >= 0) sj[q] = seg(j);
                 }
 #pragma unroll
-              for (int q = 0; q < 8; q++)
+              for (int q = 0; q < SW_BATCH; q++)
                 { const int j = i-s0-q;
                   const bool more = !bdone && j >= 0;
                   const bool inw = more && sj[q].b > limw;
