@@ -2038,7 +2038,17 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
 
 // ---------------------------------------------------------------------------------------------
 //  k_paint_labels: ClassPro.c:116-119 ('N' x (K-1)) and :265-271 (interval class per k-mer).
+//  One wave per read.  The read's label string is cut into 16-byte pieces of the output (aligned to the buffer), a lane
+//  each, 1 KB per step: the interval ends (in label coordinates, the 'N' prefix as interval 0) sit in LDS, a lane finds
+//  the interval of its piece's first label by binary search, splats that class over the piece and patches what follows
+//  an interval end inside it (one piece in ten holds one).  The form before -- interval by interval, every interval
+//  painted by the whole wave -- issued 57 instructions per interval, 0.4 G of the pipeline's 4.5 G per sub-batch
+//  (profiles/r03_sq_insts.txt), mostly scalar address arithmetic; this one about a quarter of that.
 // ---------------------------------------------------------------------------------------------
+#define PAINT_MAX 512
+__device__ __forceinline__ unsigned cp_label_char(int a)
+{ return (a == CP_ERROR) ? 'E' : (a == CP_REPEAT) ? 'R' : (a == CP_HAPLO) ? 'H' : (a == CP_DIPLO) ? 'D' : '?'; }
+
 __global__ void __launch_bounds__(WAVE)
 k_paint_labels(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ seq_off, int nreads,
                const cp_intvl *__restrict__ intvl_all, const int64_t *__restrict__ ioff,
@@ -2048,11 +2058,55 @@ k_paint_labels(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ 
   const int lane = lane_id();
   const int K = P->K;
   char *lab = labels+seq_off[r];
-  for (int i = lane; i < K-1; i += WAVE)
-    lab[i] = 'N';
-  char *pasgn = lab+(K-1);
+  const int rlen = (int)(seq_off[r+1]-seq_off[r]);
   const cp_intvl *intvl = intvl_all+ioff[r];
   const int N = nintvl[r];
+  __shared__ int s_end[PAINT_MAX];                       // end of interval k (k = 0: the 'N' prefix), label coordinates
+  __shared__ uint8_t s_chr[PAINT_MAX];
+  if (N+1 <= PAINT_MAX)
+    { if (lane == 0) { s_end[0] = K-1 < rlen ? K-1 : rlen; s_chr[0] = 'N'; }
+      for (int k = lane; k < N; k += WAVE)
+        { s_end[k+1] = intvl[k].e+(K-1); s_chr[k+1] = (uint8_t)cp_label_char(intvl[k].asgn); }
+      wave_sync();
+      const int M = N+1;
+      auto find = [&](int q) -> int                        // the interval of label q: the first one that ends beyond it
+        { int lo = 0, hi = M-1;
+          while (lo < hi) { const int m = (lo+hi) >> 1; if (s_end[m] > q) hi = m; else lo = m+1; }
+          return lo;
+        };
+      const int head = (int)((16-((uintptr_t)lab & 15)) & 15);        // bytes before the first aligned piece
+      const int h = head < rlen ? head : rlen;
+      if (lane < h) lab[lane] = (char)s_chr[find(lane)];
+      const int npiece = (rlen-h) >> 4;
+      uint4 *dst = reinterpret_cast<uint4 *>(lab+h);
+      for (int pc = lane; pc < npiece; pc += WAVE)
+        { const int q0 = h+16*pc;
+          int k = find(q0);
+          unsigned c = s_chr[k]*0x01010101u;
+          uint32_t w[4] = { c, c, c, c };
+          int e = s_end[k];
+          while (e < q0+16 && k+1 < M)                   // an interval ends inside the piece: the rest of it is the next one's
+            { k++;
+              const unsigned c2 = s_chr[k]*0x01010101u;
+              const int o = e-q0;                        // first byte of the piece that belongs to interval k
+#pragma unroll
+              for (int d = 0; d < 4; d++)
+                { const int lo = o-4*d;                  // first byte of dword d to replace
+                  if (lo <= 0) w[d] = c2;
+                  else if (lo < 4) { const uint32_t m = 0xffffffffu << (8*lo); w[d] = (w[d] & ~m) | (c2 & m); }
+                }
+              e = s_end[k];
+            }
+          dst[pc] = make_uint4(w[0],w[1],w[2],w[3]);
+        }
+      const int t0 = h+16*npiece;                        // the bytes behind the last aligned piece
+      if (t0+lane < rlen) lab[t0+lane] = (char)s_chr[find(t0+lane)];
+      return;
+    }
+  // a read with more intervals than the table holds: interval by interval, every interval painted by the whole wave
+  for (int i = lane; i < K-1 && i < rlen; i += WAVE)
+    lab[i] = 'N';
+  char *pasgn = lab+(K-1);
   for (int base = 0; base < N; base += WAVE)             // 64 interval records per round of loads
     { int b_l = 0, e_l = 0, a_l = -1;
       if (base+lane < N)
@@ -2061,7 +2115,7 @@ k_paint_labels(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ 
       for (int k = 0; k < nb; k++)
         { const int b = __builtin_amdgcn_readlane(b_l,k), e = __builtin_amdgcn_readlane(e_l,k);
           const int a = __builtin_amdgcn_readlane(a_l,k);
-          const unsigned c = (a == CP_ERROR) ? 'E' : (a == CP_REPEAT) ? 'R' : (a == CP_HAPLO) ? 'H' : (a == CP_DIPLO) ? 'D' : '?';
+          const unsigned c = cp_label_char(a);
           char *p0 = pasgn+b, *p1 = pasgn+e;               // [p0,p1): bytes up to the first aligned word, words, rest
           char *w0 = (char *)(((uintptr_t)p0+3) & ~(uintptr_t)3), *w1 = (char *)((uintptr_t)p1 & ~(uintptr_t)3);
           if (w0 >= w1)
