@@ -1101,7 +1101,21 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   // paying a global-memory round trip per element: the walls in s16[0..n_w), the boundaries in s16[n_c..), the
   // component starts / ends in s_cb / s_ce.
   int C = 0;
-  if (lane == 0)
+  if (NS <= WAVE && ccap >= WAVE)                       // a lane per E-interval: a component starts where b exceeds every end before it
+    { int b_k = 0, e_k = -1;
+      if (lane < NS) { b_k = R.eintvl.b(lane); e_k = R.eintvl.e(lane); }
+      int inc = e_k;                                    // inclusive prefix maximum of the ends
+      for (int o = 1; o < WAVE; o <<= 1) { const int y = __shfl_up(inc,o); if (lane >= o && y > inc) inc = y; }
+      const int exc = __shfl_up(inc,1);
+      const bool st = lane < NS && (lane == 0 || b_k > exc);
+      const uint64_t sm = __ballot(st);
+      const bool last = lane < NS && (lane == NS-1 || ((sm >> (lane+1)) & 1));
+      const int cid = __popcll(sm & ((2ull << lane)-1))-1;
+      if (st)   { compB[cid] = b_k; s_cb[cid] = b_k; }
+      if (last) { compE[cid] = inc; s_ce[cid] = inc; }
+      C = __popcll(sm);
+    }
+  else if (lane == 0)
     { int k = 0;
       while (k < NS)
         { int cb = R.eintvl.b(k), ce = R.eintvl.e(k);
@@ -1116,7 +1130,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
           C++;
         }
     }
-  C = __shfl(C,0);
+  if (!(NS <= WAVE && ccap >= WAVE)) C = __shfl(C,0);
   if (C > ccap) { overflow |= 2; C = ccap; }
   const bool smallc = on16 && C <= SCOMP;               // components, walls and boundaries all on chip
   // (with the flags on chip the walls are kept as candidate numbers, a byte each, where the SELF flags were -- those
@@ -1124,6 +1138,58 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   uint16_t *s_bnd = cf ? s16+2*n_c : s16+n_c;
   uint8_t *s_wq = F.fs;
   wave_sync();
+  int N = 0;
+  if (cf && smallc)
+    { // The boundaries = the union of the component starts / ends inside (0,plen) and the OTHERS walls outside every
+      // component, in order, then plen.  Every member's place in that order is a count: for a wall, the transitions
+      // below it (two per component that ends at or before it) plus the walls below it; for a transition, its number
+      // among the transitions plus the walls below it (a running count kept per candidate).  No merge loop.
+      bool vb = false, ve = false;
+      int cbk = 0, cek = 0;
+      if (lane < C) { cbk = s_cb[lane]; cek = s_ce[lane]; vb = cbk >= 1 && cbk < plen; ve = cek >= 1 && cek < plen; }
+      const uint64_t tb = __ballot(vb), te = __ballot(ve), ltm = (1ull << lane)-1;
+      int nwl = 0;                                      // walls so far that are no transition
+      for (int base = 0; base < n_c; base += WAVE)
+        { const int q = base+lane;
+          bool w = false; int i = 0, below = 0;
+          if (q < n_c && (F.fo[q] & CP_W_WALL_O))
+            { i = F.pos[q];
+              int a2 = 0, z = C-1, in = 0;              // a2: components that end at or before i
+              while (a2 <= z)
+                { const int m = (a2+z) >> 1;
+                  if (i < s_cb[m]) z = m-1;
+                  else if (i >= s_ce[m]) a2 = m+1;
+                  else { in = 1; break; }
+                }
+              if (!in)
+                { const uint64_t am = a2 >= WAVE ? ~0ull : ((1ull << a2)-1);
+                  const bool int_ = a2 > 0 && s_ce[a2-1] == i && ((te >> (a2-1)) & 1);   // the wall sits on a component's end: that transition stands for it
+                  below = __popcll(tb & am)+__popcll(te & am)-(int_ ? 1 : 0);
+                  w = !int_;
+                }
+            }
+          const uint64_t wm = __ballot(w);
+          if (w) s_bnd[below+nwl+__popcll(wm & ltm)] = (uint16_t)i;
+          if (q < n_c) s_wq[q] = (uint8_t)(nwl+__popcll(wm & (ltm | (1ull << lane))));   // walls up to and including candidate q
+          nwl += __popcll(wm);
+        }
+      wave_sync();
+      if (vb || ve)
+        { // candidates below the transition -> walls below it
+          auto walls_below = [&](int t) -> int
+            { int lo = 0, hi = n_c;                     // first candidate at or beyond t
+              while (lo < hi) { const int m = (lo+hi) >> 1; if ((int)F.pos[m] < t) lo = m+1; else hi = m; }
+              return lo > 0 ? (int)s_wq[lo-1] : 0;
+            };
+          const int tbefore = __popcll(tb & ltm)+__popcll(te & ltm);
+          if (vb) s_bnd[tbefore+walls_below(cbk)] = (uint16_t)cbk;
+          if (ve) s_bnd[tbefore+(vb ? 1 : 0)+walls_below(cek)] = (uint16_t)cek;
+        }
+      N = __popcll(tb)+__popcll(te)+nwl+1;
+      if (lane == 0) s_bnd[N-1] = (uint16_t)plen;
+    }
+  else
+    {
   int n_w = 0;                                         // OTHERS walls outside error regions, in order
   for (int base = 0; base < n_c; base += WAVE)
     { const int q = base+lane;
@@ -1152,7 +1218,6 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
       n_w += __popcll(m);
     }
   wave_sync();
-  int N = 0;
   if (lane == 0)                                       // merge: transitions, walls, plen
     { int ci = 0, phase = 0, wi = 0, last = 0;         // phase 0: next transition is compB[ci], 1: compE[ci]
       while (true)
@@ -1174,7 +1239,8 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
       if (N < icap) { if (smallc) s_bnd[N] = (uint16_t)plen; else bnd[N] = plen; }
       N++;
     }
-  N = __shfl(N,0);
+    }
+  if (!(cf && smallc)) N = __shfl(N,0);
   if (N > icap) overflow |= 2;
   wave_sync();
   for (int k = lane; k < N && k < icap; k += WAVE)     // wall.c:928-946, one lane per interval
