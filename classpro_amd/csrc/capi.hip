@@ -482,7 +482,9 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   ENSURE(ws->eff,(size_t)totalI*2*4);
   ENSURE(ws->rpos,(size_t)totalI*2);
   ENSURE(ws->asgn,(size_t)totalI*2);
-  HIPCHK(hipMemsetAsync(ws->asgn.p,0xff,(size_t)totalI*2,st));
+  // (the fw / bw assignments are only read back through the stage API: the whole-path call leaves the array as it is --
+  //  a 37-MB fill that sat 0.7 ms in the serial path of every 1-Gbase sub-batch)
+  if (last_stage < CP_STAGE_LABELS) HIPCHK(hipMemsetAsync(ws->asgn.p,0xff,(size_t)totalI*2,st));
   // size classes (kernels.hip: REL_SMALL_*): M <= 128 four reads per wave, up to 1024 one read per wave, larger (or a
   // read beyond 65535 k-mers): the sequential kernel
   rc = launch_order_by_work(ws,(const int32_t *)ws->nrel.p,nreads,0,(int32_t *)ws->perm.p,st);
@@ -519,7 +521,7 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   hipLaunchKernelGGL(k_classify_unrel,dim3(nreads < 1024 ? nreads : 1024),dim3(WAVE),0,ws->aux,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
                      (int32_t *)ws->ord.p);
-  hipLaunchKernelGGL((k_classify_unrel_grp<UNREL_SMALL_MAXN,1024,2>),dim3((nreads+1)/2 < 2048 ? (nreads+1)/2 : 2048),dim3(WAVE),0,ws->aux,
+  hipLaunchKernelGGL((k_classify_unrel_grp<UNREL_SMALL_MAXN,1024,UNREL_BIG_G>),dim3((nreads+UNREL_BIG_G-1)/UNREL_BIG_G < 2048 ? (nreads+UNREL_BIG_G-1)/UNREL_BIG_G : 2048),dim3(WAVE),0,ws->aux,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
                      (const int32_t *)ws->perm.p);
   HIPCHK(hipEventRecord(ws->ev_join,ws->aux));
@@ -606,6 +608,7 @@ extern "C" int cp_get_rel_asgn(cp_workspace *ws, int8_t *fw, int8_t *bw, int64_t
 { if (!ws) return set_err(CP_EINVAL,"cp_get_rel_asgn: null workspace");
   if (capacity < ws->totalI) return set_err(CP_EINVAL,"cp_get_rel_asgn: capacity too small");
   if (ws->last_stage < CP_STAGE_CLASS_REL) return set_err(CP_EINVAL,"cp_get_rel_asgn: stage not run");
+  if (ws->last_stage == CP_STAGE_LABELS) return set_err(CP_EINVAL,"cp_get_rel_asgn: run cp_run_stages up to CP_STAGE_CLASS_REL or CP_STAGE_CLASS_ALL (the whole-path call does not keep the two assignments of reads without reliable intervals defined)");
   int rc = cp_workspace_check(ws);
   if (rc != CP_OK) return rc;
   size_t n = (size_t)ws->totalI;

@@ -245,7 +245,11 @@ __device__ __forceinline__ T block_scan_excl_256(T x, T *tmp, T *total)
 // per round, and a wave reduction gives the block its offset.  A tile only waits for tiles with smaller block ids, which
 // the dispatcher started before it.  The last tile writes the totals.
 #define SCAN_TILE 1024
-struct cp_scan_state { int64_t s[3]; int32_t epoch; int32_t pad_; };
+// A tile's three sums are published as three 8-byte granules {sum (32 bits), epoch}: one agent-scope store each carries
+// data and tag together, so neither side needs a fence.  (With a separate flag behind a __threadfence() every tile
+// wrote back its XCD's whole L2 -- dirtied all the while by the other stream's kernels -- and the kernel took 0.8 ms
+// in the pipeline for 10 us of work.)  A tile's sums stay below 2^31: 1024 reads of fewer than 60 000 candidates.
+struct cp_scan_state { unsigned long long g[3]; unsigned long long pad_; };
 __global__ void __launch_bounds__(256)
 k_prefix_caps_mb(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__restrict__ c, int n, int64_t *__restrict__ totals,
                  cp_scan_state *__restrict__ state, int epoch)
@@ -262,22 +266,22 @@ k_prefix_caps_mb(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__re
       off[q] = block_scan_excl_256<int64_t>(s4,tmp,&tot);
       sum[q] = tot;
     }
-  if (t == 0)
-    { state[tile].s[0] = sum[0]; state[tile].s[1] = sum[1]; state[tile].s[2] = sum[2];
-      __threadfence();
-      __hip_atomic_store(&state[tile].epoch,epoch,__ATOMIC_RELEASE,__HIP_MEMORY_SCOPE_AGENT);
-    }
+  if (t < 3)
+    __hip_atomic_store(&state[tile].g[t],((unsigned long long)sum[t] << 32) | (unsigned)epoch,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
   if (t < WAVE)                                           // look back, 64 tiles per round
     { int64_t p0 = 0, p1 = 0, p2 = 0;
       for (int base = 0; base < tile; base += WAVE)
         { const int j = base+t;
           int64_t v0 = 0, v1 = 0, v2 = 0;
           if (j < tile)
-            { while (__hip_atomic_load(&state[j].epoch,__ATOMIC_ACQUIRE,__HIP_MEMORY_SCOPE_AGENT) != epoch)
+            { unsigned long long g0, g1, g2;
+              while (((g0 = __hip_atomic_load(&state[j].g[0],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT)) & 0xffffffffull) != (unsigned)epoch)
                 __builtin_amdgcn_s_sleep(1);
-              v0 = __hip_atomic_load(&state[j].s[0],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
-              v1 = __hip_atomic_load(&state[j].s[1],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
-              v2 = __hip_atomic_load(&state[j].s[2],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
+              while (((g1 = __hip_atomic_load(&state[j].g[1],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT)) & 0xffffffffull) != (unsigned)epoch)
+                __builtin_amdgcn_s_sleep(1);
+              while (((g2 = __hip_atomic_load(&state[j].g[2],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT)) & 0xffffffffull) != (unsigned)epoch)
+                __builtin_amdgcn_s_sleep(1);
+              v0 = (int64_t)(g0 >> 32); v1 = (int64_t)(g1 >> 32); v2 = (int64_t)(g2 >> 32);
             }
           for (int o = 32; o > 0; o >>= 1)
             { v0 += __shfl_xor(v0,o); v1 += __shfl_xor(v1,o); v2 += __shfl_xor(v2,o); }
@@ -1722,6 +1726,11 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
 #endif
 #ifndef UNREL_SMALL_MAXN
 #define UNREL_SMALL_MAXN 256
+#endif
+// the class above it holds a handful of reads per sub-batch, each a chain of several hundred updates: one read per wave
+// (eight speculative slots) -- with two, the stage's main kernel waited 0.5 ms for this one at its end
+#ifndef UNREL_BIG_G
+#define UNREL_BIG_G 1
 #endif
 #ifndef REL_EXTRA_ATTR
 #define REL_EXTRA_ATTR

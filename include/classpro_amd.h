@@ -196,7 +196,7 @@ int cp_run_stages(const cp_params *p, cp_workspace *ws,
  * are the exclusive prefix sums of the per-read capacities returned in cap_off[nreads+1]. */
 int cp_get_counts(cp_workspace *ws, int32_t *n_cand, int32_t *n_intvl, int32_t *n_rel, int64_t *cap_off);
 int cp_get_intervals(cp_workspace *ws, cp_intvl *intvl, cp_intvl *rintvl, int64_t capacity);
-int cp_get_rel_asgn(cp_workspace *ws, int8_t *fw, int8_t *bw, int64_t capacity);
+int cp_get_rel_asgn(cp_workspace *ws, int8_t *fw, int8_t *bw, int64_t capacity);   /* after a run that stopped at CP_STAGE_CLASS_REL or CP_STAGE_CLASS_ALL */
 int cp_get_bitmap(cp_workspace *ws, uint64_t *words, int64_t nwords);
 
 /* calc_seq_context (src/context.c:8-108), batched and dense: d_lctx/d_rctx are [total_bases][3]
