@@ -358,7 +358,7 @@ static int launch_prefix_caps(cp_workspace *ws, int64_t *a, int64_t *b, int64_t 
     { HIPCHK(hipMemsetAsync(ws->scan_state.p,0,ws->scan_state.cap,st)); ws->scan_epoch = 0; }
   if (++ws->scan_epoch == 0x7fffffff)                     // (never in practice: the tags wrap, start over from a cleared array)
     { HIPCHK(hipMemsetAsync(ws->scan_state.p,0,ws->scan_state.cap,st)); ws->scan_epoch = 1; }
-  hipLaunchKernelGGL(k_prefix_caps_mb,dim3(tiles),dim3(256),0,st,a,b,c,n,totals,(cp_scan_state *)ws->scan_state.p,ws->scan_epoch);
+  hipLaunchKernelGGL(k_prefix_caps_mb,dim3(tiles),dim3(WAVE),0,st,a,b,c,n,totals,(cp_scan_state *)ws->scan_state.p,ws->scan_epoch);
   HIPCHK(hipGetLastError());
   return CP_OK;
 }
@@ -369,8 +369,8 @@ static int launch_order_by_work(cp_workspace *ws, const int32_t *key, int n, int
   const int blocks = (n+ORDER_TILE-1)/ORDER_TILE;
   HIPCHK(hipMemsetAsync(ws->order_tmp.p,0,(size_t)2*ORDER_BINS*4,st));
   int32_t *ghist = (int32_t *)ws->order_tmp.p, *gcur = ghist+ORDER_BINS;
-  hipLaunchKernelGGL(k_order_hist,dim3(blocks),dim3(256),0,st,key,n,shift,ghist);
-  hipLaunchKernelGGL(k_order_scatter,dim3(blocks),dim3(256),0,st,key,n,shift,(const int32_t *)ghist,gcur,perm);
+  hipLaunchKernelGGL(k_order_hist,dim3(blocks),dim3(WAVE),0,st,key,n,shift,ghist);
+  hipLaunchKernelGGL(k_order_scatter,dim3(blocks),dim3(WAVE),0,st,key,n,shift,(const int32_t *)ghist,gcur,perm);
   HIPCHK(hipGetLastError());
   return CP_OK;
 }

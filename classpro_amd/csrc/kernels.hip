@@ -250,54 +250,53 @@ __device__ __forceinline__ T block_scan_excl_256(T x, T *tmp, T *total)
 // wrote back its XCD's whole L2 -- dirtied all the while by the other stream's kernels -- and the kernel took 0.8 ms
 // in the pipeline for 10 us of work.)  A tile's sums stay below 2^31: 1024 reads of fewer than 60 000 candidates.
 struct cp_scan_state { unsigned long long g[3]; unsigned long long pad_; };
-__global__ void __launch_bounds__(256)
+// One WAVE per tile of 1024 values, 16 consecutive values per lane: beside the other stream's 50 000-block kernels a
+// single free wave slot turns up at once, four on one CU (a 256-thread block) only now and then -- the 256-thread form
+// of this kernel still took 1 ms in the pipeline (profiles/r03_timeline_*.txt), all of it waiting to be placed.
+__global__ void __launch_bounds__(WAVE)
 k_prefix_caps_mb(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__restrict__ c, int n, int64_t *__restrict__ totals,
                  cp_scan_state *__restrict__ state, int epoch)
-{ __shared__ int64_t tmp[4], pre[3];
-  const int t = threadIdx.x, tile = blockIdx.x, i0 = tile*SCAN_TILE+4*t;
+{ const int t = threadIdx.x, tile = blockIdx.x, i0 = tile*SCAN_TILE+16*t;
   int64_t *arr[3] = { a, b, c };
-  int64_t x[3][4], off[3], sum[3];
+  int64_t off[3], sum[3], pre[3];
 #pragma unroll
   for (int q = 0; q < 3; q++)
-    { int64_t s4 = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) { x[q][k] = (i0+k < n) ? arr[q][i0+k] : 0; s4 += x[q][k]; }
-      int64_t tot;
-      off[q] = block_scan_excl_256<int64_t>(s4,tmp,&tot);
-      sum[q] = tot;
+    { int64_t s16 = 0;
+      for (int k = 0; k < 16; k++) s16 += (i0+k < n) ? arr[q][i0+k] : 0;
+      int64_t inc = s16;
+      for (int o = 1; o < WAVE; o <<= 1) { const int64_t y = __shfl_up(inc,o); if (t >= o) inc += y; }
+      off[q] = inc-s16;
+      sum[q] = __shfl(inc,WAVE-1);
     }
   if (t < 3)
-    __hip_atomic_store(&state[tile].g[t],((unsigned long long)sum[t] << 32) | (unsigned)epoch,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
-  if (t < WAVE)                                           // look back, 64 tiles per round
-    { int64_t p0 = 0, p1 = 0, p2 = 0;
-      for (int base = 0; base < tile; base += WAVE)
-        { const int j = base+t;
-          int64_t v0 = 0, v1 = 0, v2 = 0;
-          if (j < tile)
-            { unsigned long long g0, g1, g2;
-              while (((g0 = __hip_atomic_load(&state[j].g[0],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT)) & 0xffffffffull) != (unsigned)epoch)
-                __builtin_amdgcn_s_sleep(1);
-              while (((g1 = __hip_atomic_load(&state[j].g[1],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT)) & 0xffffffffull) != (unsigned)epoch)
-                __builtin_amdgcn_s_sleep(1);
-              while (((g2 = __hip_atomic_load(&state[j].g[2],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT)) & 0xffffffffull) != (unsigned)epoch)
-                __builtin_amdgcn_s_sleep(1);
-              v0 = (int64_t)(g0 >> 32); v1 = (int64_t)(g1 >> 32); v2 = (int64_t)(g2 >> 32);
-            }
-          for (int o = 32; o > 0; o >>= 1)
-            { v0 += __shfl_xor(v0,o); v1 += __shfl_xor(v1,o); v2 += __shfl_xor(v2,o); }
-          p0 += v0; p1 += v1; p2 += v2;
-        }
-      if (t == 0) { pre[0] = p0; pre[1] = p1; pre[2] = p2; }
+    { const int64_t mine = t == 0 ? sum[0] : t == 1 ? sum[1] : sum[2];
+      __hip_atomic_store(&state[tile].g[t],((unsigned long long)mine << 32) | (unsigned)epoch,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
     }
-  __syncthreads();
+  { int64_t p0 = 0, p1 = 0, p2 = 0;                       // look back, 64 tiles per round
+    for (int base = 0; base < tile; base += WAVE)
+      { const int j = base+t;
+        int64_t v0 = 0, v1 = 0, v2 = 0;
+        if (j < tile)
+          { unsigned long long g0, g1, g2;
+            while (((g0 = __hip_atomic_load(&state[j].g[0],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT)) & 0xffffffffull) != (unsigned)epoch)
+              __builtin_amdgcn_s_sleep(1);
+            while (((g1 = __hip_atomic_load(&state[j].g[1],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT)) & 0xffffffffull) != (unsigned)epoch)
+              __builtin_amdgcn_s_sleep(1);
+            while (((g2 = __hip_atomic_load(&state[j].g[2],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT)) & 0xffffffffull) != (unsigned)epoch)
+              __builtin_amdgcn_s_sleep(1);
+            v0 = (int64_t)(g0 >> 32); v1 = (int64_t)(g1 >> 32); v2 = (int64_t)(g2 >> 32);
+          }
+        for (int o = 32; o > 0; o >>= 1)
+          { v0 += __shfl_xor(v0,o); v1 += __shfl_xor(v1,o); v2 += __shfl_xor(v2,o); }
+        p0 += v0; p1 += v1; p2 += v2;
+      }
+    pre[0] = p0; pre[1] = p1; pre[2] = p2;
+  }
 #pragma unroll
   for (int q = 0; q < 3; q++)
     { int64_t run = pre[q]+off[q];
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-        { if (i0+k < n) arr[q][i0+k] = run;
-          run += x[q][k];
-        }
+      for (int k = 0; k < 16; k++)
+        if (i0+k < n) { const int64_t x = arr[q][i0+k]; arr[q][i0+k] = run; run += x; }
       if (tile == (int)gridDim.x-1 && t == 0)
         { arr[q][n] = pre[q]+sum[q];
           if (totals) totals[q] = pre[q]+sum[q];
@@ -314,50 +313,50 @@ k_prefix_caps_mb(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__re
 // ---------------------------------------------------------------------------------------------
 #define ORDER_BINS 1024
 #define ORDER_TILE 1024
-// One 256-thread block per 1024 reads (a single block took 0.2-0.9 ms in front of a 50 000-block kernel, three times
+// One wave per 1024 reads (a single 1024-thread block took 0.2-0.9 ms in front of a 50 000-block kernel, three times
 // per sub-batch): k_order_hist adds every block's LDS histogram to the global one; k_order_scatter turns the global
 // histogram into bin starts (every block for itself: 1024 values), reserves, per block and non-empty bin, a range of
 // the bin with ONE global atomic, and places its reads there.  `ghist` and `gcur` (ORDER_BINS ints each, adjacent) are
 // zero on entry: the launcher clears them.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(WAVE)
 k_order_hist(const int32_t *__restrict__ key, int n, int shift, int32_t *__restrict__ ghist)
 { __shared__ int hist[ORDER_BINS];
   const int t = threadIdx.x, i0 = blockIdx.x*ORDER_TILE;
-  for (int k = t; k < ORDER_BINS; k += 256) hist[k] = 0;
+  for (int k = t; k < ORDER_BINS; k += WAVE) hist[k] = 0;
   __syncthreads();
-  for (int i = i0+t; i < i0+ORDER_TILE && i < n; i += 256)
+  for (int i = i0+t; i < i0+ORDER_TILE && i < n; i += WAVE)
     { const int b = key[i] >> shift;
       atomicAdd(&hist[b < ORDER_BINS ? b : ORDER_BINS-1],1);
     }
   __syncthreads();
-  for (int k = t; k < ORDER_BINS; k += 256)
+  for (int k = t; k < ORDER_BINS; k += WAVE)
     if (hist[k]) atomicAdd(&ghist[k],hist[k]);
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(WAVE)
 k_order_scatter(const int32_t *__restrict__ key, int n, int shift, const int32_t *__restrict__ ghist, int32_t *__restrict__ gcur,
                 int32_t *__restrict__ perm)
 { __shared__ int hist[ORDER_BINS];                        // this block's count per bin, then its cursor inside the bin
   __shared__ int start[ORDER_BINS];
-  __shared__ int tmp[4];
   const int t = threadIdx.x, i0 = blockIdx.x*ORDER_TILE;
-  for (int k = t; k < ORDER_BINS; k += 256) hist[k] = 0;
-  { // descending keys: bin b starts after all larger bins.  Thread t owns the four bins 1023-4t .. 1020-4t
-    int g4[4], s4 = 0;
+  for (int k = t; k < ORDER_BINS; k += WAVE) hist[k] = 0;
+  { // descending keys: bin b starts after all larger bins.  Lane t owns the sixteen bins 1023-16t .. 1008-16t
+    int g16[16], s16 = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { g4[k] = ghist[ORDER_BINS-1-(4*t+k)]; s4 += g4[k]; }
-    int tot;
-    int run = block_scan_excl_256<int>(s4,tmp,&tot);
+    for (int k = 0; k < 16; k++) { g16[k] = ghist[ORDER_BINS-1-(16*t+k)]; s16 += g16[k]; }
+    int inc = s16;
+    for (int o = 1; o < WAVE; o <<= 1) { const int y = __shfl_up(inc,o); if (t >= o) inc += y; }
+    int run = inc-s16;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { start[ORDER_BINS-1-(4*t+k)] = run; run += g4[k]; }
+    for (int k = 0; k < 16; k++) { start[ORDER_BINS-1-(16*t+k)] = run; run += g16[k]; }
   }
   __syncthreads();
-  int b[4], r[4];
+  int b[16], r[16];
 #pragma unroll
-  for (int k = 0; k < 4; k++)
-    { const int i = i0+t+256*k;
+  for (int k = 0; k < 16; k++)
+    { const int i = i0+t+WAVE*k;
       b[k] = -1; r[k] = 0;
-      if (i < n && i < i0+ORDER_TILE)
+      if (i < n)
         { int q = key[i] >> shift;
           if (q >= ORDER_BINS) q = ORDER_BINS-1;
           b[k] = q;
@@ -365,12 +364,12 @@ k_order_scatter(const int32_t *__restrict__ key, int n, int shift, const int32_t
         }
     }
   __syncthreads();
-  for (int k = t; k < ORDER_BINS; k += 256)
+  for (int k = t; k < ORDER_BINS; k += WAVE)
     if (hist[k]) start[k] += atomicAdd(&gcur[k],hist[k]); // this block's range of bin k
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (b[k] >= 0) perm[start[b[k]]+r[k]] = i0+t+256*k;
+  for (int k = 0; k < 16; k++)
+    if (b[k] >= 0) perm[start[b[k]]+r[k]] = i0+t+WAVE*k;
 }
 
 // ---------------------------------------------------------------------------------------------
