@@ -229,6 +229,7 @@ struct cp_workspace
          s_cap, s_rcap, s_dummy, s_key, s_seg, s_aux, s_mi, s_rep, s_repcnt, scan_state, order_tmp;
     int      scan_epoch;      // tag of the next k_prefix_caps_mb launch (its state array is never cleared)
     int64_t *h_totals;        // pinned: [totalI, totalE, totalH]
+    unsigned long long *h_tot64, *d_tot64;   // pinned, and its device address: the totals as {value << 24 | launch tag}, written by the kernel itself
     int32_t *h_err;           // pinned
     // shape of the last run
     int      nreads;
@@ -276,6 +277,8 @@ extern "C" int cp_workspace_create(cp_workspace **out)
   if (!ws) return set_err(CP_ENOMEM,"cp_workspace_create: out of memory");
   ws->retired = new std::vector<void *>();
   hipError_t e = hipHostMalloc((void **)&ws->h_totals,4*sizeof(int64_t),hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&ws->h_tot64,4*sizeof(unsigned long long),hipHostMallocDefault);
+  if (e == hipSuccess) { memset(ws->h_tot64,0,4*sizeof(unsigned long long)); e = hipHostGetDevicePointer((void **)&ws->d_tot64,ws->h_tot64,0); }
   if (e == hipSuccess) e = hipHostMalloc((void **)&ws->h_err,4*sizeof(int32_t),hipHostMallocDefault);
   // the error words (device): [0] find_wall / classification, [1] find_seeds, [2] profile decode.  Sticky: kernels OR
   // into them, only cp_workspace_check reads and clears them, so a flag raised by any call since the last check is seen
@@ -308,6 +311,7 @@ extern "C" void cp_workspace_destroy(cp_workspace *ws)
   if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
   if (ws->ev_join) (void)hipEventDestroy(ws->ev_join);
   if (ws->h_totals) (void)hipHostFree(ws->h_totals);
+  if (ws->h_tot64) (void)hipHostFree(ws->h_tot64);
   if (ws->h_err) (void)hipHostFree(ws->h_err);
   free(ws);
 }
@@ -350,7 +354,8 @@ extern "C" int cp_scan_candidates(const cp_params *p, const uint16_t *d_prof, in
 }
 
 // exclusive prefix sums of the three capacity arrays (+ totals), one block per 1024 reads
-static int launch_prefix_caps(cp_workspace *ws, int64_t *a, int64_t *b, int64_t *c, int n, int64_t *totals, hipStream_t st)
+static int launch_prefix_caps(cp_workspace *ws, int64_t *a, int64_t *b, int64_t *c, int n, int64_t *totals, hipStream_t st,
+                              bool to_host = false)
 { const int tiles = (n+SCAN_TILE-1)/SCAN_TILE;
   const size_t c0 = ws->scan_state.cap;
   ENSURE(ws->scan_state,(size_t)tiles*sizeof(cp_scan_state));
@@ -358,19 +363,21 @@ static int launch_prefix_caps(cp_workspace *ws, int64_t *a, int64_t *b, int64_t 
     { HIPCHK(hipMemsetAsync(ws->scan_state.p,0,ws->scan_state.cap,st)); ws->scan_epoch = 0; }
   if (++ws->scan_epoch == 0x7fffffff)                     // (never in practice: the tags wrap, start over from a cleared array)
     { HIPCHK(hipMemsetAsync(ws->scan_state.p,0,ws->scan_state.cap,st)); ws->scan_epoch = 1; }
-  hipLaunchKernelGGL(k_prefix_caps_mb,dim3(tiles),dim3(WAVE),0,st,a,b,c,n,totals,(cp_scan_state *)ws->scan_state.p,ws->scan_epoch);
+  hipLaunchKernelGGL(k_prefix_caps_mb,dim3(tiles),dim3(WAVE),0,st,a,b,c,n,totals,(cp_scan_state *)ws->scan_state.p,ws->scan_epoch,
+                     to_host ? ws->d_tot64 : (unsigned long long *)NULL);
   HIPCHK(hipGetLastError());
   return CP_OK;
 }
 
 // perm[] = read ids by decreasing key >> shift (kernels.hip: k_order_hist / k_order_scatter)
 static int launch_order_by_work(cp_workspace *ws, const int32_t *key, int n, int shift, int32_t *perm, hipStream_t st)
-{ ENSURE(ws->order_tmp,(size_t)2*ORDER_BINS*4);
+{ const size_t c0 = ws->order_tmp.cap;
+  ENSURE(ws->order_tmp,(size_t)(2*ORDER_BINS+1)*4);
+  if (ws->order_tmp.cap != c0) HIPCHK(hipMemsetAsync(ws->order_tmp.p,0,ws->order_tmp.cap,st));   // zero once: the scatter kernel's last block leaves it zero
   const int blocks = (n+ORDER_TILE-1)/ORDER_TILE;
-  HIPCHK(hipMemsetAsync(ws->order_tmp.p,0,(size_t)2*ORDER_BINS*4,st));
   int32_t *ghist = (int32_t *)ws->order_tmp.p, *gcur = ghist+ORDER_BINS;
   hipLaunchKernelGGL(k_order_hist,dim3(blocks),dim3(WAVE),0,st,key,n,shift,ghist);
-  hipLaunchKernelGGL(k_order_scatter,dim3(blocks),dim3(WAVE),0,st,key,n,shift,(const int32_t *)ghist,gcur,perm);
+  hipLaunchKernelGGL(k_order_scatter,dim3(blocks),dim3(WAVE),0,st,key,n,shift,ghist,gcur,perm);
   HIPCHK(hipGetLastError());
   return CP_OK;
 }
@@ -408,22 +415,44 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   // Gbases/s without: the other stream's wide kernels are what fills the machine, and pre-empting them costs more than
   // the head's latency gains.)
   hipStream_t hs = st;
-  HIPCHK(hipMemsetAsync(ws->nintvl.p,0,(size_t)nreads*4,hs));
-  HIPCHK(hipMemsetAsync(ws->nrel.p,0,(size_t)nreads*4,hs));
+  if (last_stage < CP_STAGE_LABELS)                      // (the whole path writes both counts for every read: the zeros are for the
+    { HIPCHK(hipMemsetAsync(ws->nintvl.p,0,(size_t)nreads*4,hs));      //  stage API's read-back after an early stop)
+      HIPCHK(hipMemsetAsync(ws->nrel.p,0,(size_t)nreads*4,hs));
+    }
   int rc = launch_scan(&p->host,d_prof,total_kmers,(uint64_t *)ws->bitmap.p,ws->nwords,hs);
   if (rc != CP_OK) return rc;
   hipLaunchKernelGGL(k_count_caps,dim3(nreads),dim3(WAVE),0,hs,
                      (const uint64_t *)ws->bitmap.p,d_prof_off,nreads,
                      (int32_t *)ws->ncand.p,(int64_t *)ws->ioff.p,(int64_t *)ws->eoff.p,(int64_t *)ws->hoff.p);
   ENSURE(ws->dtot,32);
-  rc = launch_prefix_caps(ws,(int64_t *)ws->ioff.p,(int64_t *)ws->eoff.p,(int64_t *)ws->hoff.p,nreads,(int64_t *)ws->dtot.p,hs);
+  rc = launch_prefix_caps(ws,(int64_t *)ws->ioff.p,(int64_t *)ws->eoff.p,(int64_t *)ws->hoff.p,nreads,(int64_t *)ws->dtot.p,hs,true);
   if (rc != CP_OK) return rc;
   if (last_stage == CP_STAGE_SCAN)
     return CP_OK;
 
-  // the only host round trip of the pipeline
-  HIPCHK(hipMemcpyAsync(&ws->h_totals[0],ws->dtot.p,24,hipMemcpyDeviceToHost,hs));
-  HIPCHK(hipStreamSynchronize(hs));
+  // the only host round trip of the pipeline: the last tile of the prefix sums stores the three totals, tagged with the
+  // launch's number, into pinned host memory and the host polls for them (every so often it asks the stream whether
+  // it died instead)
+  { const unsigned tag = (unsigned)ws->scan_epoch & 0xffffffu;
+    volatile unsigned long long *ht = ws->h_tot64;
+    for (unsigned spins = 1; ; spins++)
+      { const unsigned long long g0 = __atomic_load_n(&ht[0],__ATOMIC_ACQUIRE), g1 = __atomic_load_n(&ht[1],__ATOMIC_ACQUIRE),
+                                 g2 = __atomic_load_n(&ht[2],__ATOMIC_ACQUIRE);
+        if ((g0 & 0xffffffu) == tag && (g1 & 0xffffffu) == tag && (g2 & 0xffffffu) == tag)
+          { ws->h_totals[0] = (int64_t)(g0 >> 24); ws->h_totals[1] = (int64_t)(g1 >> 24); ws->h_totals[2] = (int64_t)(g2 >> 24);
+            break;
+          }
+        if ((spins & 0x3fff) == 0)
+          { const hipError_t q = hipStreamQuery(hs);
+            if (q != hipErrorNotReady)                   // the stream is idle (or failed) and the totals never came
+              { if (q != hipSuccess) return set_err(CP_EHIP,std::string("cp_run_stages: ")+hipGetErrorString(q));
+                HIPCHK(hipMemcpy(&ws->h_totals[0],ws->dtot.p,24,hipMemcpyDeviceToHost));
+                break;
+              }
+            (void)hipGetLastError();
+          }
+      }
+  }
   const int64_t totalI = ws->h_totals[0], totalE = ws->h_totals[1], totalH = ws->h_totals[2];
   ws->totalI = totalI; ws->totalE = totalE; ws->totalH = totalH;
 

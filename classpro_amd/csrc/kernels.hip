@@ -255,7 +255,7 @@ struct cp_scan_state { unsigned long long g[3]; unsigned long long pad_; };
 // of this kernel still took 1 ms in the pipeline (profiles/r03_timeline_*.txt), all of it waiting to be placed.
 __global__ void __launch_bounds__(WAVE)
 k_prefix_caps_mb(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__restrict__ c, int n, int64_t *__restrict__ totals,
-                 cp_scan_state *__restrict__ state, int epoch)
+                 cp_scan_state *__restrict__ state, int epoch, unsigned long long *__restrict__ host_tot)
 { const int t = threadIdx.x, tile = blockIdx.x, i0 = tile*SCAN_TILE+16*t;
   int64_t *arr[3] = { a, b, c };
   int64_t off[3], sum[3], pre[3];
@@ -300,6 +300,11 @@ k_prefix_caps_mb(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__re
       if (tile == (int)gridDim.x-1 && t == 0)
         { arr[q][n] = pre[q]+sum[q];
           if (totals) totals[q] = pre[q]+sum[q];
+          // the totals straight into pinned host memory, value and launch tag in one 8-byte store: the host polls for
+          // them (capi.hip) instead of paying a copy engine's start-up and an interrupt's wake-up in every sub-batch
+          if (host_tot)
+            __hip_atomic_store(&host_tot[q],((unsigned long long)(pre[q]+sum[q]) << 24) | ((unsigned)epoch & 0xffffffu),
+                               __ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -316,8 +321,8 @@ k_prefix_caps_mb(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__re
 // One wave per 1024 reads (a single 1024-thread block took 0.2-0.9 ms in front of a 50 000-block kernel, three times
 // per sub-batch): k_order_hist adds every block's LDS histogram to the global one; k_order_scatter turns the global
 // histogram into bin starts (every block for itself: 1024 values), reserves, per block and non-empty bin, a range of
-// the bin with ONE global atomic, and places its reads there.  `ghist` and `gcur` (ORDER_BINS ints each, adjacent) are
-// zero on entry: the launcher clears them.
+// the bin with ONE global atomic, and places its reads there.  `ghist` and `gcur` (ORDER_BINS ints each, adjacent, a
+// counter of finished blocks behind them) are zero on entry: the last block of the previous sort cleared them.
 __global__ void __launch_bounds__(WAVE)
 k_order_hist(const int32_t *__restrict__ key, int n, int shift, int32_t *__restrict__ ghist)
 { __shared__ int hist[ORDER_BINS];
@@ -334,7 +339,7 @@ k_order_hist(const int32_t *__restrict__ key, int n, int shift, int32_t *__restr
 }
 
 __global__ void __launch_bounds__(WAVE)
-k_order_scatter(const int32_t *__restrict__ key, int n, int shift, const int32_t *__restrict__ ghist, int32_t *__restrict__ gcur,
+k_order_scatter(const int32_t *__restrict__ key, int n, int shift, int32_t *__restrict__ ghist, int32_t *__restrict__ gcur,
                 int32_t *__restrict__ perm)
 { __shared__ int hist[ORDER_BINS];                        // this block's count per bin, then its cursor inside the bin
   __shared__ int start[ORDER_BINS];
@@ -370,6 +375,16 @@ k_order_scatter(const int32_t *__restrict__ key, int n, int shift, const int32_t
 #pragma unroll
   for (int k = 0; k < 16; k++)
     if (b[k] >= 0) perm[start[b[k]]+r[k]] = i0+t+WAVE*k;
+  // the last block to get here leaves the histogram and the cursors zero for the next sort (a counter behind them
+  // counts the blocks that are done with both): no clearing launch in front of every sort
+  __shared__ int s_last;
+  __syncthreads();
+  if (t == 0) s_last = atomicAdd(&gcur[ORDER_BINS],1) == (int)gridDim.x-1;
+  __syncthreads();
+  if (s_last)
+    { for (int k = t; k < 2*ORDER_BINS; k += WAVE) ghist[k] = 0;      // (gcur follows ghist)
+      if (t == 0) gcur[ORDER_BINS] = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
