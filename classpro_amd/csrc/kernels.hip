@@ -710,9 +710,14 @@ __device__ unsigned long long g_phase_max[8], g_phase_sum[8], g_phase_arg[8];
 __device__ unsigned long long g_live_prof[8];
 #define PH_STAMP(k) do { if (lane == 0) { unsigned long long t_ = wall_clock64(); unsigned long long d_ = t_-ph_t; ph_t = t_; \
       atomicAdd(&g_phase_sum[k],d_); unsigned long long o_ = atomicMax(&g_phase_max[k],d_); if (d_ > o_) g_phase_arg[k] = ((unsigned long long)r << 32) | (unsigned)n_c; } } while (0)
+#elif defined(CP_STOP_AT)
+// diagnostic builds: the kernel ends after phase CP_STOP_AT (instruction counts per phase from counter passes of the
+// truncated kernels, scripts/phase_insts.sh); k_wall_tasks then reports no candidates
+#define PH_STAMP(k) do { if ((k) == CP_STOP_AT) { PH_STOP_EXTRA; return; } } while (0)
 #else
 #define PH_STAMP(k) ((void)0)
 #endif
+#define PH_STOP_EXTRA
 
 // The walk of wall.c:590-707 is two kernels.  Every load of the reference's walk is a cold miss here (the profile,
 // bases and flag arrays of a sub-batch do not stay in L2), a candidate's loads depend on each other, and its binomial-tail
@@ -786,6 +791,8 @@ __device__ __forceinline__ void fr_seq_win_load(cp_seq_lwin &sq, char *row, int 
 #ifndef FW_WAVES_PER_EU
 #define FW_WAVES_PER_EU 4
 #endif
+#undef PH_STOP_EXTRA
+#define PH_STOP_EXTRA do { if (lane == 0) { fwc[4*(int64_t)r] = 0; fwc[4*(int64_t)r+1] = 0; fwc[4*(int64_t)r+2] = 0; fwc[4*(int64_t)r+3] = 0; } } while (0)
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FW_WAVES_PER_EU)))
 k_wall_tasks(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, const int64_t *__restrict__ seq_off,
              const uint16_t *__restrict__ prof, const int64_t *__restrict__ prof_off, int nreads,
@@ -863,6 +870,7 @@ k_wall_tasks(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, 
   int ovf = 0;
   if (n_t > icap) { ovf = 1; n_t = 0; n_c = 0; }        // cannot happen: 2*n_c <= icap
   wave_sync();
+  PH_STAMP(7);
   for (int tb = 0; tb < n_t; tb += WAVE)                // 1b: lane k evaluates task k
     { const int nb = (n_t-tb < WAVE) ? n_t-tb : WAVE;
       if (lane < nb)
@@ -891,6 +899,8 @@ k_wall_tasks(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, 
   if (lane == 0) { fwc[4*(int64_t)r] = n_c; fwc[4*(int64_t)r+1] = n_t; fwc[4*(int64_t)r+2] = n_live0; fwc[4*(int64_t)r+3] = ovf; }
 }
 
+#undef PH_STOP_EXTRA
+#define PH_STOP_EXTRA
 #ifndef FW2_WAVES_PER_EU
 #define FW2_WAVES_PER_EU 6        // (LDS, 7.4 KB per wave with the on-chip interval list, allows 5.5)
 #endif
@@ -959,7 +969,136 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
         for (int k = lane; k < hc; k += WAVE) R.perror.g.keys[(size_t)e*hc+k] = -1;
   }
   wave_sync();
-  // 2, 64 tasks at a time: the chunk's task results come from HBM into LDS, then the chunk is replayed in order,
+  // 2. The replay (wall.c:639-690 with the values of step 1), 64 tasks at a time, A LANE PER TASK.  What one task reads
+  //    of another's: the "paired" flag of its own position, set by an earlier task of the same pass that took the position
+  //    as its partner, and the perror memo of its position and of its low-complexity partner's (the first request's value
+  //    stands).  So a task only has to wait for the EARLIER tasks of its pass that touch one of its three positions (its
+  //    own, the low-complexity partner, the best high-complexity partner).  Per chunk every lane enters its bit in an LDS
+  //    table of 64-bit masks indexed by a hash of (position, pass), ORs the masks of its positions -- its dependencies, a
+  //    superset when two positions share a slot -- and the chunk is done in rounds: the tasks none of whose dependencies
+  //    is still open run together.  An error's DROP and GAIN make chains of two, so a chunk takes two or three rounds
+  //    where the one-lane replay took 64 steps.  E-/O-intervals are appended after the rounds, in task order (ballots).
+  //    The memo tables take concurrent inserts of DIFFERENT keys (compare-and-swap on the key slot); tasks of one round
+  //    never share a position.  A read whose memo does not fit on chip takes the one-lane replay below.
+  if (R.perror.use_lds == 3)
+    { unsigned long long *s_dep = reinterpret_cast<unsigned long long *>(s_res);    // 256 slots (the task results stay in registers here)
+      static_assert(sizeof(task_res)*WAVE >= 256*sizeof(unsigned long long),"dependency masks fit the staging block");
+      const uint64_t ltm = (1ull << lane)-1;
+      const int ecap = R.ecap;
+      const bool ebig = R.eintvl.big != 0;
+      int eidx = 0, oidx = 0, ovf = 0;
+      auto memo_cell = [&](int pos, int e, int w) -> int      // slot of (pos,e,w) in the on-chip memo, claimed empty (-inf) if new
+        { const int key = pos*2+w, off = e ? LCAP0 : 0;
+          const uint32_t m = (uint32_t)(e ? LCAP1 : LCAP0)-1;
+          uint32_t h = ((uint32_t)key*0x9E3779B1u >> 9) & m;
+          while (true)
+            { const int32_t k = s_mkey[off+h];
+              if (k == key) break;
+              if (k < 0)
+                { const int32_t o = atomicCAS(&s_mkey[off+h],-1,key);
+                  if (o == -1) { s_mval[off+h] = -INFINITY; break; }
+                  if (o == key) break;
+                }
+              h = (h+1) & m;
+            }
+          return off+(int)h;
+        };
+      for (int tb = 0; tb < n_t; tb += WAVE)
+        { const int nb = (n_t-tb < WAVE) ? n_t-tb : WAVE;
+          bool open = lane < nb;
+          int pos = 1, e = 0, w = 0, lc_j = -1, lc_kind = CP_LC_NONE, hc_j = -1;
+          double own_pe = 0., lc_v = 0., hc_pe = 0.;
+          if (open)
+            { const int code = tlist[tb+lane], k = code >> 1, cc = ccnt[k];
+              const task_res q = tres[tb+lane];
+              pos = clist[k]; e = code & 1;
+              w = (cc & 0xffff) > ((cc >> 16) & 0xffff) ? CP_DROP : CP_GAIN;
+              own_pe = q.own_pe; lc_v = q.lc_v; hc_pe = q.hc_pe;
+              lc_j = q.lc_j; lc_kind = q.hc & 3;
+              hc_j = (q.hc & 4) ? pos+(q.hc >> 16) : -1;
+            }
+          const int p1 = (lc_kind == CP_LC_PAIR || lc_kind == CP_LC_BOUNDARY) ? lc_j : -1, p2 = hc_j;
+          for (int q = lane; q < 256; q += WAVE) s_dep[q] = 0ull;
+          wave_sync();
+          const int s0 = (int)((uint32_t)(pos*2+e)*0x9E3779B1u >> 24), s1 = (int)((uint32_t)(p1*2+e)*0x9E3779B1u >> 24),
+                    s2 = (int)((uint32_t)(p2*2+e)*0x9E3779B1u >> 24);
+          if (open)
+            { atomicOr(&s_dep[s0],1ull << lane);
+              if (p1 >= 0) atomicOr(&s_dep[s1],1ull << lane);
+              if (p2 >= 0) atomicOr(&s_dep[s2],1ull << lane);
+            }
+          wave_sync();
+          uint64_t dep = 0;
+          if (open)
+            { dep = s_dep[s0];
+              if (p1 >= 0) dep |= s_dep[s1];
+              if (p2 >= 0) dep |= s_dep[s2];
+              dep &= ltm;
+            }
+          bool hasE = false, hasO = false;
+          cp_eintvl I; I.b = I.e = 0; I.pe = 0.;
+          for (uint64_t um = __ballot(open); um; um = __ballot(open))
+            { if (open && (dep & um) == 0)
+                { open = false;
+                  const uint8_t fl = (e == CP_SELF) ? R.wall_s[pos] : wall[pos];
+                  if (!(fl & (e == CP_SELF ? CP_W_PAIRED_S : CP_W_PAIRED_O)))          // wall.c:639
+                    { const int ci = memo_cell(pos,e,w);
+                      double pe_i = s_mval[ci];
+                      if (pe_i == CP_NEG_INF) { pe_i = own_pe; s_mval[ci] = pe_i; }     // update_perror(i), wall.c:310-315
+                      bool accept = false;
+                      if (pe_i >= CP_PE_THRES_FINAL && lc_kind != CP_LC_NONE)           // find_gain / find_drop, see cp_find_pair_replay
+                        { const bool right = (w == CP_DROP);
+                          int max_j = -1;
+                          double pe = CP_NEG_INF, max_pe = CP_NEG_INF;
+                          if (lc_kind == CP_LC_BOUNDARY) pe = pe_i*pe_i;
+                          else if (lc_kind == CP_LC_PAIR)
+                            { const int cj = memo_cell(lc_j,e,1-w);
+                              double pe_j = s_mval[cj];
+                              if (pe_j == CP_NEG_INF) { pe_j = lc_v; s_mval[cj] = pe_j; }
+                              pe = right ? pe_i*pe_j : pe_j*pe_i;
+                            }
+                          if (max_pe < pe) { max_j = lc_j; max_pe = pe; }
+                          if (hc_j >= 0 && max_pe < hc_pe) { max_j = hc_j; max_pe = hc_pe; }
+                          if (max_j != -1 && max_pe >= CP_PE_THRES_FINAL)
+                            { accept = true;
+                              I.b = right ? pos : max_j; I.e = right ? max_j : pos; I.pe = max_pe;
+                              if (e == CP_SELF)                                          // wall.c:655-668 (the SELF array only ever holds these two bits)
+                                { R.wall_s[I.b] = (CP_W_WALL_S|CP_W_PAIRED_S);
+                                  R.wall_s[I.e] = (CP_W_WALL_S|CP_W_PAIRED_S);
+                                  hasE = true;
+                                }
+                              else                                                       // wall.c:678-686
+                                { wall[pos] = fl | CP_W_PAIRED_O;
+                                  if (max_j > pos) wall[max_j] = CP_W_PAIRED_O;          // not reached yet: the reference has 0 there (cp_read_t::spec_wallnow)
+                                  else             wall[max_j] |= CP_W_PAIRED_O;
+                                  hasO = true;
+                                }
+                            }
+                        }
+                      if (!accept && e == CP_OTHERS) wall[pos] = fl | CP_W_WALL_O;       // wall.c:673-676,688
+                    }
+                }
+              wave_sync();                                     // the round's flags and memo entries are visible to the next
+            }
+          const uint64_t mE = __ballot(hasE), mO = __ballot(hasO);
+          if (hasE)
+            { const int sl = eidx+__popcll(mE & ltm);
+              if (sl < ecap) { if (ebig) R.eintvl.g[sl] = I; else R.eintvl.l[sl] = I; }
+            }
+          if (hasO)
+            { const int sl = oidx+__popcll(mO & ltm);
+              if (sl < ecap) R.ointvl.g[sl] = I;
+            }
+          eidx += __popcll(mE); oidx += __popcll(mO);
+          if (eidx > ecap) { eidx = ecap; ovf = 1; }
+          if (oidx > ecap) { oidx = ecap; ovf = 1; }
+        }
+      wave_sync();
+      if (lane < 2) { R.eidx = lane == 0 ? eidx : 0; R.oidx = lane == 1 ? oidx : 0; R.overflow |= ovf; }
+    }
+  else
+  {
+  // one-lane replay, 64 tasks at a time: the chunk's task results come from HBM into LDS, then the chunk is replayed in order,
   //    lane 0 taking the SELF tasks and lane 1 the OTHERS tasks (one lane active per task; position and count pair
   //    come from the loading lane's registers by readlane).
   if (lane < 2)
@@ -990,8 +1129,8 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
             }
         }
       wave_sync();
-      PH_STAMP(1);
     }
+  }
   R.use_win = 0; R.spec_wallnow = 0;
   PH_STAMP(1);
   int NS = __shfl(R.eidx,0), NO = __shfl(R.oidx,1);
