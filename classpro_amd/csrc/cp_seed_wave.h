@@ -53,7 +53,7 @@
 #endif
 
 struct cp_seedw_lds
-  { int32_t  rb[SW_RING], rpb[SW_RING];          // begin / predecessor's begin of the valid segments around the tile being worked on
+  { int2     rbp[SW_RING];                       // (begin, predecessor's begin) of the valid segments around the tile being worked on
     int16_t  rkey[SW_RING];                      // ... and their keys
     int32_t  mi_b[SW_MI], mi_e[SW_MI];           // masked-interval list while it fits
     int32_t  cval[SW_STEP*WAVE];                 // per position: the count if the k-mer is valid, else -1; base classes for the hash
@@ -84,6 +84,11 @@ struct cp_seedw_read
 #define SW_STAMP(k) ((void)0)
 #define SW_PROF_ARGS
 #define SW_PROF_PASS
+#endif
+#ifdef CP_SEED_STOP_AT                            // diagnostic builds: every selection ends after phase CP_SEED_STOP_AT (instruction counts per phase)
+#define SW_STOP(k) do { if ((k) == CP_SEED_STOP_AT) return; } while (0)
+#else
+#define SW_STOP(k) ((void)0)
 #endif
 
 __device__ __forceinline__ int sw_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -274,8 +279,10 @@ constexpr sw_code_tab sw_make_codes()
 __device__ const sw_code_tab sw_CODE = sw_make_codes();
 
 // the k-mer's bases come in with four 16-byte loads issued together (a byte load per step made the 40 steps 40 memory
-// round trips); `rlen` bounds them: a k-mer within 64 bases of the read's end is read byte by byte
-__device__ __forceinline__ int sw_hash_at(const char *seq, int j, int K, int rlen)
+// round trips); `rlen` bounds them: a k-mer within 64 bases of the read's end is read byte by byte.  `rot` / `code`: the
+// two tables (sw_ROT, sw_CODE) -- sw_mark_all passes its on-chip copies.
+template <class ROT, class CODE>
+__device__ __forceinline__ int sw_hash_at(const char *seq, int j, int K, int rlen, const ROT rot, const CODE code_of)
 { if (K > SW_KMAX) return cp_kmer_hash(seq,j,K);
   uint64_t fh = 0, rh = 0;
   if (j+SW_KMAX <= rlen)
@@ -288,24 +295,41 @@ __device__ __forceinline__ int sw_hash_at(const char *seq, int j, int K, int rle
 #pragma unroll
       for (int t = 0; t < SW_KMAX; t++)
         if (t < K)
-          { const int code = sw_CODE.v[(w[t >> 2] >> (8*(t & 3))) & 0xff];
-            fh ^= sw_ROT.v[(code & 7)*SW_KMAX+(K-1-t)];
-            rh ^= sw_ROT.v[(code >> 3)*SW_KMAX+t];
+          { const int code = code_of[(w[t >> 2] >> (8*(t & 3))) & 0xff];
+            fh ^= rot[(code & 7)*SW_KMAX+(K-1-t)];
+            rh ^= rot[(code >> 3)*SW_KMAX+t];
           }
     }
   else
     for (int t = 0; t < K; t++)
-      { const int code = sw_CODE.v[(unsigned char)seq[j+t]];
-        fh ^= sw_ROT.v[(code & 7)*SW_KMAX+(K-1-t)];
-        rh ^= sw_ROT.v[(code >> 3)*SW_KMAX+t];
+      { const int code = code_of[(unsigned char)seq[j+t]];
+        fh ^= rot[(code & 7)*SW_KMAX+(K-1-t)];
+        rh ^= rot[(code >> 3)*SW_KMAX+t];
       }
   return (int)((rh < fh ? rh : fh) % CP_SEED_MOD);
 }
 
+// The hash loop reads a letter's class and two rotated seeds per base, each lane at its own address: as global loads
+// (the tables sit in the caches) these 120 scattered loads per k-mer kept the address unit busy for a third of the
+// kernel's time (0.37 G load instructions per launch of 48 000 reads).  For the duration of sw_mark_all the two tables
+// live in LDS, in blocks that are idle then: the window-count ring (2560 bytes = the rotated seeds) and the take buffer
+// (the 256 letter classes).  A k-mer is hashed ONCE: the hashes of up to four sweeps (256 k-mers, all but a few rounds)
+// wait in registers for the mark sweep.
 __device__ __attribute__((noinline)) void sw_mark_all(const char *seq, const char *cls, char *state, int K, int rlen, const int32_t *takes,
                                                       int ntake, bool rep, int lane)
-{ int32_t *s_pre = sw_S.pend_b, *s_min = sw_S.pend_e;        // (the pending-take buffers are idle here; SW_PEND >= 64)
+{ if (ntake == 0) return;
+  int32_t *s_pre = sw_S.pend_b, *s_min = sw_S.pend_e;        // (the pending-take buffers are idle here; SW_PEND >= 64)
   static_assert(SW_PEND >= WAVE,"one slot per segment of a round");
+  static_assert(sizeof(sw_S.rbp)+sizeof(sw_S.rkey) >= sizeof(sw_rot_tab) && offsetof(cp_seedw_lds,rkey) == sizeof(sw_S.rbp),
+                "the rotated seeds fit the ring");
+  static_assert(sizeof(sw_S.cval) >= sizeof(sw_code_tab),"the letter classes fit the take buffer");
+  uint64_t *lrot = reinterpret_cast<uint64_t *>(&sw_S.rbp[0]);
+  uint8_t *lcode = reinterpret_cast<uint8_t *>(&sw_S.cval[0]);
+  __syncthreads();
+  for (int q = lane; q < 5*SW_KMAX; q += WAVE) lrot[q] = sw_ROT.v[q];
+  for (int q = lane; q < 256/4; q += WAVE) reinterpret_cast<uint32_t *>(lcode)[q] = reinterpret_cast<const uint32_t *>(sw_CODE.v)[q];
+  __syncthreads();
+  constexpr int KEEP = 4;
   for (int base = 0; base < ntake; base += WAVE)
     { const int ns = ntake-base < WAVE ? ntake-base : WAVE;
       int b = 0, len = 0;
@@ -317,22 +341,45 @@ __device__ __attribute__((noinline)) void sw_mark_all(const char *seq, const cha
       s_pre[lane] = incl-len;                                // first k-mer slot of segment `lane`
       s_min[lane] = CP_SEED_MOD;
       __syncthreads();
-      // two sweeps: the segments' minima, then the marks
+      auto locate = [&](int q, int &lo, int &j)              // k-mer slot q -> its segment (of this round) and its position
+        { lo = 0;
+#pragma unroll
+          for (int step = WAVE/2; step > 0; step >>= 1)
+            if (lo+step < ns && s_pre[lo+step] <= q) lo += step;
+          j = __shfl(b,lo)+(q-s_pre[lo]);
+        };
+      if (total <= KEEP*WAVE)                                // the usual round: hash once, keep, mark
+        { int hk[KEEP], jk[KEEP], lk[KEEP];
+#pragma unroll
+          for (int u = 0; u < KEEP; u++)
+            { const int q = u*WAVE+lane;
+              hk[u] = -1; jk[u] = 0; lk[u] = 0;
+              if (u*WAVE < total)
+                { const bool on = q < total;
+                  int lo = 0, j = 0;
+                  locate(on ? q : 0,lo,j);
+                  if (on)
+                    { hk[u] = sw_hash_at(seq,j,K,rlen,lrot,lcode); jk[u] = j; lk[u] = lo;
+                      atomicMin(&s_min[lo],hk[u]);
+                    }
+                }
+            }
+          __syncthreads();
+#pragma unroll
+          for (int u = 0; u < KEEP; u++)
+            if (hk[u] >= 0 && hk[u] == s_min[lk[u]]) state[jk[u]] = rep ? 'R' : cls[jk[u]];
+          __syncthreads();
+          continue;
+        }
+      // a round with more k-mers: two sweeps, the segments' minima, then the marks
       for (int pass = 0; pass < 2; pass++)
         { for (int q0 = 0; q0 < total; q0 += WAVE)
             { const int q = q0+lane;
               const bool on = q < total;
-              int lo = 0;
+              int lo = 0, j = 0;
+              locate(on ? q : 0,lo,j);
               if (on)
-                {
-#pragma unroll
-                  for (int step = WAVE/2; step > 0; step >>= 1)
-                    if (lo+step < ns && s_pre[lo+step] <= q) lo += step;
-                }
-              const int sb = __shfl(b,lo), so = on ? q-s_pre[lo] : 0;
-              if (on)
-                { const int j = sb+so;
-                  const int h = sw_hash_at(seq,j,K,rlen);
+                { const int h = sw_hash_at(seq,j,K,rlen,lrot,lcode);
                   if (pass == 0) atomicMin(&s_min[lo],h);
                   else if (h == s_min[lo]) state[j] = rep ? 'R' : cls[j];
                 }
@@ -492,6 +539,7 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
     __syncthreads();
   }
   SW_STAMP(1);
+  SW_STOP(1);
   // ---- window counts, 64 valid segments at a time ----
   // key = count (H/D) or 32767 - count (repeats): both selections look for the larger key.  pb(j): the begin of j's
   // predecessor of either kind (record field z until the window count replaces it); j is still within reach of i
@@ -501,10 +549,14 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
     int ring_hi = 0;                                         // segments [ring_hi-SW_RING, ring_hi) are in the ring
     auto seg = [&](int j) -> sg                              // (a segment whose window count is written already: pb is gone, nobody asks)
       { sg r;
-        if (j < ring_hi && j >= ring_hi-SW_RING) { r.b = sw_S.rb[j & (SW_RING-1)]; r.pb = sw_S.rpb[j & (SW_RING-1)]; r.key = sw_S.rkey[j & (SW_RING-1)]; }
+        if (j < ring_hi && j >= ring_hi-SW_RING) { const int2 t = sw_S.rbp[j & (SW_RING-1)]; r.b = t.x; r.pb = t.y; r.key = sw_S.rkey[j & (SW_RING-1)]; }
         else { const int4 t = R.rec[j]; r.b = t.x; r.pb = t.z; r.key = t.w-1; }
         return r;
       };
+    // a segment within SW_IND of the tile: always in the ring (it covers [t0-SW_BACK, t0+SW_RING-SW_BACK) of [0,n)), no test
+    static_assert(SW_IND <= SW_BACK && WAVE+SW_IND <= SW_RING-SW_BACK,"the lanes' own searches stay inside the ring");
+    auto segr = [&](int j) -> sg
+      { sg r; const int2 t = sw_S.rbp[j & (SW_RING-1)]; r.b = t.x; r.pb = t.y; r.key = sw_S.rkey[j & (SW_RING-1)]; return r; };
     bool c_have = false, c_wipe = false; int c_expb = 0, c_wpb = 0, c_pos = 0;   // carried: begin of the last expiring segment, pb of the last wipe, last_oor_pos
     for (int t0 = 0; t0 < n; t0 += WAVE)
       { { int upto = t0+SW_RING-SW_BACK;                     // the ring covers [t0-SW_BACK, t0+SW_RING-SW_BACK)
@@ -515,7 +567,7 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
                 { const int j = ring_hi+lane;
                   if (j < upto)
                     { const int4 t = R.rec[j];
-                      sw_S.rb[j & (SW_RING-1)] = t.x; sw_S.rpb[j & (SW_RING-1)] = t.z; sw_S.rkey[j & (SW_RING-1)] = (int16_t)(t.w-1);
+                      sw_S.rbp[j & (SW_RING-1)] = make_int2(t.x,t.z); sw_S.rkey[j & (SW_RING-1)] = (int16_t)(t.w-1);
                     }
                   ring_hi = ring_hi+WAVE < upto ? ring_hi+WAVE : upto;
                 }
@@ -525,11 +577,11 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
         const int i = t0+lane;
         const bool act = i < n;
         sg me; me.b = 0; me.pb = NONE; me.key = -1;
-        if (act) me = seg(i);
+        if (act) me = segr(i);
         const int bi = me.b, ki = me.key, pbi = me.pb;
         int ei = 0;                                          // my end = the begin of my successor of either kind
         if (act)
-          { if (i+1 < n) { const sg nx = seg(i+1); ei = nx.pb == bi ? nx.b : nx.pb; }
+          { if (i+1 < n) { const sg nx = segr(i+1); ei = nx.pb == bi ? nx.b : nx.pb; }
             else ei = R.rec[i].y;
           }
         // -- forward: the first segment within reach that beats me; else what the reach holds --
@@ -542,7 +594,7 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
               for (int q = 0; q < SW_BATCH; q++)
                 { const int j = i+s0+q;
                   sj[q].b = 0; sj[q].pb = 0; sj[q].key = -1;
-                  if (!fdone && j < n) sj[q] = seg(j);
+                  if (!fdone && j < n) sj[q] = segr(j);
                 }
 #pragma unroll
               for (int q = 0; q < SW_BATCH; q++)
@@ -592,7 +644,7 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
               for (int q = 0; q < SW_BATCH; q++)
                 { const int j = i-s0-q;
                   sj[q].b = 0; sj[q].pb = 0; sj[q].key = -1;
-                  if (!bdone && j >= 0) sj[q] = seg(j);
+                  if (!bdone && j >= 0) sj[q] = segr(j);
                 }
 #pragma unroll
               for (int q = 0; q < SW_BATCH; q++)
@@ -678,6 +730,7 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
     }
 #endif
   SW_STAMP(5);
+  SW_STOP(2);
 #ifdef CP_SEED_PROF
   if (lane == 0) { sw_t[7] += n; }
 #endif
@@ -736,6 +789,7 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
       __syncthreads();
     }
   SW_STAMP(2);
+  SW_STOP(3);
   // ---- selection (wave-uniform control flow) ----
   // taken segments are listed in R.tmp (idle after the sort) and marked at the end; the list is written 64 takes at a
   // time from an LDS buffer (cval), so that the list update of a take -- a chain of wave barriers -- never waits for a
@@ -767,6 +821,7 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
       take(t.x,t.y);
     }
   SW_STAMP(3);
+  SW_STOP(4);
   // Then groups of equal window count, while uncovered.  The members of a group are tested against the list as it was
   // before the group, and the list changes only when a group with members outside it ends: so 64 records are tested
   // at once (a lane each) against the current list; everything up to the first record found outside is settled, that
@@ -819,6 +874,7 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
       flush(pos);
     }
   SW_STAMP(4);
+  SW_STOP(5);
   flush_takes();                                             // the list of taken segments is complete and visible to the wave
 #ifdef CP_SEED_DEBUG_TAKES
   if (R.dbg_read && rep)
@@ -891,6 +947,9 @@ __device__ __forceinline__ int sw_find_seeds(const cp_seedw_read &R, int lane SW
     }
   __syncthreads();
   SW_STAMP(0);
+#ifdef CP_SEED_STOP_AT
+  if (CP_SEED_STOP_AT == 0) return 0;
+#endif
   nrep = sw_first(nrep);
   const bool rep_big = nrep > SW_REP;                        // then the HBM list is searched (complete: rep_cap bounds the label runs)
   const int nr = nrep > R.rep_cap ? R.rep_cap : nrep;
