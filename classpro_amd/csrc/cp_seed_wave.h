@@ -35,7 +35,7 @@
 
 #ifndef SW_RING
 #define SW_RING  256                             // segments of the window-count pass kept on chip (10 bytes each; beyond: read from HBM)
-#define SW_BACK  64                              // ... of which this many lie behind the tile being worked on
+#define SW_BACK  96                              // ... of which this many lie behind the tile being worked on (a multiple of 32)
                                                  // (512 / 192: 59.4 ms on the 60x set against 57.6 -- the LDS is worth more as a sixth wave per SIMD)
 #endif
 #ifndef SW_BATCH
@@ -54,7 +54,7 @@
 
 struct cp_seedw_lds
   { int2     rbp[SW_RING];                       // (begin, predecessor's begin) of the valid segments around the tile being worked on
-    int16_t  rkey[SW_RING];                      // ... and their keys
+    int16_t  rkey[SW_RING+SW_RING/4+SW_RING/16]; // ... their keys; behind them the largest key of every aligned block of 4 and of 16 segments
     int32_t  mi_b[SW_MI], mi_e[SW_MI];           // masked-interval list while it fits
     int32_t  cval[SW_STEP*WAVE];                 // per position: the count if the k-mer is valid, else -1; base classes for the hash
     int32_t  bins[32];
@@ -554,7 +554,7 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
         return r;
       };
     // a segment within SW_IND of the tile: always in the ring (it covers [t0-SW_BACK, t0+SW_RING-SW_BACK) of [0,n)), no test
-    static_assert(SW_IND <= SW_BACK && WAVE+SW_IND <= SW_RING-SW_BACK,"the lanes' own searches stay inside the ring");
+    static_assert(SW_BACK % 32 == 0 && WAVE+1 <= SW_RING-SW_BACK,"ring fills are aligned to the blocks; a tile and its successor are in the ring");
     auto segr = [&](int j) -> sg
       { sg r; const int2 t = sw_S.rbp[j & (SW_RING-1)]; r.b = t.x; r.pb = t.y; r.key = sw_S.rkey[j & (SW_RING-1)]; return r; };
     bool c_have = false, c_wipe = false; int c_expb = 0, c_wpb = 0, c_pos = 0;   // carried: begin of the last expiring segment, pb of the last wipe, last_oor_pos
@@ -565,10 +565,18 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
             { __syncthreads();                               // (the slots being replaced are no longer read)
               while (ring_hi < upto)
                 { const int j = ring_hi+lane;
+                  int km = -1;
                   if (j < upto)
                     { const int4 t = R.rec[j];
                       sw_S.rbp[j & (SW_RING-1)] = make_int2(t.x,t.z); sw_S.rkey[j & (SW_RING-1)] = (int16_t)(t.w-1);
+                      km = t.w-1;
                     }
+                  // (ring_hi is a multiple of 32: groups of 4 / 16 lanes are aligned blocks; a block no segment of which is
+                  //  loaded yet shares its slot with the oldest ones of the ring and is left alone)
+                  km = max(km,__shfl_xor(km,1)); km = max(km,__shfl_xor(km,2));
+                  if ((lane & 3) == 0 && j < upto) sw_S.rkey[SW_RING+((j >> 2) & (SW_RING/4-1))] = (int16_t)km;
+                  km = max(km,__shfl_xor(km,4)); km = max(km,__shfl_xor(km,8));
+                  if ((lane & 15) == 0 && j < upto) sw_S.rkey[SW_RING+SW_RING/4+((j >> 4) & (SW_RING/16-1))] = (int16_t)km;
                   ring_hi = ring_hi+WAVE < upto ? ring_hi+WAVE : upto;
                 }
               __syncthreads();
@@ -585,101 +593,134 @@ __device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, i
             else ei = R.rec[i].y;
           }
         // -- forward: the first segment within reach that beats me; else what the reach holds --
+        // Both searches walk the ring by aligned blocks of 16, 4 and 1 segments whose largest key is kept beside the keys
+        // (blocks that hold nothing better are stepped over whole, a block that does is entered at the next smaller size):
+        // a dozen steps where a segment-by-segment walk over the ~70 segments of a window took 70, and the wave waits for
+        // its slowest lane.  The reach (begins grow with the index) is found first, by bisection.
+        // The loops are uniform (they run while any lane has work) and their bodies are straight-line selects: as per-lane
+        // `while` loops with early exits each step cost ~90 instructions, most of them exec-mask bookkeeping.
+        const int hiR = ring_hi-1, loR = ring_hi-SW_RING > 0 ? ring_hi-SW_RING : 0;      // the ring holds segments [loR, hiR]
+        auto blk_idx = [](int pos, int s) -> int             // slot of the block of 1 << s segments that holds segment pos
+          { return ((pos >> s) & ((SW_RING-1) >> s))+(s == 4 ? SW_RING+SW_RING/4 : s == 2 ? SW_RING : 0); };
         int g = -1, bg = 0, pbg = 0;
-        bool eq = false, nonempty = false, fdone = !act;
-        { // 32 segments ahead, eight at a time: the eight reads are issued together, then evaluated in order
-          for (int s0 = 1; s0 <= SW_IND; s0 += SW_BATCH)
-            { sg sj[SW_BATCH];
+        bool eq = false, nonempty = false, fopen = false;
+#ifndef SW_SKIP_FWD
+        { const int limv = bi+W;
+          int x = i;                                         // x(i) within the ring: the last segment with pb < b(i)+W
 #pragma unroll
-              for (int q = 0; q < SW_BATCH; q++)
-                { const int j = i+s0+q;
-                  sj[q].b = 0; sj[q].pb = 0; sj[q].key = -1;
-                  if (!fdone && j < n) sj[q] = segr(j);
-                }
-#pragma unroll
-              for (int q = 0; q < SW_BATCH; q++)
-                { const int j = i+s0+q;
-                  const bool more = !fdone && j < n;
-                  const bool reach = more && sj[q].pb < bi+W;
-                  const bool beat = reach && sj[q].key > ki;
-                  if (beat) { g = j; bg = sj[q].b; pbg = sj[q].pb; }
-                  if (reach && !beat) { nonempty = true; eq = eq || sj[q].key == ki; }
-                  fdone = fdone || !reach || beat;
-                }
-              if (__ballot(!fdone) == 0) break;
+          for (int st = SW_RING/2; st > 0; st >>= 1)
+            { const int c = x+st;
+              const int pbc = sw_S.rbp[c & (SW_RING-1)].y;
+              x = (act && c <= hiR && pbc < limv) ? c : x;
             }
-          // searches still open, one at a time, 64 segments per step
-          for (uint64_t um = __ballot(!fdone); um; um &= um-1)
-            { const int src = __ffsll((long long)um)-1;
-              const int si = __shfl(i,src), sb = __shfl(bi,src), sk = __shfl(ki,src);
-              bool seq = __shfl(eq ? 1 : 0,src) != 0, sne = __shfl(nonempty ? 1 : 0,src) != 0;
-              int rg = -1, rbg = 0, rpbg = 0;
-              for (int j0 = si+SW_IND+1; ; j0 += WAVE)
-                { const int jj = j0+lane;
-                  sg sj; sj.b = 0; sj.pb = 0; sj.key = -1;
-                  if (jj < n) sj = seg(jj);
-                  const bool reach = jj < n && sj.pb < sb+W;   // (monotone: begins grow)
-                  const uint64_t mR = __ballot(reach), mB = __ballot(reach && sj.key > sk), mE = __ballot(reach && sj.key == sk);
-                  if (mB)
-                    { const int fb = __ffsll((long long)mB)-1;
-                      const uint64_t blt = (1ull << fb)-1;
-                      rg = j0+fb; rbg = __shfl(sj.b,fb); rpbg = __shfl(sj.pb,fb);
-                      sne = sne || (mR & blt) != 0; seq = seq || (mE & blt) != 0;
-                      break;
-                    }
-                  sne = sne || mR != 0; seq = seq || mE != 0;
-                  if (mR != ~0ull) break;                    // the reach ended inside these 64
-                }
-              if (lane == src) { g = rg; bg = rbg; pbg = rpbg; eq = seq; nonempty = sne; fdone = true; }
+          nonempty = x > i;
+          int pos = act ? i+1 : x+1, maxlen = 16, eqi = 0;
+          while (__ballot(pos <= x) != 0)
+            { const int room = x-pos+1;                      // <= 0: this lane is done
+              const int q = min(min(pos & -pos,room),maxlen);
+              const int sh = q >= 16 ? 4 : q >= 4 ? 2 : 0;
+              const int m = sw_S.rkey[blk_idx(pos,sh)];
+              const bool on = room > 0, hit = on && m > ki, fnd = hit && sh == 0;
+              eqi |= (on && m == ki) ? 1 : 0;
+              g = fnd ? pos : g;
+              maxlen = (hit && sh != 0) ? (1 << (sh-2)) : maxlen;
+              pos = fnd ? 0x3fffffff : (on && !hit) ? pos+(1 << sh) : pos;
             }
+          eq = eqi != 0;
+          const int2 tg = sw_S.rbp[g & (SW_RING-1)];
+          if (g >= 0) { bg = tg.x; pbg = tg.y; }
+          fopen = act && g < 0 && x == hiR && hiR+1 < n;     // the reach may go on beyond the ring
         }
+#endif
+        // searches that leave the ring, one at a time, 64 segments per step
+#ifdef SW_SKIP_COOP
+        fopen = false;
+#endif
+        for (uint64_t um = __ballot(fopen); um; um &= um-1)
+          { const int src = __ffsll((long long)um)-1;
+            const int sb = __shfl(bi,src), sk = __shfl(ki,src);
+            bool seq = __shfl(eq ? 1 : 0,src) != 0, sne = __shfl(nonempty ? 1 : 0,src) != 0;
+            int rg = -1, rbg = 0, rpbg = 0;
+            for (int j0 = ring_hi; ; j0 += WAVE)
+              { const int jj = j0+lane;
+                sg sj; sj.b = 0; sj.pb = 0; sj.key = -1;
+                if (jj < n) sj = seg(jj);
+                const bool reach = jj < n && sj.pb < sb+W;     // (monotone: begins grow)
+                const uint64_t mR = __ballot(reach), mB = __ballot(reach && sj.key > sk), mE = __ballot(reach && sj.key == sk);
+                if (mB)
+                  { const int fb = __ffsll((long long)mB)-1;
+                    const uint64_t blt = (1ull << fb)-1;
+                    rg = j0+fb; rbg = __shfl(sj.b,fb); rpbg = __shfl(sj.pb,fb);
+                    sne = sne || (mR & blt) != 0; seq = seq || (mE & blt) != 0;
+                    break;
+                  }
+                sne = sne || mR != 0; seq = seq || mE != 0;
+                if (mR != ~0ull) break;                        // the reach ended inside these 64
+              }
+            if (lane == src) { g = rg; bg = rbg; pbg = rpbg; eq = seq; nonempty = sne; }
+          }
         // -- backward: what the deque holds when I arrive (segments beginning beyond pb(me)-W): does any of them match
-        //    or beat me (then I wipe nothing), and where does the nearest one that beats me begin --
-        bool blocked = false, bnon = false, havep = false, bdone = !act || pbi == NONE;
+        //    or beat me (then I wipe nothing), and where does the nearest one that beats me begin (a beaten segment
+        //    needs that; an expiring one only needs to know that it wipes nothing) --
+        bool blocked = false, bnon = false, havep = false, bopen = false;
         int pbeg = 0;
         const int limw = pbi-W;
-        { for (int s0 = 1; s0 <= SW_IND; s0 += SW_BATCH)
-            { sg sj[SW_BATCH];
+#ifndef SW_SKIP_BWD
+        { const bool actb = act && pbi != NONE;
+          int y = i;                                         // y(i) within the ring: the first segment with b > pb(me)-W (i: none)
 #pragma unroll
-              for (int q = 0; q < SW_BATCH; q++)
-                { const int j = i-s0-q;
-                  sj[q].b = 0; sj[q].pb = 0; sj[q].key = -1;
-                  if (!bdone && j >= 0) sj[q] = segr(j);
-                }
-#pragma unroll
-              for (int q = 0; q < SW_BATCH; q++)
-                { const int j = i-s0-q;
-                  const bool more = !bdone && j >= 0;
-                  const bool inw = more && sj[q].b > limw;
-                  const bool better = inw && sj[q].key > ki;
-                  if (inw) { bnon = true; blocked = blocked || sj[q].key >= ki; }
-                  if (better) { havep = true; pbeg = sj[q].b; }
-                  bdone = bdone || !inw || better || (blocked && g < 0);   // an expiring segment only needs to know that it wipes nothing
-                }
-              if (__ballot(!bdone) == 0) break;
+          for (int st = SW_RING/2; st > 0; st >>= 1)
+            { const int c = y-st;
+              const int bc = sw_S.rbp[c & (SW_RING-1)].x;
+              y = (actb && c >= loR && bc > limw) ? c : y;
             }
-          for (uint64_t um = __ballot(!bdone); um; um &= um-1)
-            { const int src = __ffsll((long long)um)-1;
-              const int si = __shfl(i,src), sk = __shfl(ki,src), slim = __shfl(limw,src), sgi = __shfl(g,src);
-              bool sbl = __shfl(blocked ? 1 : 0,src) != 0, sbn = __shfl(bnon ? 1 : 0,src) != 0, shp = false;
-              int spb = 0;
-              for (int j0 = si-SW_IND-1; ; j0 -= WAVE)
-                { const int jj = j0-lane;
-                  sg sj; sj.b = 0; sj.pb = 0; sj.key = -1;
-                  if (jj >= 0) sj = seg(jj);
-                  const bool inw = jj >= 0 && sj.b > slim;   // (monotone)
-                  const uint64_t mI = __ballot(inw), mS = __ballot(inw && sj.key > sk), mN = __ballot(inw && sj.key >= sk);
-                  if (mS)
-                    { const int fs = __ffsll((long long)mS)-1;
-                      shp = true; spb = __shfl(sj.b,fs); sbl = true; sbn = true;
-                      break;
-                    }
-                  sbn = sbn || mI != 0; sbl = sbl || mN != 0;
-                  if (mI != ~0ull || (sbl && sgi < 0)) break;
-                }
-              if (lane == src) { blocked = sbl; bnon = sbn; havep = shp; pbeg = spb; bdone = true; }
+          bnon = y < i;
+          const bool need = g >= 0;
+          int pos = actb ? i-1 : y-1, maxlen = 16, blk = 0, fin = 0, gp = -1;
+          while (__ballot(pos >= y) != 0)
+            { const int room = pos-y+1;                      // <= 0: this lane is done
+              const int q = min(min((pos+1) & -(pos+1),room),maxlen);       // (blocks that END at pos)
+              const int sh = q >= 16 ? 4 : q >= 4 ? 2 : 0;
+              const int m = sw_S.rkey[blk_idx(pos,sh)];
+              const bool on = room > 0, ge = on && m >= ki, gt = on && m > ki;
+              const bool stop = ge && !need, fnd = gt && need && sh == 0;
+              blk |= ge ? 1 : 0;
+              gp = fnd ? pos : gp;
+              fin |= (stop || fnd) ? 1 : 0;
+              maxlen = (gt && need && sh != 0) ? (1 << (sh-2)) : maxlen;
+              pos = (stop || fnd) ? -0x3fffffff : (on && !gt) ? pos-(1 << sh) : pos;
             }
+          blocked = blk != 0;
+          havep = gp >= 0;
+          const int bgp = sw_S.rbp[gp & (SW_RING-1)].x;
+          if (havep) pbeg = bgp;
+          bopen = actb && !fin && y == loR && loR > 0;       // the window may go on below the ring
         }
+#endif
+#ifdef SW_SKIP_COOP
+        bopen = false;
+#endif
+        for (uint64_t um = __ballot(bopen); um; um &= um-1)
+          { const int src = __ffsll((long long)um)-1;
+            const int sk = __shfl(ki,src), slim = __shfl(limw,src), sgi = __shfl(g,src);
+            bool sbl = __shfl(blocked ? 1 : 0,src) != 0, sbn = __shfl(bnon ? 1 : 0,src) != 0, shp = false;
+            int spb = 0;
+            for (int j0 = loR-1; ; j0 -= WAVE)
+              { const int jj = j0-lane;
+                sg sj; sj.b = 0; sj.pb = 0; sj.key = -1;
+                if (jj >= 0) sj = seg(jj);
+                const bool inw = jj >= 0 && sj.b > slim;       // (monotone)
+                const uint64_t mI = __ballot(inw), mS = __ballot(inw && sj.key > sk), mN = __ballot(inw && sj.key >= sk);
+                if (mS)
+                  { const int fs = __ffsll((long long)mS)-1;
+                    shp = true; spb = __shfl(sj.b,fs); sbl = true; sbn = true;
+                    break;
+                  }
+                sbn = sbn || mI != 0; sbl = sbl || mN != 0;
+                if (mI != ~0ull || (sbl && sgi < 0)) break;
+              }
+            if (lane == src) { blocked = sbl; bnon = sbn; havep = shp; pbeg = spb; }
+          }
         // -- values --
         const bool wipe = act && bnon && !blocked;
         const bool isexp = act && g < 0;
@@ -920,23 +961,40 @@ __device__ __forceinline__ int sw_find_seeds(const cp_seedw_read &R, int lane SW
           if (c == 'H' || c == 'D') normal += len;
         }
     };
-  for (int e0 = 0; e0 < plen; e0 += WAVE)
-    { const int p = e0+lane;
-      const bool in = p < plen;
-      const char c = in ? R.cls[p] : (char)0, cp = (in && p > 0) ? R.cls[p-1] : (char)0;
-      const uint64_t sm = __ballot(in && (p == 0 || c != cp));
-      if (sm == 0) continue;
-      __syncthreads();
-      sw_S.cval[lane] = c;
-      __syncthreads();
-      if (lane == 0)
-        { uint64_t m = sm;
-          while (m)
-            { const int j = __ffsll((long long)m)-1;
-              m &= m-1;
-              const int s = e0+j;
-              if (s > 0) label_run(lrun_s,lrun_c,s-lrun_s,lrun_s == 0);
-              lrun_s = s; lrun_c = (char)sw_S.cval[j];
+  // (four chunks of 64 labels per step, their loads issued together: chunk by chunk the loop was one HBM round trip per
+  //  64 positions with nothing to do in between -- 12 % of the kernel's time for 3 % of its instructions)
+  constexpr int AN = 4;
+  for (int e0 = 0; e0 < plen; e0 += AN*WAVE)
+    { char cc[AN];
+      char cprev = (e0 > 0 && lane == 0) ? R.cls[e0-1] : (char)0;
+#pragma unroll
+      for (int u = 0; u < AN; u++)
+        { const int p = e0+u*WAVE+lane;
+          cc[u] = p < plen ? R.cls[p] : (char)0;
+        }
+#pragma unroll
+      for (int u = 0; u < AN; u++)
+        { const int c0 = e0+u*WAVE, p = c0+lane;
+          if (c0 >= plen) break;
+          const bool in = p < plen;
+          const char c = cc[u];
+          int cpi = __shfl_up((int)c,1);
+          if (lane == 0) cpi = (int)cprev;
+          cprev = (char)__shfl((int)c,WAVE-1);               // (lane 0 uses it for the next chunk)
+          const uint64_t sm = __ballot(in && (p == 0 || (int)c != cpi));
+          if (sm == 0) continue;
+          __syncthreads();
+          sw_S.cval[lane] = c;
+          __syncthreads();
+          if (lane == 0)
+            { uint64_t m = sm;
+              while (m)
+                { const int j = __ffsll((long long)m)-1;
+                  m &= m-1;
+                  const int s = c0+j;
+                  if (s > 0) label_run(lrun_s,lrun_c,s-lrun_s,lrun_s == 0);
+                  lrun_s = s; lrun_c = (char)sw_S.cval[j];
+                }
             }
         }
     }
