@@ -74,5 +74,9 @@ with open(os.path.join(dst, name + "_scan_durations.txt"), "w") as f:
     f.write("# roofline loop (back-to-back on one stream), the earlier ones belong to the pipeline and overlap with the other stream's kernels\n")
     f.write("all %d launches: average %.1f us (the figure in %s_kernel_stats.csv)\n" % (len(d), sum(d) / len(d), name))
     f.write("roofline-loop launches (%d): average %.1f us, min %.1f, max %.1f\n" % (len(loop), sum(loop) / len(loop), min(loop), max(loop)))
-    f.write("bench.py HIP events (%s_bench.json): %.1f us per launch, %.0f GB/s\n" % (name, bench["roofline"]["ms_per_launch"] * 1e3, bench["roofline"]["achieved"]))
+    f.write("bench.py HIP events, separate unprofiled run (%s_bench.json): %.1f us per launch, %.0f GB/s\n" % (name, bench["roofline"]["ms_per_launch"] * 1e3, bench["roofline"]["achieved"]))
+    same = [json.loads(l) for l in open(os.path.join(src, "stats.log")) if l.startswith("{")]
+    if same:                                   # the bench line printed by the traced run itself: events and trace of the SAME launches
+        r = same[-1]["roofline"]
+        f.write("bench.py HIP events of the traced run itself (stats.log): %.1f us per launch, %.0f GB/s, frac %.3f\n" % (r["ms_per_launch"] * 1e3, r["achieved"], r["frac"]))
 print(open(os.path.join(dst, name + "_scan_durations.txt")).read())
