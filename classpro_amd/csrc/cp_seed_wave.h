@@ -52,18 +52,6 @@
 #define SW_STEP  2                               // chunks of 64 positions per load step (4: 57.6 ms against 55.6)
 #endif
 
-struct cp_seedw_lds
-  { int2     rbp[SW_RING];                       // (begin, predecessor's begin) of the valid segments around the tile being worked on
-    int16_t  rkey[SW_RING+SW_RING/4+SW_RING/16]; // ... their keys; behind them the largest key of every aligned block of 4 and of 16 segments
-    int32_t  mi_b[SW_MI], mi_e[SW_MI];           // masked-interval list while it fits
-    int32_t  cval[SW_STEP*WAVE];                 // per position: the count if the k-mer is valid, else -1; base classes for the hash
-    int32_t  bins[32];
-    int32_t  pend_b[SW_PEND], pend_e[SW_PEND];
-    int32_t  rep[2*SW_REP];                      // repetitive stretches in k-mer coordinates while they fit
-  };
-
-__shared__ cp_seedw_lds sw_S;                    // the wave's LDS block (one wave per workgroup)
-
 struct cp_seedw_read
   { const char *seq, *cls; const uint16_t *prof; char *state;
     int plen, K, cap, rep_cap;
@@ -75,6 +63,20 @@ struct cp_seedw_read
     int32_t *err;                                                       // bit 4: a read needed more segments than its scratch holds
     int dbg_read;                                                       // (diagnostic builds) this is the read to dump
   };
+
+struct cp_seedw_lds
+  { int2     rbp[SW_RING];                       // (begin, predecessor's begin) of the valid segments around the tile being worked on
+    int16_t  rkey[SW_RING+SW_RING/4+SW_RING/16]; // ... their keys; behind them the largest key of every aligned block of 4 and of 16 segments
+    int32_t  mi_b[SW_MI], mi_e[SW_MI];           // masked-interval list while it fits
+    int32_t  cval[SW_STEP*WAVE];                 // per position: the count if the k-mer is valid, else -1; base classes for the hash
+    int32_t  bins[32];
+    int32_t  pend_b[SW_PEND], pend_e[SW_PEND];
+    int32_t  rep[2*SW_REP];                      // repetitive stretches in k-mer coordinates while they fit
+    cp_seedw_read R;                             // the read (the selections are calls: what they share travels through here)
+    int32_t  lm_big;                             // the masked-interval list has moved to the read's HBM scratch
+  };
+
+__shared__ cp_seedw_lds sw_S;                    // the wave's LDS block (one wave per workgroup)
 
 #ifdef CP_SEED_PROF
 #define SW_STAMP(k) do { if (lane == 0) { unsigned long long t_ = wall_clock64(); sw_t[k] += t_-sw_last; sw_last = t_; } } while (0)
@@ -92,6 +94,11 @@ struct cp_seedw_read
 #endif
 
 __device__ __forceinline__ int sw_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T> __device__ __forceinline__ T *sw_first_ptr(T *p)
+{ const uint64_t v = (uint64_t)p;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return (T *)(((uint64_t)hi << 32) | lo);
+}
 
 // k applications of cp_nt_srol (nthash.h:181-207: rol1, then bits 0 and 33 swapped) = the low 33 bits and the high 31
 // bits each rotated left by k within themselves
@@ -409,9 +416,37 @@ __device__ __attribute__((noinline)) void sw_mark_all(const char *seq, const cha
 // done one by one by the whole wave, 64 window segments per step (ballots); the prefix operations are ballots with three
 // carried scalars.  The segments' (begin, count) sit in an LDS ring around the tile; a window that reaches beyond it is
 // read from the records in HBM.
+// A selection is a CALL (not inlined): its registers are allotted on their own -- inlined three times into the kernel the
+// wave-uniform state of everything (a dozen pointers, the list, the counters) was live across all of it and 196 scalar
+// and 45 vector registers were spilled, reloaded from scratch inside the per-position loop.  What a selection needs of the
+// read it takes from the LDS block (sw_S.R; wave-uniform by readfirstlane, since a callee's arguments arrive in vector
+// registers), the list's place goes back through sw_S.lm_big.
+__device__ __forceinline__ cp_seedw_read sw_the_read()
+{ cp_seedw_read R;
+  R.seq = sw_first_ptr(sw_S.R.seq); R.cls = sw_first_ptr(sw_S.R.cls); R.prof = sw_first_ptr(sw_S.R.prof); R.state = sw_first_ptr(sw_S.R.state);
+  R.plen = sw_first(sw_S.R.plen); R.K = sw_first(sw_S.R.K); R.cap = sw_first(sw_S.R.cap); R.rep_cap = sw_first(sw_S.R.rep_cap);
+  R.rec = sw_first_ptr(sw_S.R.rec); R.orec = sw_first_ptr(sw_S.R.orec); R.tmp = sw_first_ptr(sw_S.R.tmp);
+  R.gmi_b = sw_first_ptr(sw_S.R.gmi_b); R.gmi_e = sw_first_ptr(sw_S.R.gmi_e); R.rep_pairs = sw_first_ptr(sw_S.R.rep_pairs);
+  R.err = sw_first_ptr(sw_S.R.err); R.dbg_read = sw_first(sw_S.R.dbg_read);
+  return R;
+}
+template <bool rep> __device__ __forceinline__ void sw_select_body(const cp_seedw_read &R, sw_list &Lm, int C, int nrep, bool rep_big, int lane
+                                                                   SW_PROF_ARGS);
 template <bool rep>
-__device__ __forceinline__ void sw_select(const cp_seedw_read &R, sw_list &Lm, int C, int nrep, bool rep_big, int lane
-                                          SW_PROF_ARGS)
+__device__ __attribute__((noinline)) void sw_select(int C, int nrep, int rep_big, int lane SW_PROF_ARGS)
+{ const cp_seedw_read R = sw_the_read();
+  sw_list Lm; Lm.gb = R.gmi_b; Lm.ge = R.gmi_e; Lm.big = sw_first(sw_S.lm_big) != 0;
+  const bool was_big = Lm.big;
+  sw_select_body<rep>(R,Lm,sw_first(C),sw_first(nrep),sw_first(rep_big) != 0,lane SW_PROF_PASS);
+  if (Lm.big != was_big)
+    { __syncthreads();
+      if (lane == 0) sw_S.lm_big = 1;
+      __syncthreads();
+    }
+}
+template <bool rep>
+__device__ __forceinline__ void sw_select_body(const cp_seedw_read &R, sw_list &Lm, int C, int nrep, bool rep_big, int lane
+                                               SW_PROF_ARGS)
 { const int W = rep ? CP_SEED_W_REP : CP_SEED_W;
   const int plen = R.plen, Km1 = R.K-1;
   const uint64_t lt = (1ull << lane)-1;
@@ -941,7 +976,7 @@ __device__ __forceinline__ int sw_find_seeds(const cp_seedw_read &R, int lane SW
 { const int plen = R.plen, K = R.K, Km1 = K-1;
   if (plen <= 0) return 0;
   for (int q = lane; q < SW_MI; q += WAVE) { sw_S.mi_b[q] = 0; sw_S.mi_e[q] = 0; }     // defined start state of the list
-  sw_list Lm; Lm.gb = R.gmi_b; Lm.ge = R.gmi_e; Lm.big = false;
+  if (lane == 0) { sw_S.R = R; sw_S.lm_big = 0; }            // (visible to the selections: barriers below)
   // ---- unique / repetitive stretches -> .rep intervals (seed.c:482-566): label runs from a ballot, lane 0 over the runs ----
   const int min_uniq = (int)(K*2.5);
   int nrep = 0, rs = -1, i0 = 0, normal = 0, lrun_s = 0; bool inR = false; char lrun_c = 0;
@@ -1012,7 +1047,7 @@ __device__ __forceinline__ int sw_find_seeds(const cp_seedw_read &R, int lane SW
   const bool rep_big = nrep > SW_REP;                        // then the HBM list is searched (complete: rep_cap bounds the label runs)
   const int nr = nrep > R.rep_cap ? R.rep_cap : nrep;
   for (int sel = 0; sel < 2; sel++)                          // H, then D: one copy of the code
-    sw_select<false>(R,Lm,sel == 0 ? 'H' : 'D',nr,rep_big,lane SW_PROF_PASS);
-  sw_select<true>(R,Lm,0,nr,rep_big,lane SW_PROF_PASS);
+    sw_select<false>(sel == 0 ? 'H' : 'D',nr,rep_big ? 1 : 0,lane SW_PROF_PASS);
+  sw_select<true>(0,nr,rep_big ? 1 : 0,lane SW_PROF_PASS);
   return nrep;
 }
