@@ -74,6 +74,7 @@ struct cp_seedw_lds
     int32_t  rep[2*SW_REP];                      // repetitive stretches in k-mer coordinates while they fit
     cp_seedw_read R;                             // the read (the selections are calls: what they share travels through here)
     int32_t  lm_big;                             // the masked-interval list has moved to the read's HBM scratch
+    int32_t  sel[8];                             // what the phases of a selection hand to each other (SEL_*)
   };
 
 __shared__ cp_seedw_lds sw_S;                    // the wave's LDS block (one wave per workgroup)
@@ -416,11 +417,12 @@ __device__ __attribute__((noinline)) void sw_mark_all(const char *seq, const cha
 // done one by one by the whole wave, 64 window segments per step (ballots); the prefix operations are ballots with three
 // carried scalars.  The segments' (begin, count) sit in an LDS ring around the tile; a window that reaches beyond it is
 // read from the records in HBM.
-// A selection is a CALL (not inlined): its registers are allotted on their own -- inlined three times into the kernel the
-// wave-uniform state of everything (a dozen pointers, the list, the counters) was live across all of it and 196 scalar
-// and 45 vector registers were spilled, reloaded from scratch inside the per-position loop.  What a selection needs of the
-// read it takes from the LDS block (sw_S.R; wave-uniform by readfirstlane, since a callee's arguments arrive in vector
-// registers), the list's place goes back through sw_S.lm_big.
+// A selection runs as four CALLS (not inlined) -- segments, window counts, sort, walk -- so that each phase has its
+// registers allotted on its own: inlined three times into the kernel, the wave-uniform state of everything (a dozen
+// pointers, the list, the counters) was live across all of it and 196 scalar and 45 vector registers were spilled,
+// reloaded from scratch inside the per-position loop.  What a phase needs of the read it takes from the LDS block
+// (sw_S.R; made wave-uniform by readfirstlane, since a callee's arguments arrive in vector registers); what the phases
+// hand to each other goes through sw_S.sel[] and sw_S.lm_big.
 __device__ __forceinline__ cp_seedw_read sw_the_read()
 { cp_seedw_read R;
   R.seq = sw_first_ptr(sw_S.R.seq); R.cls = sw_first_ptr(sw_S.R.cls); R.prof = sw_first_ptr(sw_S.R.prof); R.state = sw_first_ptr(sw_S.R.state);
@@ -430,27 +432,29 @@ __device__ __forceinline__ cp_seedw_read sw_the_read()
   R.err = sw_first_ptr(sw_S.R.err); R.dbg_read = sw_first(sw_S.R.dbg_read);
   return R;
 }
-template <bool rep> __device__ __forceinline__ void sw_select_body(const cp_seedw_read &R, sw_list &Lm, int C, int nrep, bool rep_big, int lane
-                                                                   SW_PROF_ARGS);
-template <bool rep>
-__device__ __attribute__((noinline)) void sw_select(int C, int nrep, int rep_big, int lane SW_PROF_ARGS)
-{ const cp_seedw_read R = sw_the_read();
-  sw_list Lm; Lm.gb = R.gmi_b; Lm.ge = R.gmi_e; Lm.big = sw_first(sw_S.lm_big) != 0;
-  const bool was_big = Lm.big;
-  sw_select_body<rep>(R,Lm,sw_first(C),sw_first(nrep),sw_first(rep_big) != 0,lane SW_PROF_PASS);
-  if (Lm.big != was_big)
-    { __syncthreads();
-      if (lane == 0) sw_S.lm_big = 1;
-      __syncthreads();
+enum { SEL_N = 0, SEL_M, SEL_NBIG, SEL_BLAST, SEL_STOP };    // sw_S.sel[]: valid segments, skipped stretches (list slots), counts > 1000, begin of the last segment, selection over
+__device__ __forceinline__ sw_list sw_the_list(const cp_seedw_read &R)
+{ sw_list Lm; Lm.gb = R.gmi_b; Lm.ge = R.gmi_e; Lm.big = sw_first(sw_S.lm_big) != 0; return Lm; }
+__device__ __forceinline__ int sw_sel(int k) { return sw_first(sw_S.sel[k]); }
+// (wave-uniform values; the barriers make them visible to the next phase)
+__device__ __forceinline__ void sw_sel_put(int lane, int n, int M, int nbig, int b_last, int stop, bool big)
+{ __syncthreads();
+  if (lane == 0)
+    { sw_S.sel[SEL_N] = n; sw_S.sel[SEL_M] = M; sw_S.sel[SEL_NBIG] = nbig; sw_S.sel[SEL_BLAST] = b_last; sw_S.sel[SEL_STOP] = stop;
+      sw_S.lm_big = big ? 1 : 0;
     }
+  __syncthreads();
 }
+
 template <bool rep>
-__device__ __forceinline__ void sw_select_body(const cp_seedw_read &R, sw_list &Lm, int C, int nrep, bool rep_big, int lane
-                                               SW_PROF_ARGS)
-{ const int W = rep ? CP_SEED_W_REP : CP_SEED_W;
+__device__ __attribute__((noinline)) void sw_segments(int C_, int nrep_, int rep_big_, int lane SW_PROF_ARGS)
+{ const cp_seedw_read R = sw_the_read();
+  sw_list Lm = sw_the_list(R);
+  const int C = sw_first(C_), nrep = sw_first(nrep_);
+  const bool rep_big = sw_first(rep_big_) != 0;
   const int plen = R.plen, Km1 = R.K-1;
   const uint64_t lt = (1ull << lane)-1;
-  int n = 0, M = 0, nbig = 0, endpos = plen, b_last = 0;
+  int n = 0, M = 0, b_last = 0;
   // ---- segments (seed.c:61-110 / :599-665 in closed form) ----
   // valid(i): the k-mer takes part in this selection.  A valid segment is a run of equal counts from its first valid
   // k-mer on (it may run on over k-mers of other classes); the k-mers skipped between segments form invalid ones.  A
@@ -554,14 +558,13 @@ __device__ __forceinline__ void sw_select_body(const cp_seedw_read &R, sw_list &
       }
     if (lpos >= 0 && lpos >= plen-1)                         // a segment at the last k-mer is never made: it only ends its predecessor
       { if (ltype) nv--; else ni--;
-        endpos = plen-1;
       }
     else if (lpos >= 0 && lane == 0 && lidx < R.cap)         // the last segment runs to the end of the read
       { if (ltype) R.rec[lidx].y = plen; else R.orec[lidx].y = plen; }
     n = nv; M = ni;
     b_last = lpos >= plen-1 ? -1 : lpos;                     // begin of the last segment of either kind (-1: see below)
     __syncthreads();                                         // the records are visible to the wave
-    if (nv > R.cap || ni > R.cap) { if (lane == 0) atomicOr(R.err,4); return; }   // (k_seed_caps sizes the scratch; reported, never written past)
+    if (nv > R.cap || ni > R.cap) { if (lane == 0) atomicOr(R.err,4); sw_sel_put(lane,0,0,0,0,1,Lm.big); return; }   // (k_seed_caps sizes the scratch; reported, never written past)
     if (lpos >= plen-1)                                      // the dropped start's predecessor is the last segment
       { int bl = -1;
         if (nv > 0) bl = R.rec[nv-1].x;
@@ -574,7 +577,16 @@ __device__ __forceinline__ void sw_select_body(const cp_seedw_read &R, sw_list &
     __syncthreads();
   }
   SW_STAMP(1);
-  SW_STOP(1);
+  sw_sel_put(lane,n,M,0,b_last,0,Lm.big);
+}
+
+template <bool rep>
+__device__ __attribute__((noinline)) void sw_windows(int lane SW_PROF_ARGS)
+{ const cp_seedw_read R = sw_the_read();
+  const int W = rep ? CP_SEED_W_REP : CP_SEED_W;
+  const uint64_t lt = (1ull << lane)-1;
+  const int n = sw_sel(SEL_N), b_last = sw_sel(SEL_BLAST);
+  int nbig = 0;
   // ---- window counts, 64 valid segments at a time ----
   // key = count (H/D) or 32767 - count (repeats): both selections look for the larger key.  pb(j): the begin of j's
   // predecessor of either kind (record field z until the window count replaces it); j is still within reach of i
@@ -791,26 +803,40 @@ __device__ __forceinline__ void sw_select_body(const cp_seedw_read &R, sw_list &
         if (act) R.rec[i].z = nw;
       }
   }
+  __syncthreads();
+  if (lane == 0) sw_S.sel[SEL_NBIG] = nbig;
+  __syncthreads();
+}
+
+__device__ __attribute__((noinline)) void sw_sort(int rep_, int lane SW_PROF_ARGS)
+{ const cp_seedw_read R = sw_the_read();
+  const sw_list Lm = sw_the_list(R);
+  const int plen = R.plen;
+  const uint64_t lt = (1ull << lane)-1;
+  int n = sw_sel(SEL_N);
+  const int M = sw_sel(SEL_M), nbig = sw_sel(SEL_NBIG);
   // The skipped stretches join the records after all, behind the valid segments, with the reference's -10: the sort
   // puts them last (in their own order: it is stable), and the walk does reach them when the read is still uncovered --
   // the reference then tests them against its list like any segment, and its search of that list, one slot past the
   // live part, can miss the very interval they were masked with (tests/golden/seeds.npz holds such reads).
-  if (n+M > R.cap) { if (lane == 0) atomicOr(R.err,4); return; }
+  if (n+M > R.cap) { if (lane == 0) atomicOr(R.err,4); sw_sel_put(lane,0,0,0,0,1,Lm.big); return; }
   for (int q = lane; q < M; q += WAVE) { const int4 t = R.orec[q]; R.rec[n+q] = make_int4(t.x,t.y,-10,0); }
   n += M;
   __syncthreads();                                           // the window counts are visible to the wave
 #ifdef CP_SEED_DEBUG
-  if (R.dbg_read && rep)                                     // diagnostic builds: the repeat selection's records of one read
+  if (R.dbg_read && sw_first(rep_))                                     // diagnostic builds: the repeat selection's records of one read
     { for (int q = lane; q < n && q < 8192; q += WAVE) g_seed_dbg[q] = R.rec[q];
-      if (lane == 0) { g_seed_dbg_n[0] = n; g_seed_dbg_n[1] = M; g_seed_dbg_n[2] = b_last; g_seed_dbg_n[3] = nrep; }
+      if (lane == 0) { g_seed_dbg_n[0] = n; g_seed_dbg_n[1] = M; g_seed_dbg_n[2] = sw_sel(SEL_BLAST); g_seed_dbg_n[3] = 0; }
     }
 #endif
   SW_STAMP(5);
-  SW_STOP(2);
 #ifdef CP_SEED_PROF
   if (lane == 0) { sw_t[7] += n; }
 #endif
-  if (M > 0 && Lm.b(0) == 0 && Lm.e(0) == plen) return;
+#ifdef CP_SEED_STOP_AT
+  if (CP_SEED_STOP_AT == 2) { sw_sel_put(lane,n,M,nbig,0,1,Lm.big); return; }
+#endif
+  if (M > 0 && Lm.b(0) == 0 && Lm.e(0) == plen) { sw_sel_put(lane,n,M,nbig,0,1,Lm.big); return; }
   // ---- stable order by decreasing window count (the reference's qsort is glibc's stable merge sort): two 5-bit radix
   //      passes on 1000 - count (the skipped stretches, -10, come last), ranks from ballots ----
   for (int pass = 0; pass < 2; pass++)
@@ -865,7 +891,19 @@ __device__ __forceinline__ void sw_select_body(const cp_seedw_read &R, sw_list &
       __syncthreads();
     }
   SW_STAMP(2);
-  SW_STOP(3);
+  sw_sel_put(lane,n,M,nbig,0,0,Lm.big);
+}
+
+template <bool rep>
+__device__ __attribute__((noinline)) void sw_walk(int lane SW_PROF_ARGS)
+{ const cp_seedw_read R = sw_the_read();
+  sw_list Lm = sw_the_list(R);
+  const int W = rep ? CP_SEED_W_REP : CP_SEED_W;
+  const int plen = R.plen, Km1 = R.K-1;
+  const uint64_t lt = (1ull << lane)-1;
+  const int n = sw_sel(SEL_N);
+  int M = sw_sel(SEL_M);
+  const bool was_big = Lm.big;
   // ---- selection (wave-uniform control flow) ----
   // taken segments are listed in R.tmp (idle after the sort) and marked at the end; the list is written 64 takes at a
   // time from an LDS buffer (cval), so that the list update of a take -- a chain of wave barriers -- never waits for a
@@ -968,6 +1006,23 @@ __device__ __forceinline__ void sw_select_body(const cp_seedw_read &R, sw_list &
 #endif
   SW_STAMP(3);
   __syncthreads();                                           // the marks are visible to the next selection
+  if (Lm.big != was_big)
+    { if (lane == 0) sw_S.lm_big = 1;
+      __syncthreads();
+    }
+}
+
+// one selection (seed.c:190-476 with C = 'H'/'D'; seed.c:667-951 with C = 0)
+template <bool rep>
+__device__ __forceinline__ void sw_select(int C, int nrep, int rep_big, int lane SW_PROF_ARGS)
+{ sw_segments<rep>(C,nrep,rep_big,lane SW_PROF_PASS);
+  SW_STOP(1);
+  if (sw_sel(SEL_STOP)) return;
+  sw_windows<rep>(lane SW_PROF_PASS);
+  sw_sort(rep ? 1 : 0,lane SW_PROF_PASS);
+  SW_STOP(3);
+  if (sw_sel(SEL_STOP)) return;
+  sw_walk<rep>(lane SW_PROF_PASS);
 }
 
 // ---- the whole path for one read.  R.state holds 'E' at every k-mer on entry.  Returns the number of .rep intervals
