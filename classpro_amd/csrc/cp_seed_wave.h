@@ -44,7 +44,13 @@
 #ifndef SW_IND
 #define SW_IND   32                              // segments a lane searches on its own in each direction before the wave takes over
 #endif
-#define SW_MI    256
+#ifndef SW_LEV
+#define SW_LEV   7                               // levels of the range-maximum table: blocks of 1 .. 64 segments
+#endif
+#define SW_TOPB  (SW_RING >> (SW_LEV-1))          // blocks of the largest size that cover the ring
+#ifndef SW_MI
+#define SW_MI    128
+#endif
 #define SW_PEND  64
 #define SW_REP   64
 #define SW_KMAX  64                              // k-mer lengths served by the rotated-seed table (longer: byte-wise fold)
@@ -66,16 +72,22 @@ struct cp_seedw_read
 
 struct cp_seedw_lds
   { int2     rbp[SW_RING];                       // (begin, predecessor's begin) of the valid segments around the tile being worked on
-    int16_t  rkey[SW_RING+SW_RING/4+SW_RING/16]; // ... their keys; behind them the largest key of every aligned block of 4 and of 16 segments
+    int16_t  rkey[SW_RING];                      // ... their keys = level 0 of the range-maximum table: level k, slot j mod SW_RING = the largest key of [j, j+2^k)
+    union                                        // the table's higher levels live during the window counts only: they share their
+      { int16_t rkeyk[SW_LEV-1][SW_RING];        // block with the buffers of the phases around it (3 KB of the wave's 6.8: a sixth wave per SIMD)
+        struct
+          { int32_t  cval[SW_STEP*WAVE];         // label classes (anno_repeat), the take buffer of the walk, base classes for the hash
+            int32_t  bins[32];
+            int32_t  pend_b[SW_PEND], pend_e[SW_PEND];
+          };
+      };
     int32_t  mi_b[SW_MI], mi_e[SW_MI];           // masked-interval list while it fits
-    int32_t  cval[SW_STEP*WAVE];                 // per position: the count if the k-mer is valid, else -1; base classes for the hash
-    int32_t  bins[32];
-    int32_t  pend_b[SW_PEND], pend_e[SW_PEND];
     int32_t  rep[2*SW_REP];                      // repetitive stretches in k-mer coordinates while they fit
     cp_seedw_read R;                             // the read (the selections are calls: what they share travels through here)
     int32_t  lm_big;                             // the masked-interval list has moved to the read's HBM scratch
     int32_t  sel[8];                             // what the phases of a selection hand to each other (SEL_*)
   };
+static_assert(offsetof(cp_seedw_lds,rkeyk) == offsetof(cp_seedw_lds,rkey)+SW_RING*sizeof(int16_t),"the levels of the range-maximum table are one array");
 
 __shared__ cp_seedw_lds sw_S;                    // the wave's LDS block (one wave per workgroup)
 
@@ -95,10 +107,13 @@ __shared__ cp_seedw_lds sw_S;                    // the wave's LDS block (one wa
 #endif
 
 __device__ __forceinline__ int sw_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// (the pointer is rebuilt as a GLOBAL one: out of an integer it would be a flat pointer, whose loads and stores count on
+//  both memory counters and wait for each other)
 template <class T> __device__ __forceinline__ T *sw_first_ptr(T *p)
 { const uint64_t v = (uint64_t)p;
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-  return (T *)(((uint64_t)hi << 32) | lo);
+  typedef T __attribute__((address_space(1))) *gptr;
+  return (T *)(gptr)(((uint64_t)hi << 32) | lo);
 }
 
 // k applications of cp_nt_srol (nthash.h:181-207: rol1, then bits 0 and 33 swapped) = the low 33 bits and the high 31
@@ -205,7 +220,9 @@ __device__ __forceinline__ int sw_mi_add(sw_list &Lm, int M, int b, int e, int l
 // (the forward strand's seed rotated K-1-t times, the reverse strand's rotated t times: nthash.h:215-235 unrolled)
 __device__ __attribute__((noinline)) void sw_mark(const char *seq, const char *cls, char *state, int rlen, int K,
                                                   int b, int e, bool rep, int lane)
-{ if (e-b == 1) { if (lane == 0) state[b] = rep ? 'R' : cls[b]; return; }
+{ seq = sw_first_ptr(seq); cls = sw_first_ptr(cls); state = sw_first_ptr(state);       // (wave-uniform; global, not flat: sw_first_ptr)
+  rlen = sw_first(rlen); K = sw_first(K); b = sw_first(b); e = sw_first(e); rep = sw_first(rep ? 1 : 0) != 0;
+  if (e-b == 1) { if (lane == 0) state[b] = rep ? 'R' : cls[b]; return; }
   const bool table = K <= SW_KMAX;
   int mh = CP_SEED_MOD, h = CP_SEED_MOD;
   for (int pass = 0; pass < 2; pass++)                        // minimum first, marks second
@@ -325,7 +342,9 @@ __device__ __forceinline__ int sw_hash_at(const char *seq, int j, int K, int rle
 // wait in registers for the mark sweep.
 __device__ __attribute__((noinline)) void sw_mark_all(const char *seq, const char *cls, char *state, int K, int rlen, const int32_t *takes,
                                                       int ntake, bool rep, int lane)
-{ if (ntake == 0) return;
+{ seq = sw_first_ptr(seq); cls = sw_first_ptr(cls); state = sw_first_ptr(state); takes = sw_first_ptr(takes);
+  K = sw_first(K); rlen = sw_first(rlen); ntake = sw_first(ntake); rep = sw_first(rep ? 1 : 0) != 0;
+  if (ntake == 0) return;
   int32_t *s_pre = sw_S.pend_b, *s_min = sw_S.pend_e;        // (the pending-take buffers are idle here; SW_PEND >= 64)
   static_assert(SW_PEND >= WAVE,"one slot per segment of a round");
   static_assert(sizeof(sw_S.rbp)+sizeof(sw_S.rkey) >= sizeof(sw_rot_tab) && offsetof(cp_seedw_lds,rkey) == sizeof(sw_S.rbp),
@@ -461,7 +480,7 @@ __device__ __attribute__((noinline)) void sw_segments(int C_, int nrep_, int rep
   // segment that would start at the last k-mer is never made (the reference's loop ends first).
   // Per 64 k-mers the lanes only produce two masks -- run boundaries, valid k-mers -- and the segment starts come out of
   // them with scalar bit operations, the same for every lane: a segmented OR-scan ("this run already holds a valid
-  // k-mer") in six shift-and-mask steps.  The VALID segments get records of their own, (begin, end, -, key+1) at
+  // k-mer") by one carry-propagating addition.  The VALID segments get records of their own, (begin, end, -, key+1) at
   // R.rec[0..n), the skipped stretches go to a side list (R.orec) and from there to the masked-interval list: the window
   // counts, the sort and the walk then only see valid segments.  Two skipped stretches are never adjacent, so a valid
   // segment's predecessor of either kind is known from its valid predecessor's begin and end.
@@ -511,17 +530,14 @@ __device__ __attribute__((noinline)) void sw_segments(int C_, int nrep_, int rep
             const bool v = in && (rep ? (cl[u] != 'E' && st[u] == 'E' && ((rmask >> lane) & 1)) : cl[u] == (char)C);
             const uint64_t inm = plen-c0 >= WAVE ? ~0ull : ((1ull << (plen-c0))-1);
             const uint64_t bm = __ballot(bnd), vm = __ballot(v);
-            // hv: the run of a k-mer holds a valid k-mer at or before it (segmented OR-scan of vm, runs start at bm)
-            uint64_t hv = vm;
-            if (carry) hv |= bm ? ((bm & (0-bm))-1) : ~0ull;
-            { uint64_t B = ~bm;
-              hv |= (hv << 1) & B;  B &= B << 1;
-              hv |= (hv << 2) & B;  B &= B << 2;
-              hv |= (hv << 4) & B;  B &= B << 4;
-              hv |= (hv << 8) & B;  B &= B << 8;
-              hv |= (hv << 16) & B; B &= B << 16;
-              hv |= (hv << 32) & B;
-            }
+            // hv: the run of a k-mer holds a valid k-mer at or before it -- a segmented OR-scan of vm over the runs that
+            // start at bm, by ONE addition: X marks the k-mers whose successor belongs to the same run; adding a valid
+            // k-mer's bit to X sends a carry up through the rest of its run, which flips those bits of X and sets the run's
+            // last one (a second valid k-mer on the way is not flipped, but it is in vm).  (Six shift-and-mask steps
+            // before: 33 of the 81 scalar instructions per 64 k-mers of a loop whose bound is the scalar unit.)
+            const uint64_t v0 = vm | ((carry && !(bm & 1)) ? 1ull : 0ull);       // (the run entering the chunk goes on at k-mer 0)
+            const uint64_t X = ~(bm >> 1) & 0x7fffffffffffffffull;
+            const uint64_t hv = v0 | ((X+(v0 & X)) ^ X);
             const uint64_t hvs = (hv << 1) | (carry ? 1ull : 0ull);       // the same one k-mer earlier
             // a k-mer starts a segment iff it is the first valid one of its run, or it begins a run whose predecessor run
             // held a valid k-mer, or it is the read's first
@@ -601,7 +617,7 @@ __device__ __attribute__((noinline)) void sw_windows(int lane SW_PROF_ARGS)
         return r;
       };
     // a segment within SW_IND of the tile: always in the ring (it covers [t0-SW_BACK, t0+SW_RING-SW_BACK) of [0,n)), no test
-    static_assert(SW_BACK % 32 == 0 && WAVE+1 <= SW_RING-SW_BACK,"ring fills are aligned to the blocks; a tile and its successor are in the ring");
+    static_assert(WAVE+1 <= SW_RING-SW_BACK && SW_TOPB >= 2,"a tile and its successor are in the ring");
     auto segr = [&](int j) -> sg
       { sg r; const int2 t = sw_S.rbp[j & (SW_RING-1)]; r.b = t.x; r.pb = t.y; r.key = sw_S.rkey[j & (SW_RING-1)]; return r; };
     bool c_have = false, c_wipe = false; int c_expb = 0, c_wpb = 0, c_pos = 0;   // carried: begin of the last expiring segment, pb of the last wipe, last_oor_pos
@@ -610,22 +626,25 @@ __device__ __attribute__((noinline)) void sw_windows(int lane SW_PROF_ARGS)
           if (upto > n) upto = n;
           if (ring_hi < upto)
             { __syncthreads();                               // (the slots being replaced are no longer read)
-              while (ring_hi < upto)
-                { const int j = ring_hi+lane;
-                  int km = -1;
-                  if (j < upto)
-                    { const int4 t = R.rec[j];
-                      sw_S.rbp[j & (SW_RING-1)] = make_int2(t.x,t.z); sw_S.rkey[j & (SW_RING-1)] = (int16_t)(t.w-1);
-                      km = t.w-1;
-                    }
-                  // (ring_hi is a multiple of 32: groups of 4 / 16 lanes are aligned blocks; a block no segment of which is
-                  //  loaded yet shares its slot with the oldest ones of the ring and is left alone)
-                  km = max(km,__shfl_xor(km,1)); km = max(km,__shfl_xor(km,2));
-                  if ((lane & 3) == 0 && j < upto) sw_S.rkey[SW_RING+((j >> 2) & (SW_RING/4-1))] = (int16_t)km;
-                  km = max(km,__shfl_xor(km,4)); km = max(km,__shfl_xor(km,8));
-                  if ((lane & 15) == 0 && j < upto) sw_S.rkey[SW_RING+SW_RING/4+((j >> 4) & (SW_RING/16-1))] = (int16_t)km;
-                  ring_hi = ring_hi+WAVE < upto ? ring_hi+WAVE : upto;
+              const int old_hi = ring_hi;
+              for (int j = old_hi+lane; j < upto; j += WAVE)
+                { const int4 t = R.rec[j];
+                  sw_S.rbp[j & (SW_RING-1)] = make_int2(t.x,t.z); sw_S.rkey[j & (SW_RING-1)] = (int16_t)(t.w-1);
                 }
+              // level k: the blocks [j, j+2^k) that have just become complete (j+2^k in (old_hi, upto]), from the two halves
+              // one level down
+#pragma unroll
+              for (int k = 1; k < SW_LEV; k++)
+                { __syncthreads();
+                  const int h = 1 << (k-1);
+                  int j0 = old_hi-2*h+1;
+                  if (j0 < 0) j0 = 0;
+                  for (int j = j0+lane; j+2*h <= upto; j += WAVE)
+                    { const int16_t a = sw_S.rkey[(k-1)*SW_RING+(j & (SW_RING-1))], c = sw_S.rkey[(k-1)*SW_RING+((j+h) & (SW_RING-1))];
+                      sw_S.rkey[k*SW_RING+(j & (SW_RING-1))] = a > c ? a : c;
+                    }
+                }
+              ring_hi = upto;
               __syncthreads();
             }
         }
@@ -640,15 +659,27 @@ __device__ __attribute__((noinline)) void sw_windows(int lane SW_PROF_ARGS)
             else ei = R.rec[i].y;
           }
         // -- forward: the first segment within reach that beats me; else what the reach holds --
-        // Both searches walk the ring by aligned blocks of 16, 4 and 1 segments whose largest key is kept beside the keys
-        // (blocks that hold nothing better are stepped over whole, a block that does is entered at the next smaller size):
-        // a dozen steps where a segment-by-segment walk over the ~70 segments of a window took 70, and the wave waits for
-        // its slowest lane.  The reach (begins grow with the index) is found first, by bisection.
-        // The loops are uniform (they run while any lane has work) and their bodies are straight-line selects: as per-lane
-        // `while` loops with early exits each step cost ~90 instructions, most of them exec-mask bookkeeping.
+        // The reach (begins grow with the index) is found by bisection.  What it holds comes from the range-maximum table
+        // beside the ring keys (rkey[k][j] = the largest key of [j, j+2^k)): the largest key of the reach from four
+        // overlapping blocks -- larger than mine: I am beaten; equal: a segment of my own count follows me -- and the FIRST
+        // segment that beats me by a descent over the block sizes (a block that holds nothing better is stepped over
+        // whole): nine steps of one LDS read, the same for every lane.  (Before: per-lane walks over aligned blocks of
+        // 16 / 4 / 1 segments in a loop that ran until the wave's slowest lane was done, ~17 rounds of 25 instructions
+        // for a segment that is beaten by nothing in a reach of ~70 segments.)
         const int hiR = ring_hi-1, loR = ring_hi-SW_RING > 0 ? ring_hi-SW_RING : 0;      // the ring holds segments [loR, hiR]
-        auto blk_idx = [](int pos, int s) -> int             // slot of the block of 1 << s segments that holds segment pos
-          { return ((pos >> s) & ((SW_RING-1) >> s))+(s == 4 ? SW_RING+SW_RING/4 : s == 2 ? SW_RING : 0); };
+        auto lev = [](int k, int j) -> int { return (int)sw_S.rkey[k*SW_RING+(j & (SW_RING-1))]; };
+        auto range_max = [&](int s, int e) -> int            // largest key of [s,e], 1 <= e-s+1 <= 255, both inside the ring
+          { const int len = e-s+1;
+            int k = 31-__clz(len);
+            k = k > SW_LEV-1 ? SW_LEV-1 : k;
+            const int last = e-(1 << k)+1, st = 1 << k;
+            const int16_t *row = sw_S.rkey+k*SW_RING;
+            int m = row[last & (SW_RING-1)];
+#pragma unroll
+            for (int q = 0; q < SW_TOPB-1; q++)              // (below the top level two blocks cover the range: the others repeat the last)
+              m = max(m,(int)row[min(s+q*st,last) & (SW_RING-1)]);
+            return m;
+          };
         int g = -1, bg = 0, pbg = 0;
         bool eq = false, nonempty = false, fopen = false;
 #ifndef SW_SKIP_FWD
@@ -661,21 +692,20 @@ __device__ __attribute__((noinline)) void sw_windows(int lane SW_PROF_ARGS)
               x = (act && c <= hiR && pbc < limv) ? c : x;
             }
           nonempty = x > i;
-          int pos = act ? i+1 : x+1, maxlen = 16, eqi = 0;
-          while (__ballot(pos <= x) != 0)
-            { const int room = x-pos+1;                      // <= 0: this lane is done
-              const int q = min(min(pos & -pos,room),maxlen);
-              const int sh = q >= 16 ? 4 : q >= 4 ? 2 : 0;
-              const int m = sw_S.rkey[blk_idx(pos,sh)];
-              const bool on = room > 0, hit = on && m > ki, fnd = hit && sh == 0;
-              eqi |= (on && m == ki) ? 1 : 0;
-              g = fnd ? pos : g;
-              maxlen = (hit && sh != 0) ? (1 << (sh-2)) : maxlen;
-              pos = fnd ? 0x3fffffff : (on && !hit) ? pos+(1 << sh) : pos;
+          const int mx = nonempty ? range_max(i+1,x) : -1;
+          eq = nonempty && mx == ki;
+          if (mx > ki)                                       // (never for a lane that is not active: its key is -1 and its reach empty)
+            { int pos = i+1;
+#pragma unroll
+              for (int q = 0; q < SW_LEV+SW_TOPB-2; q++)     // the largest blocks SW_TOPB-1 times (a reach holds < 256 segments), then the smaller ones
+                { const int k = q < SW_TOPB-1 ? SW_LEV-1 : SW_LEV+SW_TOPB-3-q;
+                  const int m = lev(k,pos);
+                  pos = (pos+(1 << k)-1 <= x && m <= ki) ? pos+(1 << k) : pos;
+                }
+              g = pos;
+              const int2 tg = sw_S.rbp[g & (SW_RING-1)];
+              bg = tg.x; pbg = tg.y;
             }
-          eq = eqi != 0;
-          const int2 tg = sw_S.rbp[g & (SW_RING-1)];
-          if (g >= 0) { bg = tg.x; pbg = tg.y; }
           fopen = act && g < 0 && x == hiR && hiR+1 < n;     // the reach may go on beyond the ring
         }
 #endif
@@ -723,24 +753,20 @@ __device__ __attribute__((noinline)) void sw_windows(int lane SW_PROF_ARGS)
             }
           bnon = y < i;
           const bool need = g >= 0;
-          int pos = actb ? i-1 : y-1, maxlen = 16, blk = 0, fin = 0, gp = -1;
-          while (__ballot(pos >= y) != 0)
-            { const int room = pos-y+1;                      // <= 0: this lane is done
-              const int q = min(min((pos+1) & -(pos+1),room),maxlen);       // (blocks that END at pos)
-              const int sh = q >= 16 ? 4 : q >= 4 ? 2 : 0;
-              const int m = sw_S.rkey[blk_idx(pos,sh)];
-              const bool on = room > 0, ge = on && m >= ki, gt = on && m > ki;
-              const bool stop = ge && !need, fnd = gt && need && sh == 0;
-              blk |= ge ? 1 : 0;
-              gp = fnd ? pos : gp;
-              fin |= (stop || fnd) ? 1 : 0;
-              maxlen = (gt && need && sh != 0) ? (1 << (sh-2)) : maxlen;
-              pos = (stop || fnd) ? -0x3fffffff : (on && !gt) ? pos-(1 << sh) : pos;
+          const int mx = bnon ? range_max(y,i-1) : -1;
+          blocked = bnon && mx >= ki;
+          if (need && mx > ki)                               // the nearest one before me that beats me
+            { int pos = i-1;
+#pragma unroll
+              for (int q = 0; q < SW_LEV+SW_TOPB-2; q++)
+                { const int k = q < SW_TOPB-1 ? SW_LEV-1 : SW_LEV+SW_TOPB-3-q;
+                  const int m = lev(k,pos-(1 << k)+1);
+                  pos = (pos-(1 << k)+1 >= y && m <= ki) ? pos-(1 << k) : pos;
+                }
+              havep = true;
+              pbeg = sw_S.rbp[pos & (SW_RING-1)].x;
             }
-          blocked = blk != 0;
-          havep = gp >= 0;
-          const int bgp = sw_S.rbp[gp & (SW_RING-1)].x;
-          if (havep) pbeg = bgp;
+          const bool fin = (blocked && !need) || havep;
           bopen = actb && !fin && y == loR && loR > 0;       // the window may go on below the ring
         }
 #endif
