@@ -107,6 +107,9 @@ __shared__ cp_seedw_lds sw_S;                    // the wave's LDS block (one wa
 #endif
 
 __device__ __forceinline__ int sw_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// the value of the lane below (lane 0: `first`), as a DPP move (wave_shr:1) instead of a round trip through the LDS crossbar
+__device__ __forceinline__ int sw_from_below(int v, int first) { return __builtin_amdgcn_update_dpp(first,v,0x138,0xf,0xf,false); }
+__device__ __forceinline__ int sw_of_last(int v) { return __builtin_amdgcn_readlane(v,WAVE-1); }
 // (the pointer is rebuilt as a GLOBAL one: out of an integer it would be a flat pointer, whose loads and stores count on
 //  both memory counters and wait for each other)
 template <class T> __device__ __forceinline__ T *sw_first_ptr(T *p)
@@ -512,9 +515,8 @@ __device__ __attribute__((noinline)) void sw_segments(int C_, int nrep_, int rep
           { const int c0 = e0+u*WAVE, p = c0+lane;
             if (c0 >= plen) break;
             const bool in = p < plen;
-            int cpv = __shfl_up(cnt[u],1);
-            if (lane == 0) cpv = prevc;
-            prevc = __shfl(cnt[u],WAVE-1);
+            const int cpv = sw_from_below(cnt[u],prevc);
+            prevc = sw_of_last(cnt[u]);
             uint64_t rmask = ~0ull;
             if (rep)                                         // the chunk's k-mers inside repetitive stretches (scalar: the stretches are sorted)
               { rmask = 0;
@@ -1080,9 +1082,9 @@ __device__ __forceinline__ int sw_find_seeds(const cp_seedw_read &R, int lane SW
   // (four chunks of 64 labels per step, their loads issued together: chunk by chunk the loop was one HBM round trip per
   //  64 positions with nothing to do in between -- 12 % of the kernel's time for 3 % of its instructions)
   constexpr int AN = 4;
+  char cprev = 0;                                            // the label before the chunk (carried from chunk to chunk)
   for (int e0 = 0; e0 < plen; e0 += AN*WAVE)
     { char cc[AN];
-      char cprev = (e0 > 0 && lane == 0) ? R.cls[e0-1] : (char)0;
 #pragma unroll
       for (int u = 0; u < AN; u++)
         { const int p = e0+u*WAVE+lane;
@@ -1094,9 +1096,8 @@ __device__ __forceinline__ int sw_find_seeds(const cp_seedw_read &R, int lane SW
           if (c0 >= plen) break;
           const bool in = p < plen;
           const char c = cc[u];
-          int cpi = __shfl_up((int)c,1);
-          if (lane == 0) cpi = (int)cprev;
-          cprev = (char)__shfl((int)c,WAVE-1);               // (lane 0 uses it for the next chunk)
+          const int cpi = sw_from_below((int)c,(int)cprev);
+          cprev = (char)sw_of_last((int)c);                  // (the next chunk's lane 0 uses it)
           const uint64_t sm = __ballot(in && (p == 0 || (int)c != cpi));
           if (sm == 0) continue;
           __syncthreads();
