@@ -515,7 +515,7 @@ __device__ __attribute__((noinline)) void sw_segments(int C_, int nrep_, int rep
           { const int c0 = e0+u*WAVE, p = c0+lane;
             if (c0 >= plen) break;
             const bool in = p < plen;
-            const int cpv = sw_from_below(cnt[u],prevc);
+            const int prevc0 = prevc;
             prevc = sw_of_last(cnt[u]);
             uint64_t rmask = ~0ull;
             if (rep)                                         // the chunk's k-mers inside repetitive stretches (scalar: the stretches are sorted)
@@ -528,10 +528,15 @@ __device__ __attribute__((noinline)) void sw_segments(int C_, int nrep_, int rep
                     if (re <= c0+WAVE) ri++; else break;
                   }
               }
-            const bool bnd = in && cnt[u] != cpv;
             const bool v = in && (rep ? (cl[u] != 'E' && st[u] == 'E' && ((rmask >> lane) & 1)) : cl[u] == (char)C);
+            const uint64_t vm = __ballot(v);
+            // 64 k-mers without a valid one, entered by a run that holds none: no segment starts here and nothing carries
+            // over (hv = 0 below) -- most chunks of the H and of the repeat selection
+            if (vm == 0 && !carry && c0 != 0) continue;
+            const int cpv = sw_from_below(cnt[u],prevc0);
+            const bool bnd = in && cnt[u] != cpv;
             const uint64_t inm = plen-c0 >= WAVE ? ~0ull : ((1ull << (plen-c0))-1);
-            const uint64_t bm = __ballot(bnd), vm = __ballot(v);
+            const uint64_t bm = __ballot(bnd);
             // hv: the run of a k-mer holds a valid k-mer at or before it -- a segmented OR-scan of vm over the runs that
             // start at bm, by ONE addition: X marks the k-mers whose successor belongs to the same run; adding a valid
             // k-mer's bit to X sends a carry up through the rest of its run, which flips those bits of X and sets the run's
