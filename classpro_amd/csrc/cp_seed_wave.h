@@ -48,6 +48,10 @@
 #define SW_LEV   7                               // levels of the range-maximum table: blocks of 1 .. 64 segments
 #endif
 #define SW_TOPB  (SW_RING >> (SW_LEV-1))          // blocks of the largest size that cover the ring
+#define SW_SORTW 512                             // window counts (keys) put in order by one round of the sort
+#ifndef SW_SORTN
+#define SW_SORTN (1 << 30)                       // ... or ends at the key that brings it to this many segments (see sw_sort_range: not worth it)
+#endif
 #ifndef SW_MI
 #define SW_MI    128
 #endif
@@ -80,12 +84,13 @@ struct cp_seedw_lds
             int32_t  bins[32];
             int32_t  pend_b[SW_PEND], pend_e[SW_PEND];
           };
+        int32_t sbins[SW_SORTW];                 // the sort's counters, one per window count of the range being put in order
       };
     int32_t  mi_b[SW_MI], mi_e[SW_MI];           // masked-interval list while it fits
     int32_t  rep[2*SW_REP];                      // repetitive stretches in k-mer coordinates while they fit
     cp_seedw_read R;                             // the read (the selections are calls: what they share travels through here)
     int32_t  lm_big;                             // the masked-interval list has moved to the read's HBM scratch
-    int32_t  sel[8];                             // what the phases of a selection hand to each other (SEL_*)
+    int32_t  sel[12];                            // what the phases of a selection hand to each other (SEL_*)
   };
 static_assert(offsetof(cp_seedw_lds,rkeyk) == offsetof(cp_seedw_lds,rkey)+SW_RING*sizeof(int16_t),"the levels of the range-maximum table are one array");
 
@@ -309,7 +314,7 @@ __device__ const sw_code_tab sw_CODE = sw_make_codes();
 // the k-mer's bases come in with four 16-byte loads issued together (a byte load per step made the 40 steps 40 memory
 // round trips); `rlen` bounds them: a k-mer within 64 bases of the read's end is read byte by byte.  `rot` / `code`: the
 // two tables (sw_ROT, sw_CODE) -- sw_mark_all passes its on-chip copies.
-template <class ROT, class CODE>
+template <int STRIDE, class ROT, class CODE>
 __device__ __forceinline__ int sw_hash_at(const char *seq, int j, int K, int rlen, const ROT rot, const CODE code_of)
 { if (K > SW_KMAX) return cp_kmer_hash(seq,j,K);
   uint64_t fh = 0, rh = 0;
@@ -324,15 +329,15 @@ __device__ __forceinline__ int sw_hash_at(const char *seq, int j, int K, int rle
       for (int t = 0; t < SW_KMAX; t++)
         if (t < K)
           { const int code = code_of[(w[t >> 2] >> (8*(t & 3))) & 0xff];
-            fh ^= rot[(code & 7)*SW_KMAX+(K-1-t)];
-            rh ^= rot[(code >> 3)*SW_KMAX+t];
+            fh ^= rot[(code & 7)*STRIDE+(K-1-t)];
+            rh ^= rot[(code >> 3)*STRIDE+t];
           }
     }
   else
     for (int t = 0; t < K; t++)
       { const int code = code_of[(unsigned char)seq[j+t]];
-        fh ^= rot[(code & 7)*SW_KMAX+(K-1-t)];
-        rh ^= rot[(code >> 3)*SW_KMAX+t];
+        fh ^= rot[(code & 7)*STRIDE+(K-1-t)];
+        rh ^= rot[(code >> 3)*STRIDE+t];
       }
   return (int)((rh < fh ? rh : fh) % CP_SEED_MOD);
 }
@@ -350,13 +355,16 @@ __device__ __attribute__((noinline)) void sw_mark_all(const char *seq, const cha
   if (ntake == 0) return;
   int32_t *s_pre = sw_S.pend_b, *s_min = sw_S.pend_e;        // (the pending-take buffers are idle here; SW_PEND >= 64)
   static_assert(SW_PEND >= WAVE,"one slot per segment of a round");
-  static_assert(sizeof(sw_S.rbp)+sizeof(sw_S.rkey) >= sizeof(sw_rot_tab) && offsetof(cp_seedw_lds,rkey) == sizeof(sw_S.rbp),
-                "the rotated seeds fit the ring");
-  static_assert(sizeof(sw_S.cval) >= sizeof(sw_code_tab),"the letter classes fit the take buffer");
+  // (a table row per base class, 65 entries apart: 64 apart the five rows start in the same LDS bank and the lanes' reads
+  //  of one step -- same column, one of five rows -- went through it one after the other)
+  static_assert(offsetof(cp_seedw_lds,rkey) == sizeof(sw_S.rbp) && offsetof(cp_seedw_lds,cval) == offsetof(cp_seedw_lds,rkey)+sizeof(sw_S.rkey)
+                && sizeof(sw_S.rbp)+sizeof(sw_S.rkey)+sizeof(sw_S.cval)/2 >= 5*(SW_KMAX+1)*sizeof(uint64_t),
+                "the rotated seeds fit the ring and the first half of the take buffer");
+  static_assert(sizeof(sw_S.cval)/2 >= sizeof(sw_code_tab),"the letter classes fit the second half of the take buffer");
   uint64_t *lrot = reinterpret_cast<uint64_t *>(&sw_S.rbp[0]);
-  uint8_t *lcode = reinterpret_cast<uint8_t *>(&sw_S.cval[0]);
+  uint8_t *lcode = reinterpret_cast<uint8_t *>(&sw_S.cval[SW_STEP*WAVE/2]);
   __syncthreads();
-  for (int q = lane; q < 5*SW_KMAX; q += WAVE) lrot[q] = sw_ROT.v[q];
+  for (int q = lane; q < 5*SW_KMAX; q += WAVE) lrot[(q/SW_KMAX)*(SW_KMAX+1)+q%SW_KMAX] = sw_ROT.v[q];
   for (int q = lane; q < 256/4; q += WAVE) reinterpret_cast<uint32_t *>(lcode)[q] = reinterpret_cast<const uint32_t *>(sw_CODE.v)[q];
   __syncthreads();
   constexpr int KEEP = 4;
@@ -389,7 +397,7 @@ __device__ __attribute__((noinline)) void sw_mark_all(const char *seq, const cha
                   int lo = 0, j = 0;
                   locate(on ? q : 0,lo,j);
                   if (on)
-                    { hk[u] = sw_hash_at(seq,j,K,rlen,lrot,lcode); jk[u] = j; lk[u] = lo;
+                    { hk[u] = sw_hash_at<SW_KMAX+1>(seq,j,K,rlen,lrot,lcode); jk[u] = j; lk[u] = lo;
                       atomicMin(&s_min[lo],hk[u]);
                     }
                 }
@@ -409,7 +417,7 @@ __device__ __attribute__((noinline)) void sw_mark_all(const char *seq, const cha
               int lo = 0, j = 0;
               locate(on ? q : 0,lo,j);
               if (on)
-                { const int h = sw_hash_at(seq,j,K,rlen,lrot,lcode);
+                { const int h = sw_hash_at<SW_KMAX+1>(seq,j,K,rlen,lrot,lcode);
                   if (pass == 0) atomicMin(&s_min[lo],h);
                   else if (h == s_min[lo]) state[j] = rep ? 'R' : cls[j];
                 }
@@ -454,7 +462,8 @@ __device__ __forceinline__ cp_seedw_read sw_the_read()
   R.err = sw_first_ptr(sw_S.R.err); R.dbg_read = sw_first(sw_S.R.dbg_read);
   return R;
 }
-enum { SEL_N = 0, SEL_M, SEL_NBIG, SEL_BLAST, SEL_STOP };    // sw_S.sel[]: valid segments, skipped stretches (list slots), counts > 1000, begin of the last segment, selection over
+enum { SEL_N = 0, SEL_M, SEL_NBIG, SEL_BLAST, SEL_STOP,      // sw_S.sel[]: valid segments, skipped stretches (list slots), counts > 1000, begin of the last segment, selection over
+       SEL_NSORTED, SEL_NEXTKEY, SEL_POS, SEL_NTAKE, SEL_MORE }; // segments in order so far, first key not yet in order; the walk's place, its takes, "put more in order"
 __device__ __forceinline__ sw_list sw_the_list(const cp_seedw_read &R)
 { sw_list Lm; Lm.gb = R.gmi_b; Lm.ge = R.gmi_e; Lm.big = sw_first(sw_S.lm_big) != 0; return Lm; }
 __device__ __forceinline__ int sw_sel(int k) { return sw_first(sw_S.sel[k]); }
@@ -841,6 +850,89 @@ __device__ __attribute__((noinline)) void sw_windows(int lane SW_PROF_ARGS)
   __syncthreads();
 }
 
+// ---- the order of the walk: decreasing window count, segments of equal count in position order (the reference's qsort is
+//      glibc's stable merge sort).  Key = 1000 - count (counts above 1000 share key 0, the skipped stretches, -10, come
+//      last).  A round puts the segments of the next SW_SORTW keys in order behind those ordered so far: counters per key
+//      in LDS, their prefix sums, then a stable scatter of the range's segments -- ranks among the 64 of a step from
+//      ballots over the key's bits; the walk goes on from there and asks for the next round when it runs out (two rounds
+//      cover all keys).  (Two 5-bit radix passes over all segments with an index array in between before: 3.4 ms of the
+//      kernel's 23.)  A round can also end early, at the key that brings it to SW_SORTN segments (a group of equal counts
+//      is never cut) -- in the hope that the walk stops long before the last segment.  It does not: a read is seldom
+//      covered before its last groups, every round costs a pass over all segments, and 128 / 256 / 512 / 1024 / all
+//      segments per round take 25.4 / 23.7 / 22.9 / 22.3 / 22.1 ms on the 60x set -- so a round takes all its keys. ----
+__device__ __forceinline__ int sw_sort_key(int nw) { return nw > 1000 ? 0 : 1000-nw; }
+__device__ __forceinline__ void sw_sort_range(const cp_seedw_read &R, int n, int nbig, int lane)
+{ const uint64_t lt = (1ull << lane)-1;
+  const int lo = sw_sel(SEL_NEXTKEY), base = sw_sel(SEL_NSORTED);
+  constexpr int PER = SW_SORTW/WAVE;                         // counters per lane
+  __syncthreads();
+  for (int q = lane; q < SW_SORTW; q += WAVE) sw_S.sbins[q] = 0;
+  __syncthreads();
+  for (int q = lane; q < n; q += WAVE)
+    { const int d = sw_sort_key(R.rec[q].z)-lo;
+      if (d >= 0 && d < SW_SORTW) atomicAdd(&sw_S.sbins[d],1);
+    }
+  __syncthreads();
+  // the range ends at the first key whose running total reaches SW_SORTN (else with the window); exclusive prefix sums
+  int c[PER], tot = 0;
+#pragma unroll
+  for (int u = 0; u < PER; u++) { c[u] = sw_S.sbins[PER*lane+u]; tot += c[u]; }
+  int incl = tot;
+  for (int o = 1; o < WAVE; o <<= 1) { const int x = __shfl_up(incl,o); if (lane >= o) incl += x; }
+  int run = incl-tot, dend = -1, cend = 0;                   // this lane's first key that reaches the target, the total up to it
+#pragma unroll
+  for (int u = 0; u < PER; u++)
+    { const int ex = run;
+      run += c[u];
+      if (dend < 0 && run >= SW_SORTN) { dend = PER*lane+u; cend = run; }
+      c[u] = ex;
+    }
+  const uint64_t hit = __ballot(dend >= 0);
+  int hi = SW_SORTW-1, cnt = __shfl(incl,WAVE-1);
+  if (hit) { const int src = __ffsll((long long)hit)-1; hi = __shfl(dend,src); cnt = __shfl(cend,src); }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < PER; u++) sw_S.sbins[PER*lane+u] = c[u];
+  __syncthreads();
+  const int nbits = hi > 0 ? 32-__clz(hi) : 0;
+  for (int q0 = 0; q0 < n && cnt > 0; q0 += WAVE)
+    { const int q = q0+lane;
+      int4 t = make_int4(0,0,0,0);
+      int d = -1;
+      if (q < n) { t = R.rec[q]; d = sw_sort_key(t.z)-lo; }
+      const bool part = d >= 0 && d <= hi;
+      uint64_t peers = __ballot(part);
+      if (peers == 0) continue;
+      for (int bit = 0; bit < nbits; bit++)
+        { const uint64_t bmk = __ballot(part && ((d >> bit) & 1));
+          peers &= ((d >> bit) & 1) ? bmk : ~bmk;
+        }
+      const int rank = __popcll(peers & lt);
+      int dst = 0;
+      if (part) dst = base+sw_S.sbins[d]+rank;
+      __syncthreads();
+      if (part && rank == 0) sw_S.sbins[d] += __popcll(peers);
+      __syncthreads();
+      if (part) R.orec[dst] = t;
+    }
+  __syncthreads();
+  if (nbig > 0 && lo == 0)                                   // counts above 1000 share the first key with 1000: that head is put
+    { if (lane == 0)                                         // in order by insertion (rare, short)
+        { int m = 0;
+          while (m < cnt && R.orec[m].z >= 1000) m++;
+          for (int a = 1; a < m; a++)
+            { const int4 x = R.orec[a];
+              int j = a-1;
+              while (j >= 0 && R.orec[j].z < x.z) { R.orec[j+1] = R.orec[j]; j--; }
+              R.orec[j+1] = x;
+            }
+        }
+      __syncthreads();
+    }
+  if (lane == 0) { sw_S.sel[SEL_NSORTED] = base+cnt; sw_S.sel[SEL_NEXTKEY] = lo+hi+1; }
+  __syncthreads();
+}
+
 __device__ __attribute__((noinline)) void sw_sort(int rep_, int lane SW_PROF_ARGS)
 { const cp_seedw_read R = sw_the_read();
   const sw_list Lm = sw_the_list(R);
@@ -870,61 +962,17 @@ __device__ __attribute__((noinline)) void sw_sort(int rep_, int lane SW_PROF_ARG
   if (CP_SEED_STOP_AT == 2) { sw_sel_put(lane,n,M,nbig,0,1,Lm.big); return; }
 #endif
   if (M > 0 && Lm.b(0) == 0 && Lm.e(0) == plen) { sw_sel_put(lane,n,M,nbig,0,1,Lm.big); return; }
-  // ---- stable order by decreasing window count (the reference's qsort is glibc's stable merge sort): two 5-bit radix
-  //      passes on 1000 - count (the skipped stretches, -10, come last), ranks from ballots ----
-  for (int pass = 0; pass < 2; pass++)
-    { if (lane < 32) sw_S.bins[lane] = 0;
-      __syncthreads();
-      for (int q = lane; q < n; q += WAVE)
-        { const int nw = R.rec[pass ? R.tmp[q] : q].z;
-          atomicAdd(&sw_S.bins[((nw > 1000 ? 0 : 1000-nw) >> (5*pass)) & 31],1);
-        }
-      __syncthreads();
-      { int c = lane < 32 ? sw_S.bins[lane] : 0, incl = c;
-        for (int o = 1; o < 32; o <<= 1) { const int x = __shfl_up(incl,o); if (lane >= o) incl += x; }
-        __syncthreads();
-        if (lane < 32) sw_S.bins[lane] = incl-c;
-      }
-      __syncthreads();
-      for (int base = 0; base < n; base += WAVE)
-        { const int q = base+lane;
-          const bool act = q < n;
-          int i = 0, dg = 0;
-          int4 t = make_int4(0,0,0,0);
-          if (act) { i = pass ? R.tmp[q] : q; t = R.rec[i]; dg = ((t.z > 1000 ? 0 : 1000-t.z) >> (5*pass)) & 31; }
-          uint64_t peers = __ballot(act);
-          for (int bit = 0; bit < 5; bit++)
-            { const uint64_t bmk = __ballot(act && ((dg >> bit) & 1));
-              peers &= ((dg >> bit) & 1) ? bmk : ~bmk;
-            }
-          const int rank = __popcll(peers & lt);
-          int d = 0;
-          if (act) d = sw_S.bins[dg]+rank;
-          __syncthreads();
-          if (act && rank == 0) sw_S.bins[dg] += __popcll(peers);
-          __syncthreads();
-          if (act)
-            { if (pass == 0) R.tmp[d] = i;
-              else R.orec[d] = t;
-            }
-        }
-      __syncthreads();
-    }
-  if (nbig > 0)                                              // counts above 1000 share the first key with 1000: that head is put
-    { if (lane == 0)                                         // in order by insertion (rare, short)
-        { int m = 0;
-          while (m < n && R.orec[m].z >= 1000) m++;
-          for (int a = 1; a < m; a++)
-            { const int4 x = R.orec[a];
-              int j = a-1;
-              while (j >= 0 && R.orec[j].z < x.z) { R.orec[j+1] = R.orec[j]; j--; }
-              R.orec[j+1] = x;
-            }
-        }
-      __syncthreads();
-    }
-  SW_STAMP(2);
+  __syncthreads();
+  if (lane == 0) { sw_S.sel[SEL_NSORTED] = 0; sw_S.sel[SEL_NEXTKEY] = 0; sw_S.sel[SEL_POS] = 0; sw_S.sel[SEL_NTAKE] = 0; sw_S.sel[SEL_MORE] = 0; }
   sw_sel_put(lane,n,M,nbig,0,0,Lm.big);
+  sw_sort_range(R,n,nbig,lane);
+  SW_STAMP(2);
+}
+// (the walk ran out of ordered segments with the read still uncovered)
+__device__ __attribute__((noinline)) void sw_sort_more(int lane SW_PROF_ARGS)
+{ const cp_seedw_read R = sw_the_read();
+  sw_sort_range(R,sw_sel(SEL_N),0,lane);
+  SW_STAMP(2);
 }
 
 template <bool rep>
@@ -934,14 +982,14 @@ __device__ __attribute__((noinline)) void sw_walk(int lane SW_PROF_ARGS)
   const int W = rep ? CP_SEED_W_REP : CP_SEED_W;
   const int plen = R.plen, Km1 = R.K-1;
   const uint64_t lt = (1ull << lane)-1;
-  const int n = sw_sel(SEL_N);
+  const int ntot = sw_sel(SEL_N), n = sw_sel(SEL_NSORTED);   // segments in all, segments put in order so far (sw_sort_range)
   int M = sw_sel(SEL_M);
   const bool was_big = Lm.big;
   // ---- selection (wave-uniform control flow) ----
   // taken segments are listed in R.tmp (idle after the sort) and marked at the end; the list is written 64 takes at a
   // time from an LDS buffer (cval), so that the list update of a take -- a chain of wave barriers -- never waits for a
   // global store of the take before it
-  int ntake = 0, nbuf = 0;
+  int ntake = sw_sel(SEL_NTAKE), nbuf = 0;
   auto flush_takes = [&]()
     { __syncthreads();
       for (int q = lane; q < 2*nbuf; q += WAVE) R.tmp[2*(ntake-nbuf)+q] = sw_S.cval[q];
@@ -961,7 +1009,7 @@ __device__ __attribute__((noinline)) void sw_walk(int lane SW_PROF_ARGS)
           sw_mark(R.seq,R.cls,R.state,plen+Km1,R.K,b,e,rep,lane);
         }
     };
-  int pos = 0;
+  int pos = sw_sel(SEL_POS);
   for (; pos < n; pos++)                                     // every segment that is extreme over a whole window
     { const int4 t = R.orec[pos];
       if (t.z < W) break;
@@ -1023,6 +1071,15 @@ __device__ __attribute__((noinline)) void sw_walk(int lane SW_PROF_ARGS)
   SW_STAMP(4);
   SW_STOP(5);
   flush_takes();                                             // the list of taken segments is complete and visible to the wave
+  if (!covered && n < ntot)                                  // out of ordered segments: the next range of counts, then on from here
+    { if (lane == 0)
+        { sw_S.sel[SEL_M] = M; sw_S.sel[SEL_POS] = pos; sw_S.sel[SEL_NTAKE] = ntake; sw_S.sel[SEL_MORE] = 1;
+          sw_S.lm_big = Lm.big ? 1 : 0;
+        }
+      __syncthreads();
+      return;
+    }
+  if (lane == 0) sw_S.sel[SEL_MORE] = 0;
 #ifdef CP_SEED_DEBUG_TAKES
   if (R.dbg_read && rep)
     { int *d = (int *)g_seed_dbg;
@@ -1055,7 +1112,11 @@ __device__ __forceinline__ void sw_select(int C, int nrep, int rep_big, int lane
   sw_sort(rep ? 1 : 0,lane SW_PROF_PASS);
   SW_STOP(3);
   if (sw_sel(SEL_STOP)) return;
-  sw_walk<rep>(lane SW_PROF_PASS);
+  for (;;)
+    { sw_walk<rep>(lane SW_PROF_PASS);
+      if (!sw_sel(SEL_MORE)) break;
+      sw_sort_more(lane SW_PROF_PASS);
+    }
 }
 
 // ---- the whole path for one read.  R.state holds 'E' at every k-mer on entry.  Returns the number of .rep intervals
