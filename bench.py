@@ -482,12 +482,18 @@ def extra_rates(a, ds, clf, batches, hcov, dcov, dev, stream):
                            d_lab=torch.empty_like(bm.labels), d_plab=torch.empty(npk, dtype=torch.uint8, device=dev),
                            h_plab=torch.empty(npk, dtype=torch.uint8).pin_memory()))
 
-        def run2(nb):
-            for i in range(nb):
-                q = sl[i % NS]
-                q["st"].synchronize()
-                with torch.cuda.stream(q["st"]):
-                    sp = C.c_void_p(q["st"].cuda_stream)
+        # one host thread per slot, as the command line has one feeder per device slot: cp_classify_batch blocks its caller
+        # once per batch (the scratch sizes come back from the device), and with a single caller the next batch's H2D
+        # copies were not even queued during that wait
+        import threading
+
+        def slot_batches(k, nb):
+            q = sl[k]
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(q["st"]):
+                sp = C.c_void_p(q["st"].cuda_stream)
+                for _ in range(nb):
+                    q["st"].synchronize()
                     q["d_pk"].copy_(h_pk, non_blocking=True)
                     q["d_code"].copy_(h_code, non_blocking=True)
                     check(L.cp_unpack_bases(q["d_pk"].data_ptr(), d_pko.data_ptr(), bm.seq_off.data_ptr(), bm.nreads, q["d_seq"].data_ptr(), sp))
@@ -497,7 +503,24 @@ def extra_rates(a, ds, clf, batches, hcov, dcov, dev, stream):
                                               bm.prof_off.data_ptr(), bm.nreads, bm.total_bases, bm.total_kmers, q["d_lab"].data_ptr(), sp))
                     check(L.cp_pack_labels(q["d_lab"].data_ptr(), bm.seq_off.data_ptr(), d_pko.data_ptr(), bm.nreads, q["d_plab"].data_ptr(), sp))
                     q["h_plab"].copy_(q["d_plab"], non_blocking=True)
+                q["st"].synchronize()
+
+        def run2(nb):
+            errs = []
+
+            def guarded(k):
+                try:
+                    slot_batches(k, nb // NS)
+                except Exception as e:     # noqa: BLE001
+                    errs.append(e)
+            th = [threading.Thread(target=guarded, args=(k,)) for k in range(NS)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
             torch.cuda.synchronize()
+            if errs:
+                raise errs[0]
         run2(NS)
         t0 = time.perf_counter()
         run2(12)

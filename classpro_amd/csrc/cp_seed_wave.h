@@ -56,7 +56,9 @@
 #define SW_MI    128
 #endif
 #define SW_PEND  64
+#ifndef SW_REP
 #define SW_REP   64
+#endif
 #define SW_KMAX  64                              // k-mer lengths served by the rotated-seed table (longer: byte-wise fold)
 #ifndef SW_STEP
 #define SW_STEP  2                               // chunks of 64 positions per load step (4: 57.6 ms against 55.6)
