@@ -502,7 +502,7 @@ __device__ __forceinline__ int wave_sort_ev(fw_evl &ev, int n, cp_eintvl *tmp, b
 // wall.c:722-731 / 868-872: clear WALL_O at every position strictly inside one of the E-intervals ev[lo..hi).
 // OTHERS walls only exist at candidate positions, so the lanes test the candidates instead of sweeping
 // the flag array once per interval (an HBM list: the interval ends are staged in sbuf, 2*scap ints, when they fit).
-__device__ void wave_unwall_inside(uint8_t *wall, const int32_t *clist, int n_c, const fw_evl &ev, int lo, int hi,
+__device__ __forceinline__ void wave_unwall_inside(uint8_t *wall, const int32_t *clist, int n_c, const fw_evl &ev, int lo, int hi,
                                    int *sbuf, int scap)
 { const int lane = lane_id();
   const int n = hi-lo;
@@ -536,7 +536,7 @@ __device__ void wave_unwall_inside(uint8_t *wall, const int32_t *clist, int n_c,
 // kind, or the read boundary) and the first OTHERS wall, where the walk ends; the picked positions are
 // then handled in order by all lanes together (same values everywhere, stores by lane 0).
 template <class RD>
-__device__ void wave_wall_mult(RD *R, int i, int NS, int *midx)
+__device__ __forceinline__ void wave_wall_mult(RD *R, int i, int NS, int *midx)
 { const int lane = lane_id();
   uint8_t *wall = R->wall;
   const uint8_t *wall_s = R->wall_s;
@@ -623,7 +623,7 @@ __device__ __forceinline__ int cf_find(const fw_cflags &F, int x)        // inde
 }
 
 // wall.c:722-731 / 868-872 on the on-chip flags
-__device__ void cf_unwall_inside(const fw_cflags &F, const fw_evl &ev, int lo, int hi)
+__device__ __forceinline__ void cf_unwall_inside(const fw_cflags &F, const fw_evl &ev, int lo, int hi)
 { if (hi <= lo) return;
   for (int q = lane_id(); q < F.n; q += WAVE)
     if (F.fo[q] & CP_W_WALL_O)
@@ -640,7 +640,7 @@ __device__ void cf_unwall_inside(const fw_cflags &F, const fw_evl &ev, int lo, i
 // within 200 positions are the flagged candidates after (DROP) / before (GAIN) q, 64 of them per step, in order; the read's
 // boundary (plen / 0), when it lies within reach, comes last.  Same values on every lane, stores by lane 0.
 template <class RD>
-__device__ void cf_wall_mult(RD *R, const fw_cflags &F, int q, int NS, int *midx)
+__device__ __forceinline__ void cf_wall_mult(RD *R, const fw_cflags &F, int q, int NS, int *midx)
 { const int lane = lane_id();
   const int plen = R->plen, i = F.pos[q];
   fw_evl &ev = R->eintvl;
@@ -854,7 +854,8 @@ k_wall_tasks(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, 
           f1 = cp_wall_candidate_filter(P,CP_OTHERS,pre);
           cinfo[base+lane] = pre.maxt*32+pre.maxl+(f0 << 8)+(f1 << 12);
           ccnt[base+lane] = (int)R.prof[i-1] | ((int)R.prof[i] << 16);
-          if (f1 & CP_CF_WALLNOW) wall[i] = CP_W_WALL_O;   // ahead of the replay, see cp_read_t::spec_wallnow
+          // (a candidate that is an OTHERS wall whatever the replay finds -- CP_CF_WALLNOW in f1 -- gets its flag from
+          //  k_find_wall, which knows whether the read's flags live on chip or in the flag array)
         }
       const int l0 = (f0 & CP_CF_LIVE) ? 1 : 0, l1 = (f1 & CP_CF_LIVE) ? 1 : 0;
       int c = l0+l1, off = c;
@@ -980,9 +981,30 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   //    where the one-lane replay took 64 steps.  E-/O-intervals are appended after the rounds, in task order (ballots).
   //    The memo tables take concurrent inserts of DIFFERENT keys (compare-and-swap on the key slot); tasks of one round
   //    never share a position.  A read whose memo does not fit on chip takes the one-lane replay below.
+  // The candidates' flag bytes ON CHIP from the start (fw_cflags: positions, OTHERS flags, SELF flags in the front of the
+  // staging block): every cell the walk writes is a candidate's or a partner's, and a partner is nearly always a candidate
+  // itself.  The read's flags then never exist in HBM: no cold read-modify-write per flag of the replay, none of the
+  // clean-up stores that keep the flag arrays zero between batches (together 2/3 of this kernel's write traffic), and
+  // k_wall_tasks writes no flag either.  A read whose walk pairs a position that is no candidate (a boundary, a partner
+  // below the scan's threshold) starts over with its flags in the arrays.
+  int *sbuf = reinterpret_cast<int *>(s_res);
+  constexpr int SBUF = (int)(sizeof(task_res)*WAVE/sizeof(int));      // 512 ints
+  constexpr int SCOMP = 64;                             // components of the error regions kept on chip
+  constexpr int U16 = 2*(SBUF-2*SCOMP);                 // 16-bit list slots in front of the component arrays
+  uint16_t *s16 = reinterpret_cast<uint16_t *>(sbuf);
+  fw_cflags F;
+  F.pos = s16; F.fo = reinterpret_cast<uint8_t *>(s16+n_c); F.fs = F.fo+n_c; F.n = n_c;
+  constexpr int NDEP = 128;                             // slots of the dependency table (behind the flags: the block's second half)
+  static_assert(sizeof(task_res)*WAVE >= 4*256+NDEP*sizeof(unsigned long long),"flags of 255 candidates and the dependency masks fit the staging block");
+  bool onchip = R.perror.use_lds == 3 && plen <= 65535 && n_c <= 255 && 3*n_c+2*SCOMP+1 <= U16 && !R.eintvl.big;
+  const int32_t *cinfo = wl;
+  auto flags_to_hbm = [&]()                             // the flags k_wall_tasks knew: OTHERS walls whatever the replay finds (cp_read_t::spec_wallnow)
+    { for (int q = lane; q < n_c; q += WAVE)
+        if ((cinfo[q] >> 12) & CP_CF_WALLNOW) wall[clist[q]] = CP_W_WALL_O;
+      wave_sync();
+    };
   if (R.perror.use_lds == 3)
-    { unsigned long long *s_dep = reinterpret_cast<unsigned long long *>(s_res);    // 256 slots (the task results stay in registers here)
-      static_assert(sizeof(task_res)*WAVE >= 256*sizeof(unsigned long long),"dependency masks fit the staging block");
+    { unsigned long long *s_dep = reinterpret_cast<unsigned long long *>(s_res)+(sizeof(task_res)*WAVE/sizeof(unsigned long long)-NDEP);
       const uint64_t ltm = (1ull << lane)-1;
       const int ecap = R.ecap;
       const bool ebig = R.eintvl.big != 0;
@@ -1003,101 +1025,134 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
             }
           return off+(int)h;
         };
-      for (int tb = 0; tb < n_t; tb += WAVE)
-        { const int nb = (n_t-tb < WAVE) ? n_t-tb : WAVE;
-          bool open = lane < nb;
-          int pos = 1, e = 0, w = 0, lc_j = -1, lc_kind = CP_LC_NONE, hc_j = -1;
-          double own_pe = 0., lc_v = 0., hc_pe = 0.;
-          if (open)
-            { const int code = tlist[tb+lane], k = code >> 1, cc = ccnt[k];
-              const task_res q = tres[tb+lane];
-              pos = clist[k]; e = code & 1;
-              w = (cc & 0xffff) > ((cc >> 16) & 0xffff) ? CP_DROP : CP_GAIN;
-              own_pe = q.own_pe; lc_v = q.lc_v; hc_pe = q.hc_pe;
-              lc_j = q.lc_j; lc_kind = q.hc & 3;
-              hc_j = (q.hc & 4) ? pos+(q.hc >> 16) : -1;
+      for (;;)
+        { if (onchip)
+            { for (int q = lane; q < n_c; q += WAVE)
+                { F.pos[q] = (uint16_t)clist[q]; F.fo[q] = ((cinfo[q] >> 12) & CP_CF_WALLNOW) ? CP_W_WALL_O : 0; F.fs[q] = 0; }
+              wave_sync();
             }
-          const int p1 = (lc_kind == CP_LC_PAIR || lc_kind == CP_LC_BOUNDARY) ? lc_j : -1, p2 = hc_j;
-          for (int q = lane; q < 256; q += WAVE) s_dep[q] = 0ull;
-          wave_sync();
-          const int s0 = (int)((uint32_t)(pos*2+e)*0x9E3779B1u >> 24), s1 = (int)((uint32_t)(p1*2+e)*0x9E3779B1u >> 24),
-                    s2 = (int)((uint32_t)(p2*2+e)*0x9E3779B1u >> 24);
-          if (open)
-            { atomicOr(&s_dep[s0],1ull << lane);
-              if (p1 >= 0) atomicOr(&s_dep[s1],1ull << lane);
-              if (p2 >= 0) atomicOr(&s_dep[s2],1ull << lane);
-            }
-          wave_sync();
-          uint64_t dep = 0;
-          if (open)
-            { dep = s_dep[s0];
-              if (p1 >= 0) dep |= s_dep[s1];
-              if (p2 >= 0) dep |= s_dep[s2];
-              dep &= ltm;
-            }
-          bool hasE = false, hasO = false;
-          cp_eintvl I; I.b = I.e = 0; I.pe = 0.;
-          for (uint64_t um = __ballot(open); um; um = __ballot(open))
-            { if (open && (dep & um) == 0)
-                { open = false;
-                  const uint8_t fl = (e == CP_SELF) ? R.wall_s[pos] : wall[pos];
-                  if (!(fl & (e == CP_SELF ? CP_W_PAIRED_S : CP_W_PAIRED_O)))          // wall.c:639
-                    { const int ci = memo_cell(pos,e,w);
-                      double pe_i = s_mval[ci];
-                      if (pe_i == CP_NEG_INF) { pe_i = own_pe; s_mval[ci] = pe_i; }     // update_perror(i), wall.c:310-315
-                      bool accept = false;
-                      if (pe_i >= CP_PE_THRES_FINAL && lc_kind != CP_LC_NONE)           // find_gain / find_drop, see cp_find_pair_replay
-                        { const bool right = (w == CP_DROP);
-                          int max_j = -1;
-                          double pe = CP_NEG_INF, max_pe = CP_NEG_INF;
-                          if (lc_kind == CP_LC_BOUNDARY) pe = pe_i*pe_i;
-                          else if (lc_kind == CP_LC_PAIR)
-                            { const int cj = memo_cell(lc_j,e,1-w);
-                              double pe_j = s_mval[cj];
-                              if (pe_j == CP_NEG_INF) { pe_j = lc_v; s_mval[cj] = pe_j; }
-                              pe = right ? pe_i*pe_j : pe_j*pe_i;
-                            }
-                          if (max_pe < pe) { max_j = lc_j; max_pe = pe; }
-                          if (hc_j >= 0 && max_pe < hc_pe) { max_j = hc_j; max_pe = hc_pe; }
-                          if (max_j != -1 && max_pe >= CP_PE_THRES_FINAL)
-                            { accept = true;
-                              I.b = right ? pos : max_j; I.e = right ? max_j : pos; I.pe = max_pe;
-                              if (e == CP_SELF)                                          // wall.c:655-668 (the SELF array only ever holds these two bits)
-                                { R.wall_s[I.b] = (CP_W_WALL_S|CP_W_PAIRED_S);
-                                  R.wall_s[I.e] = (CP_W_WALL_S|CP_W_PAIRED_S);
-                                  hasE = true;
-                                }
-                              else                                                       // wall.c:678-686
-                                { wall[pos] = fl | CP_W_PAIRED_O;
-                                  if (max_j > pos) wall[max_j] = CP_W_PAIRED_O;          // not reached yet: the reference has 0 there (cp_read_t::spec_wallnow)
-                                  else             wall[max_j] |= CP_W_PAIRED_O;
-                                  hasO = true;
-                                }
-                            }
-                        }
-                      if (!accept && e == CP_OTHERS) wall[pos] = fl | CP_W_WALL_O;       // wall.c:673-676,688
-                    }
+          else flags_to_hbm();
+          bool bail = false;
+          for (int tb = 0; tb < n_t && !bail; tb += WAVE)
+            { const int nb = (n_t-tb < WAVE) ? n_t-tb : WAVE;
+              bool open = lane < nb;
+              int pos = 1, kc = 0, e = 0, w = 0, lc_j = -1, lc_kind = CP_LC_NONE, hc_j = -1;
+              double own_pe = 0., lc_v = 0., hc_pe = 0.;
+              if (open)
+                { const int code = tlist[tb+lane], k = code >> 1, cc = ccnt[k];
+                  const task_res q = tres[tb+lane];
+                  pos = clist[k]; kc = k; e = code & 1;
+                  w = (cc & 0xffff) > ((cc >> 16) & 0xffff) ? CP_DROP : CP_GAIN;
+                  own_pe = q.own_pe; lc_v = q.lc_v; hc_pe = q.hc_pe;
+                  lc_j = q.lc_j; lc_kind = q.hc & 3;
+                  hc_j = (q.hc & 4) ? pos+(q.hc >> 16) : -1;
                 }
-              wave_sync();                                     // the round's flags and memo entries are visible to the next
+              const int p1 = (lc_kind == CP_LC_PAIR || lc_kind == CP_LC_BOUNDARY) ? lc_j : -1, p2 = hc_j;
+              for (int q = lane; q < NDEP; q += WAVE) s_dep[q] = 0ull;
+              wave_sync();
+              const int s0 = (int)((uint32_t)(pos*2+e)*0x9E3779B1u >> 25), s1 = (int)((uint32_t)(p1*2+e)*0x9E3779B1u >> 25),
+                        s2 = (int)((uint32_t)(p2*2+e)*0x9E3779B1u >> 25);
+              if (open)
+                { atomicOr(&s_dep[s0],1ull << lane);
+                  if (p1 >= 0) atomicOr(&s_dep[s1],1ull << lane);
+                  if (p2 >= 0) atomicOr(&s_dep[s2],1ull << lane);
+                }
+              wave_sync();
+              uint64_t dep = 0;
+              if (open)
+                { dep = s_dep[s0];
+                  if (p1 >= 0) dep |= s_dep[s1];
+                  if (p2 >= 0) dep |= s_dep[s2];
+                  dep &= ltm;
+                }
+              bool hasE = false, hasO = false, off_list = false;
+              cp_eintvl I; I.b = I.e = 0; I.pe = 0.;
+              for (uint64_t um = __ballot(open); um; um = __ballot(open))
+                { if (open && (dep & um) == 0)
+                    { open = false;
+                      const uint8_t fl = onchip ? ((e == CP_SELF) ? F.fs[kc] : F.fo[kc]) : ((e == CP_SELF) ? R.wall_s[pos] : wall[pos]);
+                      if (!(fl & (e == CP_SELF ? CP_W_PAIRED_S : CP_W_PAIRED_O)))          // wall.c:639
+                        { const int ci = memo_cell(pos,e,w);
+                          double pe_i = s_mval[ci];
+                          if (pe_i == CP_NEG_INF) { pe_i = own_pe; s_mval[ci] = pe_i; }     // update_perror(i), wall.c:310-315
+                          bool accept = false;
+                          if (pe_i >= CP_PE_THRES_FINAL && lc_kind != CP_LC_NONE)           // find_gain / find_drop, see cp_find_pair_replay
+                            { const bool right = (w == CP_DROP);
+                              int max_j = -1;
+                              double pe = CP_NEG_INF, max_pe = CP_NEG_INF;
+                              if (lc_kind == CP_LC_BOUNDARY) pe = pe_i*pe_i;
+                              else if (lc_kind == CP_LC_PAIR)
+                                { const int cj = memo_cell(lc_j,e,1-w);
+                                  double pe_j = s_mval[cj];
+                                  if (pe_j == CP_NEG_INF) { pe_j = lc_v; s_mval[cj] = pe_j; }
+                                  pe = right ? pe_i*pe_j : pe_j*pe_i;
+                                }
+                              if (max_pe < pe) { max_j = lc_j; max_pe = pe; }
+                              if (hc_j >= 0 && max_pe < hc_pe) { max_j = hc_j; max_pe = hc_pe; }
+                              if (max_j != -1 && max_pe >= CP_PE_THRES_FINAL)
+                                { accept = true;
+                                  I.b = right ? pos : max_j; I.e = right ? max_j : pos; I.pe = max_pe;
+                                  const int kj = onchip ? cf_find(F,max_j) : 0;
+                                  // A partner that is no candidate: its SELF flag would be a wall the later phases must see --
+                                  // the read starts over; its OTHERS flag nobody ever reads (a task reads the flag of its own
+                                  // position, a candidate, and the ends of O-pairs are un-walled after the walk): not kept.
+                                  if (kj < 0 && e == CP_SELF) off_list = true;
+                                  else if (e == CP_SELF)                                     // wall.c:655-668 (the SELF array only ever holds these two bits)
+                                    { if (onchip) { F.fs[kc] = (CP_W_WALL_S|CP_W_PAIRED_S); F.fs[kj] = (CP_W_WALL_S|CP_W_PAIRED_S); }
+                                      else { R.wall_s[I.b] = (CP_W_WALL_S|CP_W_PAIRED_S); R.wall_s[I.e] = (CP_W_WALL_S|CP_W_PAIRED_S); }
+                                      hasE = true;
+                                    }
+                                  else                                                       // wall.c:678-686
+                                    { if (onchip)
+                                        { F.fo[kc] = fl | CP_W_PAIRED_O;
+                                          if (kj < 0) { }
+                                          else if (max_j > pos) F.fo[kj] = CP_W_PAIRED_O;    // not reached yet: the reference has 0 there (cp_read_t::spec_wallnow)
+                                          else                  F.fo[kj] |= CP_W_PAIRED_O;
+                                        }
+                                      else
+                                        { wall[pos] = fl | CP_W_PAIRED_O;
+                                          if (max_j > pos) wall[max_j] = CP_W_PAIRED_O;
+                                          else             wall[max_j] |= CP_W_PAIRED_O;
+                                        }
+                                      hasO = true;
+                                    }
+                                }
+                            }
+                          if (!accept && e == CP_OTHERS)                                     // wall.c:673-676,688
+                            { if (onchip) F.fo[kc] = fl | CP_W_WALL_O; else wall[pos] = fl | CP_W_WALL_O; }
+                        }
+                    }
+                  wave_sync();                                     // the round's flags and memo entries are visible to the next
+                }
+              if (__ballot(off_list)) { bail = true; break; }
+              const uint64_t mE = __ballot(hasE), mO = __ballot(hasO);
+              if (hasE)
+                { const int sl = eidx+__popcll(mE & ltm);
+                  if (sl < ecap) { if (ebig) R.eintvl.g[sl] = I; else R.eintvl.l[sl] = I; }
+                }
+              if (hasO)
+                { const int sl = oidx+__popcll(mO & ltm);
+                  if (sl < ecap) R.ointvl.g[sl] = I;
+                }
+              eidx += __popcll(mE); oidx += __popcll(mO);
+              if (eidx > ecap) { eidx = ecap; ovf = 1; }
+              if (oidx > ecap) { oidx = ecap; ovf = 1; }
             }
-          const uint64_t mE = __ballot(hasE), mO = __ballot(hasO);
-          if (hasE)
-            { const int sl = eidx+__popcll(mE & ltm);
-              if (sl < ecap) { if (ebig) R.eintvl.g[sl] = I; else R.eintvl.l[sl] = I; }
-            }
-          if (hasO)
-            { const int sl = oidx+__popcll(mO & ltm);
-              if (sl < ecap) R.ointvl.g[sl] = I;
-            }
-          eidx += __popcll(mE); oidx += __popcll(mO);
-          if (eidx > ecap) { eidx = ecap; ovf = 1; }
-          if (oidx > ecap) { oidx = ecap; ovf = 1; }
+          wave_sync();
+          if (!bail) break;
+#ifdef CP_PROF_WALK
+          if (lane == 0) atomicAdd(&g_live_prof[6],1ull);
+#endif
+          onchip = false;                                  // once more from the start, the flags in the arrays (nothing but LDS was written)
+          eidx = oidx = ovf = 0;
+          for (int k = lane; k < LCAP0+LCAP1; k += WAVE) s_mkey[k] = -1;
+          wave_sync();
         }
-      wave_sync();
       if (lane < 2) { R.eidx = lane == 0 ? eidx : 0; R.oidx = lane == 1 ? oidx : 0; R.overflow |= ovf; }
     }
   else
   {
+  flags_to_hbm();
   // one-lane replay, 64 tasks at a time: the chunk's task results come from HBM into LDS, then the chunk is replayed in order,
   //    lane 0 taking the SELF tasks and lane 1 the OTHERS tasks (one lane active per task; position and count pair
   //    come from the loading lane's registers by readlane).
@@ -1141,11 +1196,6 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   // ---- un-wall positions explained by O-pairs / inside E-intervals (wall.c:722-731) --------
   // From here on the lists of the walk are dead except the candidate positions (clist, second quarter of
   // wl); s_res is reused for the short lists of the phases below.
-  int *sbuf = reinterpret_cast<int *>(s_res);
-  constexpr int SBUF = (int)(sizeof(task_res)*WAVE/sizeof(int));      // 512 ints
-  constexpr int SCOMP = 64;                             // components of the error regions kept on chip
-  constexpr int U16 = 2*(SBUF-2*SCOMP);                 // 16-bit list slots in front of the component arrays
-  uint16_t *s16 = reinterpret_cast<uint16_t *>(sbuf);
   int *s_cb = sbuf+SBUF-2*SCOMP, *s_ce = sbuf+SBUF-SCOMP;
   // positions fit 16 bits and the lists of this read fit the slots: O-only walls (<= n_c) during the multi-error search,
   // then the walls outside error regions (<= n_c) followed by the boundaries (<= n_c + 2*SCOMP + 1)
@@ -1153,19 +1203,26 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   R.eintvl.big = __shfl(R.eintvl.big,0);                // (the replay's lanes cannot have moved it: see above)
   // (the "paired by OTHERS" bit goes too: nothing reads it after the walk, and an O-pair partner that is no candidate
   //  must be left clean for the next batch -- the O-interval list is reused as sort scratch below)
-  if (lane == 0)
+  if (onchip)
+    { for (int k = lane; k < NO; k += WAVE)           // (pairs that share an end clear the same bits of it)
+        { const cp_eintvl o = R.ointvl.g[k];
+          const int kb = cf_find(F,o.b), ke = cf_find(F,o.e);
+          if (kb >= 0) F.fo[kb] &= (uint8_t)~(CP_W_WALL_O|CP_W_PAIRED_O);
+          if (ke >= 0) F.fo[ke] &= (uint8_t)~(CP_W_WALL_O|CP_W_PAIRED_O);
+        }
+    }
+  else if (lane == 0)
     for (int k = 0; k < NO; k++)
       { const cp_eintvl o = R.ointvl.g[k];
         wall[o.b] &= ~(CP_W_WALL_O|CP_W_PAIRED_O);
         wall[o.e] &= ~(CP_W_WALL_O|CP_W_PAIRED_O);
       }
   wave_sync();
-  // ---- the candidates' flags on chip (fw_cflags): positions in s16[0..n_c), the two flag bytes behind them, the
-  //      boundaries from s16[2*n_c) on; possible when the read's lists fit and every flagged position is a candidate ----
-  fw_cflags F;
-  F.pos = s16; F.fo = reinterpret_cast<uint8_t *>(s16+n_c); F.fs = F.fo+n_c; F.n = n_c;
-  bool cf = plen <= 65535 && n_c <= 255 && 3*n_c+2*SCOMP+1 <= U16 && !R.eintvl.big;
-  if (cf)
+  // ---- the candidates' flags on chip for the phases after the walk as well (positions in s16[0..n_c), the two flag bytes
+  //      behind them, the boundaries from s16[2*n_c) on): they are there already when the replay ran on them; a read that
+  //      replayed on the arrays copies them in when its lists fit and every flagged position is a candidate ----
+  bool cf = onchip;
+  if (!cf && plen <= 65535 && n_c <= 255 && 3*n_c+2*SCOMP+1 <= U16 && !R.eintvl.big)
     { for (int q = lane; q < n_c; q += WAVE)
         { const int i = clist[q];
           F.pos[q] = (uint16_t)i; F.fo[q] = wall[i]; F.fs[q] = wall_s[i];
@@ -1409,7 +1466,11 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   // multi-error phase wrote is a candidate position or an end of an E-interval of the final list (the ends of O-pairs
   // were cleaned above).  A read whose lists overflowed may have unrecorded cells: its whole range is cleared.
   wave_sync();
-  if (overflow)
+#ifdef CP_PROF_WALK
+  if (lane == 0) { atomicAdd(&g_live_prof[4],R.perror.use_lds == 3 ? 1ull : 0ull); atomicAdd(&g_live_prof[5],onchip ? 1ull : 0ull); atomicAdd(&g_live_prof[7],cf ? 1ull : 0ull); }
+#endif
+  if (onchip) { }                                      // (this read's flags never left the chip)
+  else if (overflow)
     { for (int j = lane; j <= plen; j += WAVE) { wall[j] = 0; R.wall_s[j] = 0; } }
   else
     { for (int q = lane; q < n_c; q += WAVE)

@@ -39,3 +39,5 @@ for k in (0, 6, 1, 2, 3, 4, 5):
     print("  %-30s %12d %12.1f      %d / %d" % (pn[k], ph[k], ph[8 + k] / b.nreads, ph[16 + k] >> 32, ph[16 + k] & 0xffffffff))
 print("inside the live-task evaluation (wave time, ticks per read): own P(error) %.0f, low-complexity partner search %.0f,"
       " its filters + P(error) %.0f, six high-complexity partners %.0f" % tuple(lv[k] / b.nreads for k in range(4)))
+print("reads %d: memo on chip %d, flags on chip to the end %d, started over with the flags in HBM %d, flags on chip after the walk %d" %
+      (b.nreads, lv[4], lv[5], lv[6], lv[7]))
