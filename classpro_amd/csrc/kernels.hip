@@ -43,6 +43,10 @@
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE-1); }
+// the value of the lane below (lane 0: `first`) as a DPP move (wave_shr:1), the last lane's value as a readlane: neither
+// goes through the LDS crossbar as __shfl_up / __shfl do
+__device__ __forceinline__ int wave_from_below(int v, int first) { return __builtin_amdgcn_update_dpp(first,v,0x138,0xf,0xf,false); }
+__device__ __forceinline__ int wave_of_last(int v) { return __builtin_amdgcn_readlane(v,WAVE-1); }
 
 // ---------------------------------------------------------------------------------------------
 //  k_scan_candidates: bit g of the bitmap <=> g >= 1, min(c[g-1],c[g]) < R and |c[g-1]-c[g]| >= 3
@@ -112,9 +116,9 @@ k_scan_candidates(const uint16_t *__restrict__ prof, int64_t total, int rep, uin
         { const bool live = g[u] < ngroups;
           // packed 16-bit arithmetic, two counts per instruction: pair k of a dword holds (count, its
           // predecessor); min < R and |difference| >= 3 become "both saturating differences non-zero"
-          unsigned before = __shfl_up(v[u].w,1);                      // the dword that ends with this lane's predecessor
-          if (lane == 0) before = carry << 16;
-          carry = __shfl(v[u].w,WAVE-1) >> 16;                        // lane 0's predecessor in the next row
+          // (DPP move / readlane; as __shfl_up / __shfl through the LDS crossbar the kernel ran at the same rate: A/B 0.64 both)
+          const unsigned before = (unsigned)wave_from_below((int)v[u].w,(int)(carry << 16));   // the dword that ends with this lane's predecessor
+          carry = (unsigned)wave_of_last((int)v[u].w) >> 16;          // lane 0's predecessor in the next row
           const unsigned w0 = scan_pair_flags(__builtin_amdgcn_alignbit(v[u].x,before,16),v[u].x,rep);
           const unsigned w1 = scan_pair_flags(__builtin_amdgcn_alignbit(v[u].y,v[u].x,16),v[u].y,rep);
           const unsigned w2 = scan_pair_flags(__builtin_amdgcn_alignbit(v[u].z,v[u].y,16),v[u].z,rep);
