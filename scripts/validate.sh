@@ -3,7 +3,7 @@
 # N > 1 path with resident windows (gloo: both ranks on the one GPU), a shard of configs[3]
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r3g; rm -rf $O; mkdir -p $O
+O=gpurun_out/validate; rm -rf $O; mkdir -p $O
 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1 || { tail -30 $O/pytest.log; exit 1; }
 tail -2 $O/pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || { tail $O/smoke.log; exit 1; }
@@ -11,13 +11,13 @@ tail -2 $O/smoke.log
 python bench.py --steps 10 --warmup 3 > $O/bench.json 2> $O/bench.err || { tail $O/bench.err; exit 1; }
 python - <<'PY'
 import json
-j=json.loads(open("gpurun_out/r3g/bench.json").read().strip().splitlines()[-1])
+j=json.loads(open("gpurun_out/validate/bench.json").read().strip().splitlines()[-1])
 print("default:", j["value"], j["ms_per_step"], j["roofline"]["frac"], j["cpu_baseline"]["value"], j["cpu_baseline"]["label_mismatches_vs_hip"])
 print({k:v for k,v in j["extras"].items() if k not in ("cli_end_to_end",)})
 PY
 python bench.py --gpus 2 --backend gloo --genome 4e8 --window-gbases 4 --steps 3 --warmup 1 > $O/n2.json 2> $O/n2.err || { tail $O/n2.err; exit 1; }
 python - <<'PY'
 import json
-j=json.loads(open("gpurun_out/r3g/n2.json").read().strip().splitlines()[-1])
+j=json.loads(open("gpurun_out/validate/n2.json").read().strip().splitlines()[-1])
 print("2 ranks (gloo, one GPU):", j["value"], j["n_gpus"], j["config"]["workload"][:200], j["extras"]["resident_windows_per_rank"])
 PY
