@@ -1953,8 +1953,10 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
 #ifndef REL_EXTRA_ATTR
 #define REL_EXTRA_ATTR
 #endif
+// (4 waves per SIMD = 128 VGPRs with 32 of them spilled to scratch, against 167 and none at 3: 192 against 186 Gbases/s on the
+//  whole bench -- what this kernel waits for is latency, and a fourth wave hides more of it than the spills add; 5: 186)
 #ifndef REL_WAVES_PER_EU
-#define REL_WAVES_PER_EU 3
+#define REL_WAVES_PER_EU 4
 #endif
 
 template <int MINM, int MAXM, int G>
