@@ -863,22 +863,33 @@ __device__ __attribute__((noinline)) void sw_windows(int lane SW_PROF_ARGS)
 //      covered before its last groups, every round costs a pass over all segments, and 128 / 256 / 512 / 1024 / all
 //      segments per round take 25.4 / 23.7 / 22.9 / 22.3 / 22.1 ms on the 60x set -- so a round takes all its keys. ----
 __device__ __forceinline__ int sw_sort_key(int nw) { return nw > 1000 ? 0 : 1000-nw; }
-__device__ __forceinline__ void sw_sort_range(const cp_seedw_read &R, int n, int nbig, int lane)
+// PACKED: two 16-bit counters per LDS word -- twice the keys per round, so ONE round covers all keys (0 .. 1010); possible
+// while a read has fewer than 65536 segments (its counts and offsets then fit 16 bits).
+template <bool PACKED>
+__device__ __forceinline__ void sw_sort_range_t(const cp_seedw_read &R, int n, int nbig, int lane)
 { const uint64_t lt = (1ull << lane)-1;
   const int lo = sw_sel(SEL_NEXTKEY), base = sw_sel(SEL_NSORTED);
-  constexpr int PER = SW_SORTW/WAVE;                         // counters per lane
+  constexpr int NKEY = PACKED ? 2*SW_SORTW : SW_SORTW;      // keys of a round
+  constexpr int PER = NKEY/WAVE;                             // counters per lane
+  uint16_t *sb16 = reinterpret_cast<uint16_t *>(sw_S.sbins);
   __syncthreads();
   for (int q = lane; q < SW_SORTW; q += WAVE) sw_S.sbins[q] = 0;
   __syncthreads();
   for (int q = lane; q < n; q += WAVE)
     { const int d = sw_sort_key(R.rec[q].z)-lo;
-      if (d >= 0 && d < SW_SORTW) atomicAdd(&sw_S.sbins[d],1);
+      if (d >= 0 && d < NKEY)
+        { if (PACKED) atomicAdd(&sw_S.sbins[d >> 1],(d & 1) ? 0x10000 : 1);
+          else atomicAdd(&sw_S.sbins[d],1);
+        }
     }
   __syncthreads();
-  // the range ends at the first key whose running total reaches SW_SORTN (else with the window); exclusive prefix sums
+  // the range ends at the first key whose running total reaches SW_SORTN (else with the round's keys); exclusive prefix sums
   int c[PER], tot = 0;
 #pragma unroll
-  for (int u = 0; u < PER; u++) { c[u] = sw_S.sbins[PER*lane+u]; tot += c[u]; }
+  for (int u = 0; u < PER; u++)
+    { c[u] = PACKED ? (int)sb16[PER*lane+u] : sw_S.sbins[PER*lane+u];
+      tot += c[u];
+    }
   int incl = tot;
   for (int o = 1; o < WAVE; o <<= 1) { const int x = __shfl_up(incl,o); if (lane >= o) incl += x; }
   int run = incl-tot, dend = -1, cend = 0;                   // this lane's first key that reaches the target, the total up to it
@@ -890,11 +901,14 @@ __device__ __forceinline__ void sw_sort_range(const cp_seedw_read &R, int n, int
       c[u] = ex;
     }
   const uint64_t hit = __ballot(dend >= 0);
-  int hi = SW_SORTW-1, cnt = __shfl(incl,WAVE-1);
+  int hi = NKEY-1, cnt = __shfl(incl,WAVE-1);
   if (hit) { const int src = __ffsll((long long)hit)-1; hi = __shfl(dend,src); cnt = __shfl(cend,src); }
   __syncthreads();
 #pragma unroll
-  for (int u = 0; u < PER; u++) sw_S.sbins[PER*lane+u] = c[u];
+  for (int u = 0; u < PER; u++)
+    { if (PACKED) sb16[PER*lane+u] = (uint16_t)c[u];
+      else sw_S.sbins[PER*lane+u] = c[u];
+    }
   __syncthreads();
   const int nbits = hi > 0 ? 32-__clz(hi) : 0;
   for (int q0 = 0; q0 < n && cnt > 0; q0 += WAVE)
@@ -911,9 +925,12 @@ __device__ __forceinline__ void sw_sort_range(const cp_seedw_read &R, int n, int
         }
       const int rank = __popcll(peers & lt);
       int dst = 0;
-      if (part) dst = base+sw_S.sbins[d]+rank;
+      if (part) dst = base+(PACKED ? (int)sb16[d] : sw_S.sbins[d])+rank;
       __syncthreads();
-      if (part && rank == 0) sw_S.sbins[d] += __popcll(peers);
+      if (part && rank == 0)
+        { if (PACKED) sb16[d] = (uint16_t)(sb16[d]+__popcll(peers));
+          else sw_S.sbins[d] += __popcll(peers);
+        }
       __syncthreads();
       if (part) R.orec[dst] = t;
     }
@@ -933,6 +950,10 @@ __device__ __forceinline__ void sw_sort_range(const cp_seedw_read &R, int n, int
     }
   if (lane == 0) { sw_S.sel[SEL_NSORTED] = base+cnt; sw_S.sel[SEL_NEXTKEY] = lo+hi+1; }
   __syncthreads();
+}
+__device__ __forceinline__ void sw_sort_range(const cp_seedw_read &R, int n, int nbig, int lane)
+{ if (n < 65536) sw_sort_range_t<true>(R,n,nbig,lane);
+  else sw_sort_range_t<false>(R,n,nbig,lane);
 }
 
 __device__ __attribute__((noinline)) void sw_sort(int rep_, int lane SW_PROF_ARGS)

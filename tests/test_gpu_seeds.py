@@ -108,7 +108,7 @@ def test_seeds_beyond_the_on_chip_sizes(torch_dev):
     counts above 1000 give window counts above the window (the sorted head is ordered by insertion); hundreds of short
     label islands make the masked-interval list longer than its LDS part, in the first selection and in a later one;
     more than 64 repetitive stretches; groups with more than 64 members to take (equal window counts all over the
-    read); a read of more than 65535 k-mers."""
+    read); a read of more than 65535 k-mers; a selection of more than 65535 segments."""
     from classpro_amd.api import Classifier
     from oracle.oracle import Oracle
     rng = np.random.default_rng(9)
@@ -148,5 +148,8 @@ def test_seeds_beyond_the_on_chip_sizes(torch_dev):
     plen = 70000                                                      # more than 65535 k-mers
     lab = np.repeat(np.frombuffer(b"EHDR", np.uint8)[rng.choice(4, plen, p=[.1, .2, .5, .2])], rng.integers(1, 400, plen))[:plen]
     add(np.repeat(rng.integers(1, 80, plen), rng.integers(1, 9, plen))[:plen], lab.tobytes())
+    plen = 90000                                                      # more than 65535 SEGMENTS in one selection: the sort's counters
+    prof = (20 + (np.arange(plen) % 2) * 7 + (np.arange(plen) // 3000) % 5).astype(np.uint16)   # no longer fit 16 bits (two rounds of keys)
+    add(prof, b"D" * plen)
     _check_against_oracle(clf, O, 40, cases)
     clf.close()
