@@ -500,9 +500,38 @@ __device__ __attribute__((noinline)) void sw_segments(int C_, int nrep_, int rep
   // segment's predecessor of either kind is known from its valid predecessor's begin and end.
   { bool carry = false;                                      // the run entering the chunk already holds a valid k-mer
     int nv = 0, ni = 0;                                      // valid / skipped segments so far
-    int lpos = -1, ltype = 0, lidx = 0;                      // the last segment start so far: position, valid?, its index
     int ri = 0;                                              // (repeats) first repetitive stretch that ends beyond the chunk start
     int prevc = -1;                                          // count of the k-mer before the chunk
+    int nbuf = 0;                                            // segment starts waiting in sw_S.cval (< 2*WAVE)
+    int prev_e = -1, prev_idx = 0;                           // the last start written so far ((position << 1) | valid, its index), -1: none
+    auto emit = [&](int m)                                   // records of the first m <= WAVE waiting starts (wave-uniform)
+      { __syncthreads();
+        const bool a = lane < m;
+        const int e = a ? sw_S.cval[lane] : 0;
+        const int p = e >> 1;
+        const bool mv = (e & 1) != 0;
+        const uint64_t vb = __ballot(a && mv), ib = __ballot(a && !mv);
+        const int idx = mv ? nv+__popcll(vb & lt) : ni+__popcll(ib & lt);
+        const int ep = sw_from_below(e,prev_e), pidx = sw_from_below(idx,prev_idx);    // the segment before mine ends where mine begins
+        int cnt = 0;
+        if (a && mv) cnt = (int)R.prof[p];
+        if (a)
+          { if (ep >= 0 && pidx < R.cap) { if (ep & 1) R.rec[pidx].y = p; else R.orec[pidx].y = p; }
+            if (idx < R.cap)                                 // (z: the begin of my predecessor of either kind, until the window count replaces it)
+              { if (mv) { R.rec[idx].x = p; R.rec[idx].z = ep >= 0 ? (ep >> 1) : -(1 << 30); R.rec[idx].w = (rep ? 32767-cnt : cnt)+1; }
+                else R.orec[idx].x = p;
+              }
+          }
+        prev_e = __builtin_amdgcn_readlane(e,m-1); prev_idx = __builtin_amdgcn_readlane(idx,m-1);
+        nv += __popcll(vb); ni += __popcll(ib);
+        const int rest = nbuf-m;                             // (< WAVE) move the waiting rest to the front
+        int t = 0;
+        if (lane < rest) t = sw_S.cval[m+lane];
+        __syncthreads();
+        if (lane < rest) sw_S.cval[lane] = t;
+        nbuf = rest;
+        __syncthreads();
+      };
     int ncnt[SW_STEP]; char ncl[SW_STEP], nst[SW_STEP];      // a step's loads are issued one step ahead
     auto load_step = [&](int e0)
       {
@@ -561,35 +590,19 @@ __device__ __attribute__((noinline)) void sw_segments(int C_, int nrep_, int rep
             // held a valid k-mer, or it is the read's first
             const uint64_t sm = inm & ((vm & ~(hvs & ~bm)) | (bm & hvs) | (c0 == 0 ? 1ull : 0ull));
             carry = (hv >> 63) != 0;
-            const uint64_t vs = sm & vm, is = sm & ~vm;      // valid / skipped segments starting here
-            if ((sm >> lane) & 1)
-              { const bool mv = (vm >> lane) & 1;
-                const int idx = mv ? nv+__popcll(vs & lt) : ni+__popcll(is & lt);
-                // the segment before mine ends where mine begins
-                const uint64_t below = sm & lt;
-                int ptype = ltype, pidx = lidx, ppos = lpos;
-                if (below)
-                  { const int pl = 63-__clzll((long long)below);
-                    const uint64_t blt = (1ull << pl)-1;
-                    ptype = (int)((vm >> pl) & 1);
-                    pidx = ptype ? nv+__popcll(vs & blt) : ni+__popcll(is & blt);
-                    ppos = c0+pl;
-                  }
-                if (ppos >= 0 && pidx < R.cap) { if (ptype) R.rec[pidx].y = p; else R.orec[pidx].y = p; }
-                if (idx < R.cap)                             // (z: the begin of my predecessor of either kind, until the window count replaces it)
-                  { if (mv) { R.rec[idx].x = p; R.rec[idx].z = ppos >= 0 ? ppos : -(1 << 30); R.rec[idx].w = (rep ? 32767-cnt[u] : cnt[u])+1; }
-                    else R.orec[idx].x = p;
-                  }
-              }
+            // The starts only go to a list in LDS here ((position, valid?) in position order); their records are written
+            // 64 starts at a time by sw_emit below, every lane with a start of its own -- written on the spot, the record
+            // code ran for every chunk with a handful of its lanes, and the last start's place had to be kept by scalar
+            // bookkeeping in a loop that the scalar unit bounds.
             if (sm)
-              { const int top = 63-__clzll((long long)sm);
-                const uint64_t blt = (1ull << top)-1;
-                lpos = c0+top; ltype = (int)((vm >> top) & 1);
-                lidx = ltype ? nv+__popcll(vs & blt) : ni+__popcll(is & blt);
-                nv += __popcll(vs); ni += __popcll(is);
+              { if ((sm >> lane) & 1) sw_S.cval[nbuf+__popcll(sm & lt)] = (p << 1) | (int)((vm >> lane) & 1);
+                nbuf += __popcll(sm);
+                if (nbuf >= WAVE) emit(WAVE);
               }
           }
       }
+    if (nbuf > 0) emit(nbuf);
+    const int lpos = prev_e >= 0 ? (prev_e >> 1) : -1, ltype = prev_e & 1, lidx = prev_idx;
     if (lpos >= 0 && lpos >= plen-1)                         // a segment at the last k-mer is never made: it only ends its predecessor
       { if (ltype) nv--; else ni--;
       }
