@@ -744,29 +744,33 @@ __device__ __attribute__((noinline)) void sw_windows(int lane SW_PROF_ARGS)
 #ifdef SW_SKIP_COOP
         fopen = false;
 #endif
-        for (uint64_t um = __ballot(fopen); um; um &= um-1)
-          { const int src = __ffsll((long long)um)-1;
-            const int sb = __shfl(bi,src), sk = __shfl(ki,src);
-            bool seq = __shfl(eq ? 1 : 0,src) != 0, sne = __shfl(nonempty ? 1 : 0,src) != 0;
-            int rg = -1, rbg = 0, rpbg = 0;
-            for (int j0 = ring_hi; ; j0 += WAVE)
-              { const int jj = j0+lane;
-                sg sj; sj.b = 0; sj.pb = 0; sj.key = -1;
-                if (jj < n) sj = seg(jj);
-                const bool reach = jj < n && sj.pb < sb+W;     // (monotone: begins grow)
-                const uint64_t mR = __ballot(reach), mB = __ballot(reach && sj.key > sk), mE = __ballot(reach && sj.key == sk);
-                if (mB)
-                  { const int fb = __ffsll((long long)mB)-1;
-                    const uint64_t blt = (1ull << fb)-1;
-                    rg = j0+fb; rbg = __shfl(sj.b,fb); rpbg = __shfl(sj.pb,fb);
-                    sne = sne || (mR & blt) != 0; seq = seq || (mE & blt) != 0;
-                    break;
-                  }
-                sne = sne || mR != 0; seq = seq || mE != 0;
-                if (mR != ~0ull) break;                        // the reach ended inside these 64
-              }
-            if (lane == src) { g = rg; bg = rbg; pbg = rpbg; eq = seq; nonempty = sne; }
-          }
+        // (block by block, every open search looking at the block while it is in registers: searched one after the other,
+        //  each search loaded its blocks from HBM again -- a round trip per open lane and block, one behind the other)
+        { uint64_t um = __ballot(fopen);
+          for (int j0 = ring_hi; um; j0 += WAVE)
+            { const int jj = j0+lane;
+              sg sj; sj.b = 0; sj.pb = 0; sj.key = -1;
+              if (jj < n) sj = seg(jj);
+              uint64_t still = 0;
+              for (uint64_t t = um; t; t &= t-1)
+                { const int src = __ffsll((long long)t)-1;
+                  const int sb = __builtin_amdgcn_readlane(bi,src), sk = __builtin_amdgcn_readlane(ki,src);
+                  const bool reach = jj < n && sj.pb < sb+W;   // (monotone: begins grow)
+                  const uint64_t mR = __ballot(reach), mB = __ballot(reach && sj.key > sk), mE = __ballot(reach && sj.key == sk);
+                  if (mB)
+                    { const int fb = __ffsll((long long)mB)-1;
+                      const uint64_t blt = (1ull << fb)-1;
+                      const int rbg = __builtin_amdgcn_readlane(sj.b,fb), rpbg = __builtin_amdgcn_readlane(sj.pb,fb);
+                      if (lane == src) { g = j0+fb; bg = rbg; pbg = rpbg; nonempty = nonempty || (mR & blt) != 0; eq = eq || (mE & blt) != 0; }
+                    }
+                  else
+                    { if (lane == src) { nonempty = nonempty || mR != 0; eq = eq || mE != 0; }
+                      if (mR == ~0ull) still |= 1ull << src;     // (else the reach ended inside these 64)
+                    }
+                }
+              um = still;
+            }
+        }
         // -- backward: what the deque holds when I arrive (segments beginning beyond pb(me)-W): does any of them match
         //    or beat me (then I wipe nothing), and where does the nearest one that beats me begin (a beaten segment
         //    needs that; an expiring one only needs to know that it wipes nothing) --
@@ -804,27 +808,32 @@ __device__ __attribute__((noinline)) void sw_windows(int lane SW_PROF_ARGS)
 #ifdef SW_SKIP_COOP
         bopen = false;
 #endif
-        for (uint64_t um = __ballot(bopen); um; um &= um-1)
-          { const int src = __ffsll((long long)um)-1;
-            const int sk = __shfl(ki,src), slim = __shfl(limw,src), sgi = __shfl(g,src);
-            bool sbl = __shfl(blocked ? 1 : 0,src) != 0, sbn = __shfl(bnon ? 1 : 0,src) != 0, shp = false;
-            int spb = 0;
-            for (int j0 = loR-1; ; j0 -= WAVE)
-              { const int jj = j0-lane;
-                sg sj; sj.b = 0; sj.pb = 0; sj.key = -1;
-                if (jj >= 0) sj = seg(jj);
-                const bool inw = jj >= 0 && sj.b > slim;       // (monotone)
-                const uint64_t mI = __ballot(inw), mS = __ballot(inw && sj.key > sk), mN = __ballot(inw && sj.key >= sk);
-                if (mS)
-                  { const int fs = __ffsll((long long)mS)-1;
-                    shp = true; spb = __shfl(sj.b,fs); sbl = true; sbn = true;
-                    break;
-                  }
-                sbn = sbn || mI != 0; sbl = sbl || mN != 0;
-                if (mI != ~0ull || (sbl && sgi < 0)) break;
-              }
-            if (lane == src) { blocked = sbl; bnon = sbn; havep = shp; pbeg = spb; }
-          }
+        { uint64_t um = __ballot(bopen);
+          for (int j0 = loR-1; um; j0 -= WAVE)
+            { const int jj = j0-lane;
+              sg sj; sj.b = 0; sj.pb = 0; sj.key = -1;
+              if (jj >= 0) sj = seg(jj);
+              uint64_t still = 0;
+              for (uint64_t t = um; t; t &= t-1)
+                { const int src = __ffsll((long long)t)-1;
+                  const int sk = __builtin_amdgcn_readlane(ki,src), slim = __builtin_amdgcn_readlane(limw,src), sgi = __builtin_amdgcn_readlane(g,src);
+                  const bool sbl = __builtin_amdgcn_readlane(blocked ? 1 : 0,src) != 0;
+                  const bool inw = jj >= 0 && sj.b > slim;     // (monotone)
+                  const uint64_t mI = __ballot(inw), mS = __ballot(inw && sj.key > sk), mN = __ballot(inw && sj.key >= sk);
+                  if (mS)
+                    { const int fs = __ffsll((long long)mS)-1;
+                      const int spb = __builtin_amdgcn_readlane(sj.b,fs);
+                      if (lane == src) { havep = true; pbeg = spb; blocked = true; bnon = true; }
+                    }
+                  else
+                    { const bool nbl = sbl || mN != 0;
+                      if (lane == src) { bnon = bnon || mI != 0; blocked = nbl; }
+                      if (mI == ~0ull && !(nbl && sgi < 0)) still |= 1ull << src;
+                    }
+                }
+              um = still;
+            }
+        }
         // -- values --
         const bool wipe = act && bnon && !blocked;
         const bool isexp = act && g < 0;
