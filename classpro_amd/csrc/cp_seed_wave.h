@@ -327,12 +327,32 @@ __device__ __forceinline__ int sw_hash_at(const char *seq, int j, int K, int rle
         { const cp_u8x16 x = *reinterpret_cast<const cp_u8x16 *>(seq+j+16*q);
           w[4*q] = x.v[0]; w[4*q+1] = x.v[1]; w[4*q+2] = x.v[2]; w[4*q+3] = x.v[3];
         }
+      // Eight bases per group: their letter classes are looked up together, one group ahead, and the group's sixteen
+      // rotated seeds together -- a group costs one table round trip.  (Step by step under `if (t < K)` the compiler
+      // made groups of four with two dependent round trips each: twenty LDS latencies per k-mer at K = 40 and almost
+      // nothing else in flight -- the marks took 88 us per selection for ~540 k-mers.)  Steps beyond K read the zero row.
+      constexpr int GB = 8;
+      int cd[GB], cdn[GB];
 #pragma unroll
-      for (int t = 0; t < SW_KMAX; t++)
-        if (t < K)
-          { const int code = code_of[(w[t >> 2] >> (8*(t & 3))) & 0xff];
-            fh ^= rot[(code & 7)*STRIDE+(K-1-t)];
-            rh ^= rot[(code >> 3)*STRIDE+t];
+      for (int u = 0; u < GB; u++) { cd[u] = code_of[(w[u >> 2] >> (8*(u & 3))) & 0xff]; cdn[u] = 0; }
+#pragma unroll
+      for (int t0 = 0; t0 < SW_KMAX; t0 += GB)
+        if (t0 < K)
+          { if (t0+GB < SW_KMAX && t0+GB < K)
+              {
+#pragma unroll
+                for (int u = 0; u < GB; u++) { const int t = t0+GB+u; cdn[u] = code_of[(w[t >> 2] >> (8*(t & 3))) & 0xff]; }
+              }
+#pragma unroll
+            for (int u = 0; u < GB; u++)
+              { const int t = t0+u;
+                const bool on = t < K;
+                const int code = on ? cd[u] : (4 | (4 << 3));
+                fh ^= rot[(code & 7)*STRIDE+(on ? K-1-t : 0)];
+                rh ^= rot[(code >> 3)*STRIDE+(on ? t : 0)];
+              }
+#pragma unroll
+            for (int u = 0; u < GB; u++) cd[u] = cdn[u];
           }
     }
   else
@@ -343,6 +363,9 @@ __device__ __forceinline__ int sw_hash_at(const char *seq, int j, int K, int rle
       }
   return (int)((rh < fh ? rh : fh) % CP_SEED_MOD);
 }
+
+// (defined below sw_mark_all's comment) one copy of the unrolled hash for all call sites of sw_mark_all
+__device__ __attribute__((noinline)) int sw_hash_lds(const char *seq, int j, int K, int rlen);
 
 // The hash loop reads a letter's class and two rotated seeds per base, each lane at its own address: as global loads
 // (the tables sit in the caches) these 120 scattered loads per k-mer kept the address unit busy for a third of the
@@ -370,13 +393,20 @@ __device__ __attribute__((noinline)) void sw_mark_all(const char *seq, const cha
   for (int q = lane; q < 256/4; q += WAVE) reinterpret_cast<uint32_t *>(lcode)[q] = reinterpret_cast<const uint32_t *>(sw_CODE.v)[q];
   __syncthreads();
   constexpr int KEEP = 4;
-  for (int base = 0; base < ntake; base += WAVE)
-    { const int ns = ntake-base < WAVE ? ntake-base : WAVE;
+  int ns = 0;
+  for (int base = 0; base < ntake; base += ns)
+    { // A round takes as many of the next segments as hold KEEP*WAVE k-mers together (one at least): their hashes then
+      // wait in registers for the mark sweep.  (64 segments per round before: with ~16 k-mers per taken segment nearly
+      // every round was over that size and hashed every k-mer twice, once for the minimum and once for the marks.)
+      const int nmax = ntake-base < WAVE ? ntake-base : WAVE;
       int b = 0, len = 0;
-      if (lane < ns) { b = takes[2*(base+lane)]; len = takes[2*(base+lane)+1]-b; }
+      if (lane < nmax) { b = takes[2*(base+lane)]; len = takes[2*(base+lane)+1]-b; }
       int incl = len;
       for (int o = 1; o < WAVE; o <<= 1) { const int x = __shfl_up(incl,o); if (lane >= o) incl += x; }
-      const int total = __shfl(incl,WAVE-1);
+      ns = __popcll(__ballot(lane < nmax && incl <= KEEP*WAVE));      // (the sums grow: a prefix of the lanes)
+      if (ns == 0) ns = 1;
+      if (lane >= ns) { b = 0; len = 0; }
+      const int total = __builtin_amdgcn_readlane(incl,ns-1);
       __syncthreads();
       s_pre[lane] = incl-len;                                // first k-mer slot of segment `lane`
       s_min[lane] = CP_SEED_MOD;
@@ -399,7 +429,7 @@ __device__ __attribute__((noinline)) void sw_mark_all(const char *seq, const cha
                   int lo = 0, j = 0;
                   locate(on ? q : 0,lo,j);
                   if (on)
-                    { hk[u] = sw_hash_at<SW_KMAX+1>(seq,j,K,rlen,lrot,lcode); jk[u] = j; lk[u] = lo;
+                    { hk[u] = sw_hash_lds(seq,j,K,rlen); jk[u] = j; lk[u] = lo;
                       atomicMin(&s_min[lo],hk[u]);
                     }
                 }
@@ -419,7 +449,7 @@ __device__ __attribute__((noinline)) void sw_mark_all(const char *seq, const cha
               int lo = 0, j = 0;
               locate(on ? q : 0,lo,j);
               if (on)
-                { const int h = sw_hash_at<SW_KMAX+1>(seq,j,K,rlen,lrot,lcode);
+                { const int h = sw_hash_lds(seq,j,K,rlen);
                   if (pass == 0) atomicMin(&s_min[lo],h);
                   else if (h == s_min[lo]) state[j] = rep ? 'R' : cls[j];
                 }
@@ -427,6 +457,15 @@ __device__ __attribute__((noinline)) void sw_mark_all(const char *seq, const cha
           __syncthreads();
         }
     }
+}
+
+// The hash of sw_mark_all as a call: inlined at its five call sites the unrolled 64-step body made sw_mark_all 10 000
+// lines of code (the tables are where sw_mark_all put them: rotated seeds over the ring, letter classes in the take buffer).
+__device__ __attribute__((noinline)) int sw_hash_lds(const char *seq, int j, int K, int rlen)
+{ typedef const char __attribute__((address_space(1))) *gcp;
+  const uint64_t *lrot = reinterpret_cast<const uint64_t *>(&sw_S.rbp[0]);
+  const uint8_t *lcode = reinterpret_cast<const uint8_t *>(&sw_S.cval[SW_STEP*WAVE/2]);
+  return sw_hash_at<SW_KMAX+1>((const char *)(gcp)(uintptr_t)seq,j,K,rlen,lrot,lcode);
 }
 
 // ---- one selection (seed.c:190-476 with C = 'H'/'D'; seed.c:667-951 with C = 0) --------------------------------------
