@@ -1,6 +1,6 @@
 """The product's N>1 path with the HIP classifier (`-m gpu`): two ranks (gloo rendezvous; both on the one MI355X of
 the box, as the driver's 8-GPU run puts one rank on each GPU) classify their shard of ONE read set through
-classpro_amd.shard.classify_sharded; rank 0's ordered gather equals the single-rank labels byte for byte."""
+classpro_amd.shard.classify_sharded; rank 0's ordered gather equals the single-rank labels and the CPU oracle's byte for byte."""
 import os
 import sys
 
@@ -26,7 +26,9 @@ def _worker(rank, world, port, q):
     merged, bounds = classify_sharded(lambda *a: clf.classify(Batch(*a)), seq, so, prof, po, rank, world)
     if rank == 0:
         whole = clf.classify(Batch(seq, so, prof, po))
-        q.put((bool(np.array_equal(merged, whole)), [int(b) for b in bounds], int(so[-1])))
+        from oracle.oracle import Oracle                      # (the checker: the gathered labels against the CPU oracle as well)
+        want = Oracle(40, 20000, 20, 40).classify_batch(seq, so, prof, po, nthreads=4)
+        q.put((bool(np.array_equal(merged, whole)) and bool(np.array_equal(merged, want)), [int(b) for b in bounds], int(so[-1])))
     clf.close()
     dist.barrier()
     dist.destroy_process_group()
