@@ -14,35 +14,33 @@
 //   * the result per k-mer: 'E' (no seed) or the class of the seed ('H', 'D', or 'R' for a repeat seed),
 //     seed.c:1007-1015 -- what the .class.data track carries under -s (ClassPro.c:293).
 //
-// Who does what in the wave:
-//   * all 64 lanes: the per-position work.  256 k-mer positions are loaded coalesced per step; run boundaries, the
-//     selection's valid flags and from them the SEGMENT STARTS come out of three ballots per 64 positions in closed
-//     form (a position starts a segment iff it is the first valid k-mer of its run of equal counts, or it begins a run
-//     whose predecessor run held a valid k-mer, or it is position 0): no walk over the positions.  Label runs for
-//     anno_repeat, the stable radix sort by window count (ballot ranks), the group tests against the masked-interval
-//     list (64 sorted segments at once) and the ntHash of a taken segment's k-mers (a lane per k-mer over a table of
-//     pre-rotated seeds, wave minimum) are wave-parallel too.
-//   * lane 0: the one inherently sequential chain -- the monotone deque that gives every segment its window count --
-//     with its state on chip: the deque's two ends in registers, the ring in LDS.
+// How the wave does it (every phase is wave-parallel; nothing runs on one lane except the short label-run bookkeeping of
+// anno_repeat):
+//   * segments: 256 k-mer positions are loaded coalesced per step; run boundaries and the selection's valid flags are two
+//     ballots per 64 positions and the SEGMENT STARTS follow from them in closed form by scalar bit operations (a position
+//     starts a segment iff it is the first valid k-mer of its run of equal counts, or it begins a run whose predecessor
+//     run held a valid k-mer, or it is position 0); the starts go to an LDS list and get their records 64 at a time;
+//   * window counts: the reference's monotone deque restated per segment (the comment of sw_windows) -- two searches over
+//     a window of segments, from an LDS ring of segments with a range-maximum table beside their keys, and two prefix
+//     operations over the segment order (ballots with carried scalars);
+//   * the order of the walk: counters per window count in LDS and a stable scatter (ranks from ballots);
+//   * the walk: 64 sorted segments at once tested against the masked-interval list (a binary search per lane); a take
+//     updates the list wave-uniformly; the canonical-ntHash minimizers of all taken segments are marked at the end of the
+//     selection, a lane per k-mer over tables of pre-rotated seeds in LDS;
 //   * the masked-interval list is restated slot for slot: the reference searches and sorts one slot past the live part
 //     of that array (seed.c:141,161-166), so its leftovers matter; the defined behaviour is that the array
 //     is all zeros when a read starts.
-// Nothing is bounded by the on-chip sizes: a deque deeper than the ring, a list longer than SW_MI, more than SW_REP
-// repetitive stretches, a group with more than SW_PEND members to take move to (or are flagged in) the read's HBM
-// scratch and the same code goes on there.
+// A selection runs as four calls (sw_segments, sw_windows, sw_sort, sw_walk) whose state travels through LDS: each phase
+// has its registers to itself.
+// Nothing is bounded by the on-chip sizes: a window that reaches beyond the ring, a list longer than SW_MI, more than
+// SW_REP repetitive stretches, a group with more than SW_PEND members to take, a selection of more than 65535 segments
+// move to (or are flagged in) the read's HBM scratch and the same code goes on there.
 #pragma once
 #include "cp_seed.h"
 
 #ifndef SW_RING
-#define SW_RING  256                             // segments of the window-count pass kept on chip (10 bytes each; beyond: read from HBM)
-#define SW_BACK  96                              // ... of which this many lie behind the tile being worked on (a multiple of 32)
-                                                 // (512 / 192: 59.4 ms on the 60x set against 57.6 -- the LDS is worth more as a sixth wave per SIMD)
-#endif
-#ifndef SW_BATCH
-#define SW_BATCH 8                               // ... that many at a time (their reads are issued together)
-#endif
-#ifndef SW_IND
-#define SW_IND   32                              // segments a lane searches on its own in each direction before the wave takes over
+#define SW_RING  256                             // segments of the window-count pass kept on chip (10 bytes each + the range maxima; beyond: read from HBM)
+#define SW_BACK  96                              // ... of which this many lie behind the tile being worked on
 #endif
 #ifndef SW_LEV
 #define SW_LEV   7                               // levels of the range-maximum table: blocks of 1 .. 64 segments
@@ -61,7 +59,7 @@
 #endif
 #define SW_KMAX  64                              // k-mer lengths served by the rotated-seed table (longer: byte-wise fold)
 #ifndef SW_STEP
-#define SW_STEP  2                               // chunks of 64 positions per load step (4: 57.6 ms against 55.6)
+#define SW_STEP  2                               // chunks of 64 positions per load step
 #endif
 
 struct cp_seedw_read
@@ -686,7 +684,7 @@ __device__ __attribute__((noinline)) void sw_windows(int lane SW_PROF_ARGS)
         else { const int4 t = R.rec[j]; r.b = t.x; r.pb = t.z; r.key = t.w-1; }
         return r;
       };
-    // a segment within SW_IND of the tile: always in the ring (it covers [t0-SW_BACK, t0+SW_RING-SW_BACK) of [0,n)), no test
+    // the tile and its successor: always in the ring (it covers [t0-SW_BACK, t0+SW_RING-SW_BACK) of [0,n)), no test
     static_assert(WAVE+1 <= SW_RING-SW_BACK && SW_TOPB >= 2,"a tile and its successor are in the ring");
     auto segr = [&](int j) -> sg
       { sg r; const int2 t = sw_S.rbp[j & (SW_RING-1)]; r.b = t.x; r.pb = t.y; r.key = sw_S.rkey[j & (SW_RING-1)]; return r; };

@@ -4,7 +4,7 @@
 // prof[prof_off[r] .. prof_off[r+1]) and seq[seq_off[r] .. seq_off[r+1]).  Per-read scratch is
 // addressed with the same offsets:
 //   bitmap   1 bit per profile position over the WHOLE concatenated profile (bit g = candidate at g)
-//   wall     1 byte per position, read r at wall + prof_off[r] + r        (plen+1 cells per read)
+//   wall     1 byte per position, read r at wall + prof_off[r] + r        (plen+1 cells per read; only reads whose flags do not fit on chip use it)
 //   hkeys/hvals  per-read open-addressing table position -> 4 memoised probabilities (perror), read r at hoff[r]
 //   eintvl / ointvl   E-/O-interval lists, read r at eoff[r], capacity eoff[r+1]-eoff[r]
 //   intvl / rintvl / relmap / DP scratch   read r at ioff[r], capacity ioff[r+1]-ioff[r]
@@ -14,7 +14,7 @@
 //   k_count_caps        per-read candidate count -> scratch capacities
 //   k_prefix_caps_mb    exclusive prefix sums of the capacities (one block per 1024 reads, single pass with look-back)
 //   k_wall_tasks        one wave per read: the read-only part of the candidate walk, wall.c:590-707 (lists + task results to HBM)
-//   k_find_wall         one wave per read: the walk's in-order replay and everything after it, wall.c:639-958
+//   k_find_wall         one wave per read: the walk's replay (dependency rounds, flags in LDS) and everything after it, wall.c:639-958
 //   k_find_rel          one wave per read, one lane per interval: wall.c:960-1051
 //   k_classify_rel_grp   4 reads per wave (1 for M > 128), 8 lanes per direction: class_rel.c:871-963
 //   k_classify_unrel_grp 2 reads per wave, speculative update slots committed in order: class_unrel.c:248-300
@@ -734,11 +734,12 @@ __device__ unsigned long long g_live_prof[8];
 //       (cp_wall_candidate_live: own P(error), low-complexity partner, best high-complexity partner).  Dense lanes
 //       matter: this is where the instructions are -- and the registers: 96 VGPRs and 192 bytes of spills with this
 //       part inside, 70 and none without it;
-//   2.  the candidates are replayed in order (cp_wall_candidate_replay: paired flags, perror memo, flag and
-//       interval-list updates), the SELF pass on lane 0 and the OTHERS pass on lane 1 (disjoint state: own flag
-//       array, own memo table, own interval list).
-// k_wall_tasks does 0-1b (5 waves per SIMD) and leaves the lists and the task results in HBM; k_find_wall does 2 and
-// the list phases after the walk at 7 waves per SIMD: they are chains of dependent loads and want waves, not registers.
+//   2.  the tasks are replayed (paired flags, perror memo, flag and interval-list updates): a lane per task in rounds of
+//       tasks with no open dependency on an earlier one, on flag bytes kept in LDS (k_find_wall below); a read whose
+//       memo does not fit on chip takes the one-lane form (cp_wall_candidate_replay: the SELF pass on lane 0 and the
+//       OTHERS pass on lane 1 -- disjoint state: own flag array, own memo table, own interval list).
+// k_wall_tasks does 0-1b (4 waves per SIMD) and leaves the lists and the task results in HBM; k_find_wall does 2 and
+// the list phases after the walk at 5.5 waves per SIMD: they are chains of dependent loads and want waves, not registers.
 // Scratch: the four int lists of `wl` hold per candidate [0] maxt,maxl and both filter results, [1] the position,
 // [2] the count pair, and [3] the task list; `tres` the task results; `fwc` per read n_c, n_t, SELF tasks, overflow.
 struct task_res { double own_pe, lc_v, hc_pe; int lc_j, hc;  };   // hc: lc_kind | (hc_j >= 0) << 2 | (hc_j - i) << 16
