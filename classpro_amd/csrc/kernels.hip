@@ -2663,7 +2663,24 @@ k_seed_caps(const uint16_t *__restrict__ prof, const int64_t *__restrict__ prof_
   const uint16_t *p = prof+po;
   const char *c = labels+seq_off[r]+(K-1);
   int nc = 0, nl = 0;
-  for (int i = 1+lane; i < plen; i += WAVE)
+  // eight positions per lane and step from one 16-byte and one 8-byte load (the addresses are only 2- / 1-byte aligned;
+  // gfx9 global loads take unaligned addresses) plus the element before them; position by position this pass over the
+  // counts and labels of the whole batch ran at 3.6 TB/s of narrow loads
+  int i0 = 1;
+  for (; i0+8*WAVE <= plen; i0 += 8*WAVE)
+    { const int i = i0+8*lane;
+      const cp_u16x8 x = cp_load_u16x8(p,i);
+      struct __attribute__((packed, aligned(1))) u8x8 { uint32_t x, y; };
+      const u8x8 y = *reinterpret_cast<const u8x8 *>(c+i);
+      unsigned pc = p[i-1], pl = (unsigned char)c[i-1];
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        { const unsigned cc = x.v[q], cl = ((q < 4 ? y.x : y.y) >> (8*(q & 3))) & 0xff;
+          nc += (cc != pc) ? 1 : 0; nl += (cl != pl) ? 1 : 0;
+          pc = cc; pl = cl;
+        }
+    }
+  for (int i = i0+lane; i < plen; i += WAVE)
     { nc += (p[i] != p[i-1]) ? 1 : 0;
       nl += (c[i] != c[i-1]) ? 1 : 0;
     }
