@@ -412,7 +412,7 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   ENSURE(ws->hoff,((size_t)nreads+1)*8);
   // The head of a call: scan, candidate counts, prefix sums, then the one host round trip (scratch sizes depend on the
   // data).  (Tried: the head on a high-priority stream of its own, forked from the caller's -- 143.9 against 146.9
-  // Gbases/s without: the other stream's wide kernels are what fills the machine, and pre-empting them costs more than
+  // Gbases/s without, 187 against 192 with the kernels of the end of round 3: the other stream's wide kernels are what fills the machine, and pre-empting them costs more than
   // the head's latency gains.)
   hipStream_t hs = st;
   if (last_stage < CP_STAGE_LABELS)                      // (the whole path writes both counts for every read: the zeros are for the
