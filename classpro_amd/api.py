@@ -85,6 +85,19 @@ def unpack_labels(packed, pack_off, rlens, K):
     return out[:so[-1]]
 
 
+def math_eval(fn, x, x2=None, device="cuda:0"):
+    """cp_math_eval: the device's own exp (fn 0) / log (1) / sqrt (2) / bessi (3, n = x2) / logp_skellam (4, k = x2) on an
+    array of doubles; returns a host float64 array."""
+    dev = torch.device(device)
+    xd = torch.from_numpy(np.ascontiguousarray(x, np.float64)).to(dev)
+    x2d = torch.from_numpy(np.ascontiguousarray(x2, np.float64)).to(dev) if x2 is not None else None
+    yd = torch.empty_like(xd)
+    check(lib().cp_math_eval(fn, xd.data_ptr(), x2d.data_ptr() if x2d is not None else None, yd.data_ptr(), xd.numel(),
+                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    torch.cuda.synchronize(dev)
+    return yd.cpu().numpy()
+
+
 class Batch:
     """A batch of reads resident in HBM in the flat layout of include/classpro_amd.h."""
 

@@ -8,6 +8,8 @@
 #include <string>
 #include <mutex>
 #include <vector>
+#include <chrono>
+#include <time.h>
 #include "cp_host_setup.h"
 #include "kernels.hip"
 
@@ -199,6 +201,31 @@ extern "C" int cp_params_tables(const cp_params *p, size_t *skel_bytes, size_t *
   return CP_OK;
 }
 
+__global__ void k_math_eval(int fn, const double *__restrict__ x, const double *__restrict__ x2, double *__restrict__ y, int64_t n)
+{ for (int64_t i = blockIdx.x*(int64_t)blockDim.x+threadIdx.x; i < n; i += (int64_t)gridDim.x*blockDim.x)
+    { const double a = x[i];
+      double r;
+      switch (fn)
+        { case 0:  r = cp_exp(a); break;
+          case 1:  r = cp_log(a); break;
+          case 2:  r = sqrt(a); break;
+          case 3:  r = cp_bessi((int)x2[i],a); break;
+          default: r = cp_logp_skellam((int)x2[i],a); break;
+        }
+      y[i] = r;
+    }
+}
+
+extern "C" int cp_math_eval(int fn, const double *d_x, const double *d_x2, double *d_y, int64_t n, void *stream)
+{ if (fn < 0 || fn > 4 || n < 0 || (n > 0 && (!d_x || !d_y)) || (fn >= 3 && n > 0 && !d_x2))
+    return set_err(CP_EINVAL,"cp_math_eval: bad argument");
+  if (n == 0) return CP_OK;
+  const int64_t blocks = (n+255)/256;
+  hipLaunchKernelGGL(k_math_eval,dim3((unsigned)(blocks < 4096 ? blocks : 4096)),dim3(256),0,(hipStream_t)stream,fn,d_x,d_x2,d_y,n);
+  HIPCHK(hipGetLastError());
+  return CP_OK;
+}
+
 extern "C" int cp_params_export(const cp_params *p, int *cov4, double *dr_ratio, int *cmax, double *hc_erate,
                                 uint8_t *cthres, double *pe, double *logfact)
 { if (!p) return set_err(CP_EINVAL,"cp_params_export: null params");
@@ -359,10 +386,15 @@ static int launch_prefix_caps(cp_workspace *ws, int64_t *a, int64_t *b, int64_t 
 { const int tiles = (n+SCAN_TILE-1)/SCAN_TILE;
   const size_t c0 = ws->scan_state.cap;
   ENSURE(ws->scan_state,(size_t)tiles*sizeof(cp_scan_state));
+  // The launch tag only ever grows (1 .. 2^24-1): a freshly zeroed array (tag 0) is valid for any launch, so growing it
+  // does NOT start the count over -- the pinned words the host polls still hold the tags of earlier launches, and a
+  // second "launch 1" would match them at once and hand the previous batch's totals to this one.
   if (ws->scan_state.cap != c0)
-    { HIPCHK(hipMemsetAsync(ws->scan_state.p,0,ws->scan_state.cap,st)); ws->scan_epoch = 0; }
-  if (++ws->scan_epoch == 0x7fffffff)                     // (never in practice: the tags wrap, start over from a cleared array)
-    { HIPCHK(hipMemsetAsync(ws->scan_state.p,0,ws->scan_state.cap,st)); ws->scan_epoch = 1; }
+    HIPCHK(hipMemsetAsync(ws->scan_state.p,0,ws->scan_state.cap,st));
+  if (++ws->scan_epoch > (int)SCAN_TAG_MASK)              // the tags start over: from a cleared array, and with the polled
+    { HIPCHK(hipMemsetAsync(ws->scan_state.p,0,ws->scan_state.cap,st)); ws->scan_epoch = 1; }   // words invalidated below
+  if (to_host)                                            // no earlier launch's totals can pass for this one's
+    for (int q = 0; q < 3; q++) __atomic_store_n(&ws->h_tot64[q],0ull,__ATOMIC_RELEASE);
   hipLaunchKernelGGL(k_prefix_caps_mb,dim3(tiles),dim3(WAVE),0,st,a,b,c,n,totals,(cp_scan_state *)ws->scan_state.p,ws->scan_epoch,
                      to_host ? ws->d_tot64 : (unsigned long long *)NULL);
   HIPCHK(hipGetLastError());
@@ -395,6 +427,10 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
     return set_err(CP_EINVAL,"cp_run_stages: bad stage");
   if (last_stage == CP_STAGE_LABELS && nreads > 0 && !d_labels)
     return set_err(CP_EINVAL,"cp_run_stages: labels buffer required");
+  // capacities per read are at most 16 per k-mer position + 64 (k_count_caps); their prefix sums travel in 40 bits
+  // (k_prefix_caps_mb): a batch that could overflow them is refused here, not found out by a wrong offset
+  if (total_kmers > CP_MAX_BATCH_KMERS || 16*total_kmers+64*(int64_t)nreads >= ((int64_t)1 << 40))
+    return set_err(CP_EINVAL,"cp_run_stages: more than CP_MAX_BATCH_KMERS k-mer positions in one batch: split it");
   hipStream_t st = (hipStream_t)stream;
   ws->nreads = nreads; ws->total_kmers = total_kmers; ws->total_bases = total_bases;
   ws->totalI = ws->totalE = 0; ws->last_stage = last_stage; ws->stream = st;
@@ -433,8 +469,14 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   // the only host round trip of the pipeline: the last tile of the prefix sums stores the three totals, tagged with the
   // launch's number, into pinned host memory and the host polls for them (every so often it asks the stream whether
   // it died instead)
-  { const unsigned tag = (unsigned)ws->scan_epoch & 0xffffffu;
+  { const unsigned tag = (unsigned)ws->scan_epoch;         // 1 .. 2^24-1 (launch_prefix_caps)
     volatile unsigned long long *ht = ws->h_tot64;
+    // Polling costs a host core while it lasts (about the head's 1 ms per call and caller: INTEGRATION.md).  Each turn
+    // is a cpu-relax; the clock is read every 64 turns; the stream is asked whether it died every 100 us; and a wait
+    // that has lasted 2 ms -- the head queued behind other streams' work -- goes on in 20-us sleeps instead of spinning.
+    const auto t0 = std::chrono::steady_clock::now();
+    auto next_query = t0+std::chrono::microseconds(100);
+    bool sleepy = false;
     for (unsigned spins = 1; ; spins++)
       { const unsigned long long g0 = __atomic_load_n(&ht[0],__ATOMIC_ACQUIRE), g1 = __atomic_load_n(&ht[1],__ATOMIC_ACQUIRE),
                                  g2 = __atomic_load_n(&ht[2],__ATOMIC_ACQUIRE);
@@ -442,8 +484,14 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
           { ws->h_totals[0] = (int64_t)(g0 >> 24); ws->h_totals[1] = (int64_t)(g1 >> 24); ws->h_totals[2] = (int64_t)(g2 >> 24);
             break;
           }
-        if ((spins & 0x3fff) == 0)
-          { const hipError_t q = hipStreamQuery(hs);
+        if (sleepy) { struct timespec ts = { 0, 20000 }; nanosleep(&ts,NULL); }
+        else __builtin_ia32_pause();
+        if (sleepy || (spins & 63) == 0)
+          { const auto now = std::chrono::steady_clock::now();
+            if (now-t0 > std::chrono::milliseconds(2)) sleepy = true;
+            if (now < next_query) continue;
+            next_query = now+std::chrono::microseconds(sleepy ? 1000 : 100);
+            const hipError_t q = hipStreamQuery(hs);
             if (q != hipErrorNotReady)                   // the stream is idle (or failed) and the totals never came
               { if (q != hipSuccess) return set_err(CP_EHIP,std::string("cp_run_stages: ")+hipGetErrorString(q));
                 HIPCHK(hipMemcpy(&ws->h_totals[0],ws->dtot.p,24,hipMemcpyDeviceToHost));
@@ -683,6 +731,8 @@ extern "C" int cp_find_seeds_batch(const cp_params *p, cp_workspace *ws, const c
     return set_err(CP_EINVAL,"cp_find_seeds_batch: bad argument");
   if (nreads > 0 && (!d_seq || !d_seq_off || !d_prof || !d_prof_off || !d_labels || !d_seeds))
     return set_err(CP_EINVAL,"cp_find_seeds_batch: null device pointer");
+  if (total_kmers > CP_MAX_BATCH_KMERS)                   // same limit as cp_run_stages (the seed capacities are ~2 per position)
+    return set_err(CP_EINVAL,"cp_find_seeds_batch: more than CP_MAX_BATCH_KMERS k-mer positions in one batch: split it");
   hipStream_t st = (hipStream_t)stream;
   ws->stream = st; ws->seed_nreads = nreads; ws->seed_totalR = 0;
   if (nreads == 0) return CP_OK;

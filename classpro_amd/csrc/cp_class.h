@@ -247,9 +247,9 @@ CP_HD void cp_rel_direction(const cp_dev_params *P, const cp_intvl *rintvl, int 
       }
     double psum = 0.;
     for (int s = 0; s < 4; s++)
-      psum += exp(prev[s].dp);
+      psum += cp_exp(prev[s].dp);
     for (int s = 0; s < 4; s++)
-      prev[s].dp = log(exp(prev[s].dp)/psum);
+      prev[s].dp = cp_log(cp_exp(prev[s].dp)/psum);
     rpos[i] = 0;
     eff[i] = i;
   }
@@ -271,7 +271,7 @@ CP_HD void cp_rel_direction(const cp_dev_params *P, const cp_intvl *rintvl, int 
               continue;
             }
           for (int t = 0; t < 4; t++)
-            tr[s*4+t] = exp(cp_calc_logp(P,t,I,prev[s],F,COV));
+            tr[s*4+t] = cp_exp(cp_calc_logp(P,t,I,prev[s],F,COV));
         }
       double psum = 0.;
       for (int k = 0; k < 16; k++)
@@ -282,7 +282,7 @@ CP_HD void cp_rel_direction(const cp_dev_params *P, const cp_intvl *rintvl, int 
           psum = 4.;
         }
       for (int k = 0; k < 16; k++)
-        tr[k] = log(tr[k]/psum);
+        tr[k] = cp_log(tr[k]/psum);
 
       bool only_r = true;                                // :348-380
       for (int s = 0; s < 4; s++)

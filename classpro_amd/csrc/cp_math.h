@@ -9,6 +9,7 @@
 #pragma once
 #include <math.h>
 #include "cp_types.h"
+#include "cp_libm.h"
 
 #ifndef __HIPCC__
 #undef  CP_HD
@@ -25,7 +26,7 @@ CP_HD double cp_bessi0(double x)
     }
   else
     { y = 3.75/ax;
-      ans = (exp(ax)/sqrt(ax))*(0.39894228+y*(0.1328592e-1
+      ans = (cp_exp(ax)/sqrt(ax))*(0.39894228+y*(0.1328592e-1
             +y*(0.225319e-2+y*(-0.157565e-2+y*(0.916281e-2
             +y*(-0.2057706e-1+y*(0.2635537e-1+y*(-0.1647633e-1
             +y*0.392377e-2))))))));
@@ -47,7 +48,7 @@ CP_HD double cp_bessi1(double x)
             -y*0.420059e-2));
       ans = 0.39894228+y*(-0.3988024e-1+y*(-0.362018e-2
             +y*(0.163801e-2+y*(-0.1031555e-1+y*ans))));
-      ans *= (exp(ax)/sqrt(ax));
+      ans *= (cp_exp(ax)/sqrt(ax));
     }
   return x < 0.0 ? -ans : ans;
 }
@@ -135,13 +136,13 @@ CP_HD int cp_check_cnt(int n)
 // ---- prob.c:33-39 ---------------------------------------------------------------------------
 CP_HD double cp_logp_poisson(const cp_dev_params *P, int k, int lambda)
 { k = cp_check_cnt(k);
-  double ll = (lambda >= 0 && lambda <= CP_MAX_KMER_CNT) ? P->logint[lambda] : log((double)lambda);
+  double ll = (lambda >= 0 && lambda <= CP_MAX_KMER_CNT) ? P->logint[lambda] : cp_log((double)lambda);
   return k * ll - lambda - P->logfact[k];
 }
 
 // ---- prob.c:41-44 ---------------------------------------------------------------------------
 CP_HD double cp_logp_skellam(int k, double lambda)
-{ return -2. * lambda + log(cp_bessi(k < 0 ? -k : k,2.*lambda)); }
+{ return -2. * lambda + cp_log(cp_bessi(k < 0 ? -k : k,2.*lambda)); }
 
 // ---- prob.c:59-73 with log(p), log(1-p) supplied ----------------------------------------------
 // `lf` is anything indexable like the log-factorial table: P->logfact, or an LDS-backed accessor.
@@ -160,17 +161,17 @@ CP_HD double cp_binom_test_g(const LF &P, int k, int n, double pe, double lpe, d
   const double mean = n * pe;
   double s, p_first, p_curr;
   if ((double)k >= mean)
-    { s = p_first = exp(cp_logp_binom_pre(P,k,n,lpe,l1mpe));
+    { s = p_first = cp_exp(cp_logp_binom_pre(P,k,n,lpe,l1mpe));
       for (int x = k+1; x <= n; x++)
-        { s += p_curr = exp(cp_logp_binom_pre(P,x,n,lpe,l1mpe));
+        { s += p_curr = cp_exp(cp_logp_binom_pre(P,x,n,lpe,l1mpe));
           if (10 * p_curr < p_first)
             break;
         }
     }
   else
-    { s = p_first = (k == 0) ? 0. : exp(cp_logp_binom_pre(P,k-1,n,lpe,l1mpe));
+    { s = p_first = (k == 0) ? 0. : cp_exp(cp_logp_binom_pre(P,k-1,n,lpe,l1mpe));
       for (int x = k-2; x >= 0; x--)
-        { s += p_curr = exp(cp_logp_binom_pre(P,x,n,lpe,l1mpe));
+        { s += p_curr = cp_exp(cp_logp_binom_pre(P,x,n,lpe,l1mpe));
           if (10 * p_curr < p_first)
             break;
         }
@@ -235,7 +236,7 @@ __host__ __device__ __attribute__((noinline))
 static inline
 #endif
 double cp_logp_uerr_calc(const cp_dev_params *P, int est, int c)
-{ return log(cp_p_errorin(P->logfact,CP_OTHERS,0.1,P->u_lpe,P->u_l1mpe,est,c)); }
+{ return cp_log(cp_p_errorin(P->logfact,CP_OTHERS,0.1,P->u_lpe,P->u_l1mpe,est,c)); }
 
 CP_HD double cp_logp_uerr(const cp_dev_params *P, int est, int c)
 {

@@ -711,18 +711,21 @@ CP_HD void cp_make_interval(const RD *R, int NS, int b, int e, cp_intvl *out)
   out->is_rel = 0;
   out->asgn = CP_N_STATE;
   for (int k = 0; k < 6; k++) out->_pad[k] = 0;
-  out->pe = (idx != -1) ? log(R->eintvl.pe(idx)) : CP_NEG_INF;
+  out->pe = (idx != -1) ? cp_log(R->eintvl.pe(idx)) : CP_NEG_INF;
   double d = CP_PERR(R,b,CP_OTHERS,CP_DROP), g = CP_PERR(R,b,CP_OTHERS,CP_GAIN);
   double peob = d > g ? d : g;
   d = CP_PERR(R,e,CP_OTHERS,CP_DROP); g = CP_PERR(R,e,CP_OTHERS,CP_GAIN);
   double peoe = d > g ? d : g;
-  out->peo_b = (peob != CP_NEG_INF) ? log(peob) : CP_NEG_INF;
-  out->peo_e = (peoe != CP_NEG_INF) ? log(peoe) : CP_NEG_INF;
+  out->peo_b = (peob != CP_NEG_INF) ? cp_log(peob) : CP_NEG_INF;
+  out->peo_e = (peoe != CP_NEG_INF) ? cp_log(peoe) : CP_NEG_INF;
 }
 
 // Sum over i in [lo,hi) of the upward (sgn = +1) or downward (sgn = -1) steps prof[i+1]-prof[i] of a count
 // profile, eight counts per load where that stays inside the read's plen counts (the addresses are only
 // 2-byte aligned; gfx9 global loads take unaligned addresses).  Same terms as the loops of wall.c:972-1001.
+// hi may equal plen (wall.c:976-978, `last = I.b+lmax` with a low-complexity run that reaches the end of the read):
+// the reference then reads profile[plen], a cell no read owns -- fresh heap for the first read of a thread.  Here
+// that cell reads 0 whatever follows the read in memory, so a read's result is a function of the read alone.
 CP_HD int cp_sum_steps(const uint16_t *prof, int lo, int hi, int plen, int sgn)
 { int acc = 0, i = lo;
   if (lo >= hi) return 0;
@@ -740,7 +743,7 @@ CP_HD int cp_sum_steps(const uint16_t *prof, int lo, int hi, int plen, int sgn)
       i += 8;
     }
   for (; i < hi; i++)
-    { const int cur = prof[i+1], d = sgn*(cur-prev);
+    { const int cur = (i+1 < plen) ? prof[i+1] : 0, d = sgn*(cur-prev);   // prof[plen] is DEFINED as 0 (hazard 8)
       if (d > 0) acc += d;
       prev = cur;
     }
@@ -760,7 +763,7 @@ CP_HD bool cp_rel_interval(const cp_dev_params *P, const uint16_t *prof, const S
     return false;
   if ((I->cb > I->ce ? I->cb : I->ce) >= P->cov[CP_REPEAT])
     return false;
-  if (I->pe >= P->log_pe_final)                          // log(PE_THRES[FINAL][SELF]), wall.c:1018
+  if (I->pe >= P->log_pe_final)                          // cp_log(PE_THRES[FINAL][SELF]), wall.c:1018
     return false;
 
   int first, last, n_gain = 0, n_drop = 0, lmax;

@@ -249,10 +249,15 @@ __device__ __forceinline__ T block_scan_excl_256(T x, T *tmp, T *total)
 // per round, and a wave reduction gives the block its offset.  A tile only waits for tiles with smaller block ids, which
 // the dispatcher started before it.  The last tile writes the totals.
 #define SCAN_TILE 1024
-// A tile's three sums are published as three 8-byte granules {sum (32 bits), epoch}: one agent-scope store each carries
-// data and tag together, so neither side needs a fence.  (With a separate flag behind a __threadfence() every tile
-// wrote back its XCD's whole L2 -- dirtied all the while by the other stream's kernels -- and the kernel took 0.8 ms
-// in the pipeline for 10 us of work.)  A tile's sums stay below 2^31: 1024 reads of fewer than 60 000 candidates.
+// A tile's three sums are published as three 8-byte granules {sum (40 bits), launch tag (24 bits)}: one agent-scope store
+// each carries data and tag together, so neither side needs a fence.  (With a separate flag behind a __threadfence()
+// every tile wrote back its XCD's whole L2 -- dirtied all the while by the other stream's kernels -- and the kernel took
+// 0.8 ms in the pipeline for 10 us of work.)  A tile's sums stay below 2^40 because a whole batch's do: the host refuses
+// a batch whose capacities could add up to more (capi.hip: cp_run_stages, CP_MAX_BATCH_KMERS).  The tag runs from 1 to
+// 2^24-1; the host clears the array before it starts over (launch_prefix_caps), and a freshly cleared array (tag 0)
+// is valid for any launch.
+#define SCAN_TAG_BITS 24
+#define SCAN_TAG_MASK 0xffffffull
 struct cp_scan_state { unsigned long long g[3]; unsigned long long pad_; };
 // One WAVE per tile of 1024 values, 16 consecutive values per lane: beside the other stream's 50 000-block kernels a
 // single free wave slot turns up at once, four on one CU (a 256-thread block) only now and then -- the 256-thread form
@@ -274,7 +279,7 @@ k_prefix_caps_mb(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__re
     }
   if (t < 3)
     { const int64_t mine = t == 0 ? sum[0] : t == 1 ? sum[1] : sum[2];
-      __hip_atomic_store(&state[tile].g[t],((unsigned long long)mine << 32) | (unsigned)epoch,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&state[tile].g[t],((unsigned long long)mine << SCAN_TAG_BITS) | (unsigned)epoch,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
     }
   { int64_t p0 = 0, p1 = 0, p2 = 0;                       // look back, 64 tiles per round
     for (int base = 0; base < tile; base += WAVE)
@@ -282,13 +287,13 @@ k_prefix_caps_mb(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__re
         int64_t v0 = 0, v1 = 0, v2 = 0;
         if (j < tile)
           { unsigned long long g0, g1, g2;
-            while (((g0 = __hip_atomic_load(&state[j].g[0],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT)) & 0xffffffffull) != (unsigned)epoch)
+            while (((g0 = __hip_atomic_load(&state[j].g[0],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT)) & SCAN_TAG_MASK) != (unsigned)epoch)
               __builtin_amdgcn_s_sleep(1);
-            while (((g1 = __hip_atomic_load(&state[j].g[1],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT)) & 0xffffffffull) != (unsigned)epoch)
+            while (((g1 = __hip_atomic_load(&state[j].g[1],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT)) & SCAN_TAG_MASK) != (unsigned)epoch)
               __builtin_amdgcn_s_sleep(1);
-            while (((g2 = __hip_atomic_load(&state[j].g[2],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT)) & 0xffffffffull) != (unsigned)epoch)
+            while (((g2 = __hip_atomic_load(&state[j].g[2],__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT)) & SCAN_TAG_MASK) != (unsigned)epoch)
               __builtin_amdgcn_s_sleep(1);
-            v0 = (int64_t)(g0 >> 32); v1 = (int64_t)(g1 >> 32); v2 = (int64_t)(g2 >> 32);
+            v0 = (int64_t)(g0 >> SCAN_TAG_BITS); v1 = (int64_t)(g1 >> SCAN_TAG_BITS); v2 = (int64_t)(g2 >> SCAN_TAG_BITS);
           }
         for (int o = 32; o > 0; o >>= 1)
           { v0 += __shfl_xor(v0,o); v1 += __shfl_xor(v1,o); v2 += __shfl_xor(v2,o); }
@@ -307,7 +312,7 @@ k_prefix_caps_mb(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__re
           // the totals straight into pinned host memory, value and launch tag in one 8-byte store: the host polls for
           // them (capi.hip) instead of paying a copy engine's start-up and an interrupt's wake-up in every sub-batch
           if (host_tot)
-            __hip_atomic_store(&host_tot[q],((unsigned long long)(pre[q]+sum[q]) << 24) | ((unsigned)epoch & 0xffffffu),
+            __hip_atomic_store(&host_tot[q],((unsigned long long)(pre[q]+sum[q]) << SCAN_TAG_BITS) | (unsigned)epoch,
                                __ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -1736,7 +1741,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
       cp_cell c;
       cp_rel_init_cell(P,ld,I,i,plen,F,COV,&c);
       static_cast<cp_cell &>(S.cell[g][d][0][ld]) = c;
-      S.tr[g][d][ld] = exp(c.dp);
+      S.tr[g][d][ld] = cp_exp(c.dp);
       if (ld == 0)
         { S.parent[g][d][i] = 0xe4;                        // each state its own parent: 3,2,1,0
           S.eff[g][d][i] = (typename rel_grp_lds<MAXM,G>::eff_t)i;            // (rpos flag clear)
@@ -1747,7 +1752,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
     { double psum = 0.;
       for (int x = 0; x < 4; x++)
         psum += S.tr[g][d][x];
-      S.cell[g][d][0][ld].dp = log(S.tr[g][d][ld]/psum);
+      S.cell[g][d][0][ld].dp = cp_log(S.tr[g][d][ld]/psum);
     }
   wave_sync();
 
@@ -1803,7 +1808,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
             }
         }
       { const double A = P->logfact[f0], B = P->logfact[f1], C = P->logfact[f2];
-        const double D = (li >= 0 && li <= CP_MAX_KMER_CNT) ? P->logint[li] : log((double)li);
+        const double D = (li >= 0 && li <= CP_MAX_KMER_CNT) ? P->logint[li] : cp_log((double)li);
         if (on && live)
           { if (t_tab == CP_ERROR)
               { double po = (f0 * D - li - A)+(f1 * D - li - B)+CP_E_PO_BASE;       // prob.c:33-39 twice
@@ -1823,7 +1828,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
       if (is_sk)
         lp_sk = cp_logp_trans(P,tb,te,tcb,tce,tcov);
       if (on)
-        { if (live) { v_sk = exp(lp_sk); v_tab = exp(lp_tab); }
+        { if (live) { v_sk = cp_exp(lp_sk); v_tab = cp_exp(lp_tab); }
           if (t_sk >= 0)  S.tr[g][d][s*4+t_sk]  = v_sk;
           if (t_tab >= 0) S.tr[g][d][s*4+t_tab] = v_tab;
         }
@@ -1837,8 +1842,8 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
             { if (t_tab == CP_ERROR) v_tab = 1.;
               psum = 4.;
             }
-          if (t_sk >= 0)  nv_sk  = log(v_sk/psum);
-          if (t_tab >= 0) nv_tab = log(v_tab/psum);
+          if (t_sk >= 0)  nv_sk  = cp_log(v_sk/psum);
+          if (t_tab >= 0) nv_tab = cp_log(v_tab/psum);
         }
       wave_sync();
       if (on)

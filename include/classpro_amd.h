@@ -92,6 +92,12 @@ void cp_params_destroy(cp_params *p);
 /* Device bytes of the three look-up tables this cp_params uses (0 = that table is not in use: its values are
  * computed on the spot). */
 int  cp_params_tables(const cp_params *p, size_t *skel_bytes, size_t *uerr_bytes, size_t *petab_bytes);
+/* The device's scalar numerics, for inspection/tests: y[i] = f(x[i]) computed ON THE DEVICE by the functions the kernels
+ * call -- fn 0: exp, 1: log (csrc/cp_libm.h: glibc 2.35's routines, the libm the reference's prob.c / class_rel.c /
+ * class_unrel.c / wall.c results come from; bit-identical to the host's exp()/log() on an x86-64 host with FMA),
+ * 2: sqrt, 3: bessi(n = (int)x2[i], x[i]) (bessel.c:478-521), 4: logp_skellam(k = (int)x2[i], lambda = x[i])
+ * (prob.c:41-44).  d_x2 may be null for fn 0-2. */
+int  cp_math_eval(int fn, const double *d_x, const double *d_x2, double *d_y, int64_t n, void *stream);
 /* Host copies of the tables, for inspection/tests: cov[4]=GLOBAL_COV[E,R,H,D]; cthres is
  * [3][21][256][2][2] = [ctype][l][cout][INIT|FINAL][SELF|OTHERS]; pe is [3][21]; logfact[32768]. */
 int  cp_params_export(const cp_params *p, int *cov4, double *dr_ratio, int *cmax, double *hc_erate,
@@ -116,7 +122,14 @@ size_t cp_workspace_bytes(const cp_workspace *ws); /* device bytes currently hel
 
 /* Whole hot path for a batch: replaces the body of the read loop, ClassPro.c:229-271
  * (calc_seq_context, find_wall, find_rel_intvl, classify_rel, classify_unrel, label paint).
- * Asynchronous on `stream` except for one small D2H size read-back after the scan stage. */
+ * Asynchronous on `stream` except for one small D2H size read-back after the scan stage.
+ * A read's labels are a function of that read alone (its bases, its counts, the parameters): they do not depend on
+ * the batch it travels in, its place in it, or what lies before or after its counts in memory.  (The reference reads
+ * profile[plen] in correct_wall_cnt, wall.c:976-978, when a low-complexity run reaches the end of the read; that
+ * cell is defined as 0 here.)
+ * Limit: a batch holds at most CP_MAX_BATCH_KMERS k-mer positions (its scratch capacities, up to 16 per position,
+ * are summed in 40 bits); a larger one is refused with CP_EINVAL -- split it. */
+#define CP_MAX_BATCH_KMERS ((int64_t)1 << 35)
 int cp_classify_batch(const cp_params *p, cp_workspace *ws,
                       const char *d_seq, const int64_t *d_seq_off,
                       const uint16_t *d_prof, const int64_t *d_prof_off,

@@ -1103,8 +1103,12 @@ int cpo_find_rel_intvl(const cpo_params *p, cpo_intvl *intvl, int N, cpo_intvl *
                 if (lmax < l) lmax = l;
               }
             last = I.b+lmax;
+            /* wall.c:976-978 reads profile[plen] when the low-complexity run that starts at read base b+K-1
+               reaches the end of the read (last == plen).  In the reference that cell is whatever the thread's
+               profile buffer holds there: 0 on fresh heap (the first read of a thread), else a longer earlier
+               read's count.  DEFINED here (hazard 8): profile[plen] == 0. */
             for (int i = I.b; i < last; i++)
-              n_gain -= MAXI((int)profile[i]-profile[i+1],0);
+              n_gain -= MAXI((int)profile[i]-(i+1 < plen ? (int)profile[i+1] : 0),0);
           }
         first = MAXI(I.e-K+1,I.b);
         for (int i = first; i < I.e-1; i++)

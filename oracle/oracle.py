@@ -21,16 +21,40 @@ INTVL_DTYPE = np.dtype({
 })
 
 
+# CP_SANITIZE=1 (scripts/sanitize.sh): the restatement is built with AddressSanitizer + UBSan into its own file and
+# that file is the one loaded (the process must then run with libasan preloaded).
+_SAN = os.environ.get("CP_SANITIZE") == "1"
+_SO = "libclasspro_oracle_san.so" if _SAN else "libclasspro_oracle.so"
+
+
+def _stale(out, deps, force):
+    """Content hash of the sources kept beside the output (file times say nothing on a copied snapshot)."""
+    import hashlib
+    h = hashlib.sha1(os.path.basename(out).encode())
+    for d in deps:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    key, side = h.hexdigest(), out + ".srchash"
+    if not force and os.path.exists(out) and os.path.exists(side) and open(side).read().strip() == key:
+        return None
+    return side, key
+
+
 def build(force=False):
     """Compile the oracle (and _ref when /root/reference is present).  Building is not using."""
-    so = os.path.join(_HERE, "libclasspro_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("classpro_oracle.c", "classpro_oracle_seed.c", "classpro_oracle.h")]
-    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(x) for x in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "libclasspro_oracle.so"], stdout=subprocess.DEVNULL)
+    so = os.path.join(_HERE, _SO)
+    srcs = [os.path.join(_HERE, f) for f in ("classpro_oracle.c", "classpro_oracle_seed.c", "classpro_oracle.h", "Makefile")]
+    st = _stale(so, srcs, force)
+    if st:
+        subprocess.check_call(["make", "-B", "-C", _HERE, _SO], stdout=subprocess.DEVNULL)
+        open(st[0], "w").write(st[1] + "\n")
     ref = os.path.join(_HERE, "_ref", "libclasspro_ref.so")
     drv = os.path.join(_HERE, "ref_driver.c")
-    if os.path.exists("/root/reference/src/ClassPro.h") and (force or not os.path.exists(ref) or os.path.getmtime(ref) < os.path.getmtime(drv)):
-        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    if os.path.exists("/root/reference/src/ClassPro.h"):
+        st = _stale(ref, [drv, os.path.join(_HERE, "Makefile")], force)
+        if st:
+            subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+            open(st[0], "w").write(st[1] + "\n")
 
 
 def _p(a, t):
@@ -40,7 +64,7 @@ def _p(a, t):
 class Oracle:
     def __init__(self, K=40, read_len=20000, hcov=20, dcov=40, model=None):
         build()
-        L = C.CDLL(os.path.join(_HERE, "libclasspro_oracle.so"))
+        L = C.CDLL(os.path.join(_HERE, _SO))
         self.L = L
         L.cpo_params_new.restype = C.c_void_p
         L.cpo_params_new.argtypes = [C.c_int] * 4

@@ -16,10 +16,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# CP_SANITIZE=1 (scripts/sanitize.sh): every host helper the tests build gets AddressSanitizer + UBSan.
+SAN = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g"] if os.environ.get("CP_SANITIZE") == "1" else []
+
+
 def build_if_changed(out, cmd, deps):
     """Runs `cmd` (which writes `out`) unless `out` exists and was built from exactly these sources and this command:
     the key is a hash of the CONTENT of `deps` kept beside the output (`<out>.srchash`), not file times -- after a
     fresh checkout, or on a snapshot copied to another box, every mtime is the copy time and says nothing."""
+    if SAN and cmd[0] in ("gcc", "g++"):
+        cmd = [cmd[0]] + SAN + cmd[1:]
     h = hashlib.sha1(" ".join(cmd).encode())
     for d in sorted(deps):
         h.update(d.encode())

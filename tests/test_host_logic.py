@@ -234,6 +234,48 @@ def test_device_functions_vs_oracle_adversarial(harness):
     harness.hh_params_free(C.c_void_p(P))
 
 
+def _with_neighbour(s, p, first_count, K=40):
+    """(seq, seq_off, prof, prof_off) of a two-read batch: the read, then a neighbour whose first count is given."""
+    nb = b"ACGTTGCA" * 15
+    npf = np.full(len(nb) - K + 1, first_count, np.uint16)
+    seq = np.frombuffer(s + nb, np.uint8)
+    prof = np.concatenate([p, npf])
+    return seq, [0, len(s), len(s) + len(nb)], prof, [0, len(p), len(p) + len(npf)]
+
+
+@pytest.mark.parametrize("read_len", [20000, 2000])
+def test_tail_runs_result_is_a_function_of_the_read(harness, read_len):
+    """Hazard 8: correct_wall_cnt reads profile[plen] when a low-complexity run reaches the end of the
+    read (wall.c:976-978).  That cell is DEFINED as 0: the oracle and the product's scalar code must agree on reads
+    built to hit it, and a read's labels and interval records must not change with what follows it in a batch.
+    (Under scripts/sanitize.sh the exact-size numpy buffers of the single-read calls make any read past the end of a
+    profile a hard error in both implementations.)"""
+    from adversarial import tail_run_reads
+    seqs, profs = tail_run_reads(3, n=150)
+    O = Oracle(40, read_len, 20, 40)
+    P = harness.hh_params_new(40, read_len, 20, 40)
+    hit = rel_tail = 0
+    for s, p in zip(seqs, profs):
+        try:
+            want, iv, M = O.classify_read(s, p, want_intvl=True)
+        except OverflowError:
+            continue
+        hit += 1
+        rel_tail += int(iv[-1]["is_rel"])
+        N, lab, hiv, hriv, *_ = run_harness_read(harness, P, s, p)
+        assert lab == want and N == len(iv)
+        for f in ("b", "e", "cb", "ce", "is_rel"):
+            assert np.array_equal(hiv[f], iv[f]), f
+        rel = iv[iv["is_rel"] != 0]                   # corrected counts mean something on reliable intervals only
+        for f in ("b", "e", "ccb", "cce"):
+            assert np.array_equal(hriv[f], rel[f]), f
+        for first in (0, 1, 32767):
+            got = O.classify_batch(*_with_neighbour(s, p, first))[:len(s)].tobytes()
+            assert got == want, "labels depend on the next read's first count (%d)" % first
+    assert hit > 100 and rel_tail > 20            # the generator does reach reliable last intervals
+    harness.hh_params_free(C.c_void_p(P))
+
+
 def test_pack_bases_and_unpack_labels_host(built):
     """cp_pack_bases == Compress_Read's layout (gene_core.c:235-254; classpro_amd.dazz.pack_2bit restates it for the
     database writer) for pure upper-case ACGT and refuses anything else; cp_unpack_labels inverts the track payload."""
