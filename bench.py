@@ -65,6 +65,16 @@ def parse():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend of the barrier / max-over-ranks reduction; gloo = rehearsal of N ranks on a box with "
                          "fewer GPUs (ranks beyond the device count share device 0)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="create the process group even for one rank (--gpus 1 --backend nccl --force-dist runs the RCCL barrier and all_reduce on one device)")
+    ap.add_argument("--pcie-gbases", type=float, default=2.0,
+                    help="extras.pcie: this many Gbases of the resident set are staged in pinned host memory (bases as characters, FASTK codes) and streamed "
+                         "through the three-slot pipeline, over and over, for at least --pcie-seconds; 8 = all of configs[2]")
+    ap.add_argument("--pcie-seconds", type=float, default=1.5)
+    ap.add_argument("--pcie-batch-mbases", type=float, default=400.0)
+    ap.add_argument("--pcie-slots", type=int, default=3)
+    ap.add_argument("--pcie-pack-threads", type=int, default=8, help="host threads packing a batch's bases to 2 bits (per slot, inside the timed region)")
+    ap.add_argument("--only-pcie", action="store_true", help="skip the other extras (profiling the PCIe pipeline)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the MHC-like / PCIe / CLI extras (profiling runs)")
     return ap.parse_args()
@@ -109,8 +119,14 @@ def main():
     from classpro_amd.shard import plan_shards
     from classpro_amd._lib import lib, check
 
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:  # --force-dist without a launcher: a rendezvous of one
+            s_ = socket.socket()
+            s_.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+            s_.close()
         dist.init_process_group(a.backend, rank=rank, world_size=world)
     if a.backend == "gloo" and local >= torch.cuda.device_count():
         local = 0                                           # rehearsal: more ranks than GPUs
@@ -149,7 +165,7 @@ def main():
     nst = max(1, a.streams)
     # resident windows of the share (one when it fits), every rank the same number of them (the barriers pair up)
     nwin = max(1, -(-share // int(a.window_gbases * 1e9)))
-    if world > 1:
+    if use_dist:
         t = torch.tensor([nwin], dtype=torch.int64, device=rdev or dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         nwin = int(t.item())
@@ -157,6 +173,32 @@ def main():
     while len(windows) < nwin:
         windows.append((last, 0))
 
+    # pre-flight: a window's tensors (4 B per base: bases, 2-byte counts, labels; + offsets), the workspaces (about 11 B
+    # per base of a sub-batch each, measured: DESIGN section 2) and the tables must fit what the device has free NOW --
+    # two ranks sharing one GPU, or a window sized for another card, end here with a message instead of a raw hipMalloc
+    # failure in the middle of the run
+    win_max = max((int(ds.seq_off_all[f + c] - ds.seq_off_all[f]) for f, c in windows if c), default=0)
+    need = 4.05 * win_max + nst * 11.5 * min(win_max, a.batch_mbases * 1e6) + 1.3e9
+    torch.cuda.empty_cache()
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    sharers = 1
+    if use_dist:                                            # ranks that sit on the same card (a rehearsal) share what is free
+        pr = torch.cuda.get_device_properties(dev)
+        me = "%s/%04x:%02x:%02x" % (socket.gethostname(), pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        ids = [None] * world
+        dist.all_gather_object(ids, me)
+        sharers = ids.count(me)
+        fr = torch.tensor([free_b], dtype=torch.int64, device=rdev or dev)
+        dist.all_reduce(fr, op=dist.ReduceOp.MIN)           # (the ranks look at different moments: take the lowest figure)
+        free_b = int(fr.item()) if sharers > 1 else free_b
+    need *= sharers
+    if need > free_b:
+        sys.stderr.write("bench.py: rank %d: %d rank(s) on device %d need about %.0f GB of device memory (a %.1f-Gbase resident window + %d workspaces + "
+                         "tables each), but the device has %.0f GB free of %.0f GB: lower --window-gbases (now %.0f), or give every rank its own GPU\n"
+                         % (rank, sharers, local, need / 1e9, win_max / 1e9, nst, free_b / 1e9, total_b / 1e9, a.window_gbases))
+        if use_dist:
+            dist.destroy_process_group()
+        sys.exit(2)
     clf = Classifier(K=K, read_len=a.read_len, hcov=hcov, dcov=dcov, device=str(dev))
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nst - 1)]
     wss = [clf.ws]
@@ -189,7 +231,7 @@ def main():
                                       b.labels.data_ptr(), C.c_void_p(streams[k].cuda_stream)))
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -217,7 +259,8 @@ def main():
     # (the last window stays resident: the roofline loop, the CPU legs and the extras below run on it)
     win_bases = sum(b.total_bases for _, b in batches)
     win_kmers = sum(b.total_kmers for _, b in batches)
-    if world > 1:
+    my_dt = dt
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=rdev or dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -268,7 +311,10 @@ def main():
                 "working_set_bytes": 2.0 * win_kmers}
 
         rd0, b0 = batches[0]
-        extras = {"whole_step_algorithmic_gb_per_s": round((2.0 * my_kmers + 2.0 * my_bases) * world / (dt / a.steps) / 1e9, 1),
+        extras = {"per_gpu_mbases_per_s": round(total_bases_all * a.steps / dt / 1e6 / world, 1),
+                  "rank0_mbases_per_s_own_clock": round(my_bases * a.steps / my_dt / 1e6, 1),
+                  "process_group": ("%s, world %d" % (a.backend, world)) if use_dist else None,
+                  "whole_step_algorithmic_gb_per_s": round((2.0 * my_kmers + 2.0 * my_bases) * world / (dt / a.steps) / 1e9, 1),
                   "synth_setup_seconds": round(t_setup, 2), "gen_seconds": round(t_gen, 2), "sub_batches_per_rank": nsub,
                   "resident_windows_per_rank": len(windows), "window_gbases": round(win_bases / 1e9, 2), "streams": nst,
                   "tables_bytes": clf.tables(), "hbm_peak_allocated_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
@@ -310,7 +356,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "extras": extras,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     for w in wss[1:]:
@@ -372,6 +418,236 @@ def cpu_baseline(a, ds, batches, hcov, dcov):
             "seconds": t16["seconds"], "label_mismatches_vs_hip": mism, "legs": legs, "host_cores": ncores}
 
 
+def gpu_numa(dev):
+    """(numa node of the GPU or -1, the node's cpu set or None) from sysfs."""
+    import torch
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return node, None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        return node, cpus
+    except Exception:
+        return -1, None
+
+
+def pcie_pipeline(a, ds, clf, batches, dev):
+    """The north star's host-feed pipeline, PCIe included: reads as they come from the files -- bases as characters, FASTK
+    code strings -- sit in pinned host memory; per batch a feeder thread packs the bases to 2 bits (cp_pack_bases_batch,
+    INSIDE the timed region), sends packed bases + codes + the four offset arrays (hipMemcpyAsync), runs cp_unpack_bases,
+    cp_decode_profiles, cp_classify_batch, cp_pack_labels, and brings the 2-bit labels back; --pcie-slots batches in
+    flight (stream + workspace + staging each, a host thread per slot, as the command line has).  The span is at least
+    --pcie-seconds; the pinned-copy peaks it is judged against are measured in the same run, on the same buffers."""
+    import torch
+    import ctypes as C
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    from classpro_amd._lib import lib, check
+    L = lib()
+    res = {}
+    node, cpus = gpu_numa(dev)
+    aff0 = os.sched_getaffinity(0)
+    res["gpu_numa_node"] = node
+    res["host_cpus_allowed"] = len(aff0)
+    pinned_to = None
+    if cpus and (cpus & aff0):
+        os.sched_setaffinity(0, cpus & aff0)                # feeder / packing threads and first-touch of the pinned buffers on the GPU's node
+        pinned_to = len(cpus & aff0)
+    res["feeder_cpus_on_gpu_node"] = pinned_to
+    try:
+        # ---- stage the inputs in pinned memory (untimed) ----
+        want = int(a.pcie_gbases * 1e9)
+        parts = []
+        got = 0
+        for rd, b in batches:
+            if got >= want:
+                break
+            parts.append((rd, b))
+            got += b.total_bases
+        tgt = int(a.pcie_batch_mbases * 1e6)
+        hb = []                                             # host batches
+        pool = ThreadPoolExecutor(16)
+        for rd, b in parts:
+            so_all, po_all = rd["seq_off_h"], rd["prof_off_h"]
+            r0 = 0
+            while r0 < b.nreads and sum(x["bases"] for x in hb) < want:
+                r1 = int(np.searchsorted(so_all, so_all[r0] + tgt, side="left"))
+                r1 = min(max(r1, r0 + 1), b.nreads)
+                if b.nreads - r1 < (r1 - r0) // 4:
+                    r1 = b.nreads
+                n = r1 - r0
+                so = (so_all[r0:r1 + 1] - so_all[r0]).astype(np.int64)
+                po = (po_all[r0:r1 + 1] - po_all[r0]).astype(np.int64)
+                h_seq = torch.empty(int(so[-1]), dtype=torch.uint8).pin_memory()
+                h_seq.copy_(rd["seq"][so_all[r0]:so_all[r1]])
+                prof = rd["prof"][po_all[r0]:po_all[r1]].cpu().numpy().view(np.uint16)
+                # FASTK code strings of the reads (host encoder, 16 threads; untimed: they are what the .prof files hold)
+                bufs = [None] * n
+
+                def enc(i, prof=prof, po=po, bufs=bufs):
+                    pr_ = prof[po[i]:po[i + 1]]
+                    buf = np.empty(2 * len(pr_) + 2, np.uint8)
+                    m = L.cp_encode_profile(pr_.ctypes.data, len(pr_), buf.ctypes.data, len(buf))
+                    bufs[i] = buf[:m]
+                list(pool.map(enc, range(n), chunksize=256))
+                co = np.zeros(n + 1, np.int64)
+                np.cumsum([len(x) for x in bufs], out=co[1:])
+                h_code = torch.empty(int(co[-1]), dtype=torch.uint8).pin_memory()
+                hc_np = h_code.numpy()
+                for i in range(n):
+                    hc_np[co[i]:co[i + 1]] = bufs[i]
+                pko = np.zeros(n + 1, np.int64)
+                np.cumsum((np.diff(so) + 3) // 4, out=pko[1:])
+                offs = torch.from_numpy(np.concatenate([so, po, co, pko])).pin_memory()     # the four offset arrays, one copy
+                hb.append(dict(n=n, bases=int(so[-1]), kmers=int(po[-1]), ncode=int(co[-1]), npk=int(pko[-1]), h_seq=h_seq, h_code=h_code,
+                               offs=offs, so=so, pko=pko, src=(rd, b, r0, r1)))
+                r0 = r1
+        pool.shutdown()
+        NS = max(1, a.pcie_slots)
+        mx = lambda k: max(x[k] for x in hb)
+        sl = []
+        for _ in range(NS):
+            w = C.c_void_p()
+            check(L.cp_workspace_create(C.byref(w)))
+            sl.append(dict(st=torch.cuda.Stream(dev), ws=w,
+                           h_pk=torch.empty(mx("npk") + 64, dtype=torch.uint8).pin_memory(),
+                           h_plab=torch.empty(mx("npk") + 64, dtype=torch.uint8).pin_memory(),
+                           d_pk=torch.empty(mx("npk") + 64, dtype=torch.uint8, device=dev),
+                           d_code=torch.empty(mx("ncode") + 64, dtype=torch.uint8, device=dev),
+                           d_offs=torch.empty(4 * (mx("n") + 1), dtype=torch.int64, device=dev),
+                           d_seq=torch.empty(mx("bases") + 64, dtype=torch.uint8, device=dev),
+                           d_prof=torch.empty(mx("kmers") + 64, dtype=torch.int16, device=dev),
+                           d_lab=torch.empty(mx("bases") + 64, dtype=torch.uint8, device=dev),
+                           d_plab=torch.empty(mx("npk") + 64, dtype=torch.uint8, device=dev), t_pack=0.0, done=[]))
+
+        # ---- the pinned-copy peaks of this box, this process, these buffers ----
+        big = max(hb, key=lambda x: x["bases"])
+        dbuf = torch.empty(big["bases"], dtype=torch.uint8, device=dev)
+        hback = torch.empty(big["bases"], dtype=torch.uint8).pin_memory()
+
+        def rate(fn, nbytes, reps=6):
+            fn(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return nbytes * reps / (time.perf_counter() - t0) / 1e9
+        s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+
+        def h2d():
+            with torch.cuda.stream(s1):
+                dbuf.copy_(big["h_seq"], non_blocking=True)
+
+        def d2h():
+            with torch.cuda.stream(s2):
+                hback.copy_(dbuf, non_blocking=True)
+
+        def both():
+            h2d(); d2h()
+        res["pinned_h2d_peak_gb_per_s"] = round(rate(h2d, big["bases"]), 1)
+        res["pinned_d2h_peak_gb_per_s"] = round(rate(d2h, big["bases"]), 1)
+        res["pinned_bidirectional_gb_per_s_each_way"] = round(rate(both, big["bases"]), 1)
+        del dbuf, hback
+
+        # ---- the pipeline ----
+        def feed(k, order):
+            q = sl[k]
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(q["st"]):
+                sp = C.c_void_p(q["st"].cuda_stream)
+                for j in order:
+                    x = hb[j]
+                    n = x["n"]
+                    q["st"].synchronize()                   # the slot's previous batch has left (its labels are in h_plab)
+                    t0 = time.perf_counter()
+                    ok = L.cp_pack_bases_batch(x["h_seq"].data_ptr(), x["so"].ctypes.data, n, q["h_pk"].data_ptr(), x["pko"].ctypes.data,
+                                               a.pcie_pack_threads)
+                    q["t_pack"] += time.perf_counter() - t0
+                    if ok != 1:
+                        raise RuntimeError("the synthetic reads should be pure ACGT")
+                    q["d_pk"][:x["npk"]].copy_(q["h_pk"][:x["npk"]], non_blocking=True)
+                    q["d_code"][:x["ncode"]].copy_(x["h_code"], non_blocking=True)
+                    q["d_offs"][:4 * (n + 1)].copy_(x["offs"], non_blocking=True)
+                    o = q["d_offs"].data_ptr()
+                    d_so, d_po, d_co, d_pko = o, o + 8 * (n + 1), o + 16 * (n + 1), o + 24 * (n + 1)
+                    check(L.cp_unpack_bases(q["d_pk"].data_ptr(), d_pko, d_so, n, q["d_seq"].data_ptr(), sp))
+                    check(L.cp_decode_profiles(q["ws"], q["d_code"].data_ptr(), d_co, d_po, n, q["d_prof"].data_ptr(), sp))
+                    check(L.cp_classify_batch(clf.p, q["ws"], q["d_seq"].data_ptr(), d_so, q["d_prof"].data_ptr(), d_po, n,
+                                              x["bases"], x["kmers"], q["d_lab"].data_ptr(), sp))
+                    check(L.cp_pack_labels(q["d_lab"].data_ptr(), d_so, d_pko, n, q["d_plab"].data_ptr(), sp))
+                    q["h_plab"][:x["npk"]].copy_(q["d_plab"][:x["npk"]], non_blocking=True)
+                    q["done"].append(j)
+                q["st"].synchronize()
+
+        def run(order):
+            errs = []
+
+            def guarded(k):
+                try:
+                    feed(k, order[k::NS])
+                except Exception as e:     # noqa: BLE001
+                    errs.append(e)
+            th = [threading.Thread(target=guarded, args=(k,)) for k in range(NS)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            torch.cuda.synchronize()
+            if errs:
+                raise errs[0]
+        nbt = len(hb)
+        run(list(range(min(nbt, 2 * NS))))                  # warm-up: workspaces grow, pages are touched
+        for q in sl:
+            q["t_pack"] = 0.0
+        t0 = time.perf_counter()
+        run(list(range(nbt)))
+        t1 = time.perf_counter() - t0
+        passes = 1
+        if t1 < a.pcie_seconds:                             # repeat the staged set until the span is long enough
+            more = int(np.ceil(a.pcie_seconds / t1))
+            for q in sl:
+                q["t_pack"] = 0.0
+            t0 = time.perf_counter()
+            run(list(range(nbt)) * more)
+            t1 = time.perf_counter() - t0
+            passes = more
+        for q in sl:
+            check(L.cp_workspace_check(q["ws"]))
+        tot_bases = sum(x["bases"] for x in hb) * passes
+        in_bytes = sum(x["npk"] + x["ncode"] + 32 * (x["n"] + 1) for x in hb) * passes
+        out_bytes = sum(x["npk"] for x in hb) * passes
+        # every slot's last batch: the 2-bit labels that came back == the resident run's labels, packed by the same layout
+        ok = True
+        from classpro_amd.api import unpack_labels
+        for q in sl:
+            j = q["done"][-1]
+            x = hb[j]
+            rd, b, r0, r1 = x["src"]
+            so_all = rd["seq_off_h"]
+            want_lab = b.labels[so_all[r0]:so_all[r1]].cpu().numpy()
+            got = unpack_labels(q["h_plab"].numpy(), x["pko"], np.diff(x["so"]), K)
+            ok &= bool(np.array_equal(got, want_lab))
+        res.update({"mbases_per_s": round(tot_bases / t1 / 1e6, 1), "seconds": round(t1, 3), "bases": tot_bases,
+                    "distinct_gbases_staged": round(sum(x["bases"] for x in hb) / 1e9, 2), "passes_over_staged_set": passes,
+                    "batches": nbt * passes, "batch_mbases": round(np.mean([x["bases"] for x in hb]) / 1e6, 1), "slots": NS,
+                    "pack_threads_per_slot": a.pcie_pack_threads,
+                    "host_pack_seconds_per_slot": [round(q["t_pack"], 3) for q in sl],
+                    "bytes_per_base_in_out": [round(in_bytes / tot_bases, 3), round(out_bytes / tot_bases, 3)],
+                    "h2d_gb_per_s": round(in_bytes / t1 / 1e9, 2), "d2h_gb_per_s": round(out_bytes / t1 / 1e9, 2),
+                    "labels_match_resident_run": ok})
+        res["frac_of_pinned_h2d_peak"] = round(res["h2d_gb_per_s"] / res["pinned_h2d_peak_gb_per_s"], 3)
+        for q in sl:
+            L.cp_workspace_destroy(q["ws"])
+    finally:
+        os.sched_setaffinity(0, aff0)
+    return res
+
+
 def extra_rates(a, ds, clf, batches, hcov, dcov, dev, stream):
     """Reported beside `value`, never as `value`: the MHC-like configs[1] batch, the PCIe-inclusive rate of the
     drop-in's own transfer pattern, and the drop-in binary end to end on files in tmpfs."""
@@ -382,6 +658,13 @@ def extra_rates(a, ds, clf, batches, hcov, dcov, dev, stream):
     from classpro_amd._lib import lib, check
     L = lib()
     ex = {}
+    # the PCIe-inclusive pipeline on the bench workload itself (bases as characters + FASTK codes in pinned host memory)
+    try:
+        ex["pcie"] = pcie_pipeline(a, ds, clf, batches, dev)
+    except Exception as e:                                  # the extras never take the bench line down
+        ex["pcie_error"] = repr(e)[:300]
+    if a.only_pcie:
+        return ex
     # MHC-like set (BASELINE configs[1] stand-in): 5 Mbp x 40x = 10 000 reads, 200 Mbases, ONE batch per step
     m = DeviceSynth(genome_len=5_000_000, cov=a.cov, read_len=a.read_len, K=K, seed=a.seed, device=str(dev))
     rdm = m.reads(0, m.n_reads)
@@ -422,123 +705,6 @@ def extra_rates(a, ds, clf, batches, hcov, dcov, dev, stream):
     ex["pcie_inclusive_pinned_codes_mbases_per_s"] = round(bm.total_bases / min(ts) / 1e6, 1)
     ex["code_bytes_per_base"] = round(len(codes) / bm.total_bases, 4)
     ex["decode_matches"] = bool(torch.equal(d_prof[:bm.total_kmers], bm.prof[:bm.total_kmers]))
-    # the same transfers with three batches in flight (own stream, workspace and buffers each), as the command line
-    # keeps them: H2D of batch k+1 and D2H of batch k-1 overlap the kernels of batch k.  Sustained rate over 12 batches.
-    try:
-        NS = 3
-        sl = []
-        for _ in range(NS):
-            w = C.c_void_p()
-            check(L.cp_workspace_create(C.byref(w)))
-            sl.append(dict(st=torch.cuda.Stream(dev), ws=w, d_seq=torch.empty_like(bm.seq), d_code=torch.empty(len(codes), dtype=torch.uint8, device=dev),
-                           d_prof=torch.empty_like(bm.prof), d_lab=torch.empty_like(bm.labels),
-                           h_lab=torch.empty(bm.total_bases, dtype=torch.uint8).pin_memory()))
-
-        def run(nb):
-            for i in range(nb):
-                q = sl[i % NS]
-                q["st"].synchronize()                       # the slot's previous batch has left
-                with torch.cuda.stream(q["st"]):
-                    sp = C.c_void_p(q["st"].cuda_stream)
-                    q["d_seq"].copy_(h_seq, non_blocking=True)
-                    q["d_code"].copy_(h_code, non_blocking=True)
-                    check(L.cp_decode_profiles(q["ws"], q["d_code"].data_ptr(), d_coff.data_ptr(), bm.prof_off.data_ptr(), bm.nreads,
-                                               q["d_prof"].data_ptr(), sp))
-                    check(L.cp_classify_batch(clf.p, q["ws"], q["d_seq"].data_ptr(), bm.seq_off.data_ptr(), q["d_prof"].data_ptr(),
-                                              bm.prof_off.data_ptr(), bm.nreads, bm.total_bases, bm.total_kmers, q["d_lab"].data_ptr(), sp))
-                    q["h_lab"].copy_(q["d_lab"][:bm.total_bases], non_blocking=True)
-            torch.cuda.synchronize()
-        run(NS)
-        t0 = time.perf_counter()
-        run(12)
-        dt3 = time.perf_counter() - t0
-        for q in sl:
-            check(L.cp_workspace_check(q["ws"]))
-        ex["pcie_inclusive_3_in_flight_mbases_per_s"] = round(12 * bm.total_bases / dt3 / 1e6, 1)
-        ex["pcie_3_in_flight_labels_match"] = bool(all(np.array_equal(q["h_lab"].numpy(), h_lab.numpy()) for q in sl))
-        for q in sl:
-            L.cp_workspace_destroy(q["ws"])
-        del sl
-    except Exception as e:
-        ex["pcie_3_in_flight_error"] = repr(e)[:200]
-    # the same three-in-flight pipeline with 2-bit payloads: host-packed bases in (cp_pack_bases -> cp_unpack_bases), FASTK
-    # codes in, 2-bit labels out (cp_pack_labels; the host side's cp_unpack_labels is checked on one slot): 0.52 B/base
-    # in and 0.25 out instead of 1.27 and 1
-    try:
-        from classpro_amd.api import pack_bases, unpack_labels
-        pk = pack_bases(hm["seqs"])
-        if pk is None:
-            raise RuntimeError("the synthetic reads should be pure ACGT")
-        h_pk = torch.from_numpy(pk[0]).pin_memory()
-        d_pko = torch.from_numpy(pk[1]).to(dev)
-        npk = int(pk[1][-1])
-        NS = int(os.environ.get("CP_BENCH_SLOTS", "3"))
-        sl = []
-        for _ in range(NS):
-            w = C.c_void_p()
-            check(L.cp_workspace_create(C.byref(w)))
-            sl.append(dict(st=torch.cuda.Stream(dev), ws=w, d_pk=torch.empty(npk, dtype=torch.uint8, device=dev), d_seq=torch.empty_like(bm.seq),
-                           d_code=torch.empty(len(codes), dtype=torch.uint8, device=dev), d_prof=torch.empty_like(bm.prof),
-                           d_lab=torch.empty_like(bm.labels), d_plab=torch.empty(npk, dtype=torch.uint8, device=dev),
-                           h_plab=torch.empty(npk, dtype=torch.uint8).pin_memory()))
-
-        # one host thread per slot, as the command line has one feeder per device slot: cp_classify_batch blocks its caller
-        # once per batch (the scratch sizes come back from the device), and with a single caller the next batch's H2D
-        # copies were not even queued during that wait
-        import threading
-
-        def slot_batches(k, nb):
-            q = sl[k]
-            torch.cuda.set_device(dev)
-            with torch.cuda.stream(q["st"]):
-                sp = C.c_void_p(q["st"].cuda_stream)
-                for _ in range(nb):
-                    q["st"].synchronize()
-                    q["d_pk"].copy_(h_pk, non_blocking=True)
-                    q["d_code"].copy_(h_code, non_blocking=True)
-                    check(L.cp_unpack_bases(q["d_pk"].data_ptr(), d_pko.data_ptr(), bm.seq_off.data_ptr(), bm.nreads, q["d_seq"].data_ptr(), sp))
-                    check(L.cp_decode_profiles(q["ws"], q["d_code"].data_ptr(), d_coff.data_ptr(), bm.prof_off.data_ptr(), bm.nreads,
-                                               q["d_prof"].data_ptr(), sp))
-                    check(L.cp_classify_batch(clf.p, q["ws"], q["d_seq"].data_ptr(), bm.seq_off.data_ptr(), q["d_prof"].data_ptr(),
-                                              bm.prof_off.data_ptr(), bm.nreads, bm.total_bases, bm.total_kmers, q["d_lab"].data_ptr(), sp))
-                    check(L.cp_pack_labels(q["d_lab"].data_ptr(), bm.seq_off.data_ptr(), d_pko.data_ptr(), bm.nreads, q["d_plab"].data_ptr(), sp))
-                    q["h_plab"].copy_(q["d_plab"], non_blocking=True)
-                q["st"].synchronize()
-
-        def run2(nb):
-            errs = []
-
-            def guarded(k):
-                try:
-                    slot_batches(k, nb // NS)
-                except Exception as e:     # noqa: BLE001
-                    errs.append(e)
-            th = [threading.Thread(target=guarded, args=(k,)) for k in range(NS)]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-            torch.cuda.synchronize()
-            if errs:
-                raise errs[0]
-        run2(NS)
-        t0 = time.perf_counter()
-        NB2 = 36 // NS * NS                                   # (12 batches = 40 ms: too short a span to repeat within 10 %)
-        run2(NB2)
-        dt2 = time.perf_counter() - t0
-        for q in sl:
-            check(L.cp_workspace_check(q["ws"]))
-        ex["pcie_inclusive_2bit_3_in_flight_mbases_per_s"] = round(NB2 * bm.total_bases / dt2 / 1e6, 1)
-        ex["pcie_2bit_slots"] = NS
-        ex["pcie_2bit_bytes_per_base_in_out"] = [round((npk + len(codes)) / bm.total_bases, 3), round(npk / bm.total_bases, 3)]
-        got = unpack_labels(sl[0]["h_plab"].numpy(), pk[1], np.diff(rdm["seq_off_h"]), K)
-        ex["pcie_2bit_labels_match"] = bool(np.array_equal(got, h_lab.numpy())
-                                            and all(torch.equal(q["h_plab"], sl[0]["h_plab"]) for q in sl))
-        for q in sl:
-            L.cp_workspace_destroy(q["ws"])
-        del sl, h_pk
-    except Exception as e:
-        ex["pcie_2bit_error"] = repr(e)[:200]
     del m, rdm, bm, d_prof, h_seq, h_code, h_lab
 
     # BASELINE configs[4] stand-in: 60x, r=25000, with the -s seed path (cp_find_seeds_batch after the classification)

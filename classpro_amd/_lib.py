@@ -15,7 +15,7 @@ SYMBOLS = [
     "cp_workspace_bytes", "cp_classify_batch", "cp_workspace_check", "cp_run_stages", "cp_get_counts",
     "cp_get_intervals", "cp_get_rel_asgn", "cp_get_bitmap", "cp_seq_context", "cp_scan_candidates",
     "cp_encode_profile", "cp_decode_profiles", "cp_params_create_model", "cp_load_error_model", "cp_unpack_bases",
-    "cp_find_seeds_batch", "cp_get_rep_masks", "cp_rep_masks_capacity", "cp_params_tables", "cp_pack_bases", "cp_pack_labels", "cp_unpack_labels", "cp_math_eval",
+    "cp_find_seeds_batch", "cp_get_rep_masks", "cp_rep_masks_capacity", "cp_params_tables", "cp_pack_bases", "cp_pack_labels", "cp_unpack_labels", "cp_math_eval", "cp_pack_bases_batch",
 ]
 
 _lib = None
@@ -56,6 +56,7 @@ def lib():
     L.cp_params_tables.argtypes = [vp, vp, vp, vp]
     L.cp_math_eval.argtypes = [i32, vp, vp, vp, i64, vp]
     L.cp_pack_bases.argtypes = [vp, i32, vp]
+    L.cp_pack_bases_batch.argtypes = [vp, vp, i32, vp, vp, i32]
     L.cp_pack_labels.argtypes = [vp, vp, vp, i32, vp, vp]
     L.cp_unpack_labels.argtypes = [vp, i32, i32, vp]
     L.cp_decode_profile.argtypes = [vp, i64, vp, i32]

@@ -9,6 +9,7 @@
 #include <mutex>
 #include <vector>
 #include <chrono>
+#include <thread>
 #include <time.h>
 #include "cp_host_setup.h"
 #include "kernels.hip"
@@ -822,9 +823,48 @@ extern "C" int cp_unpack_labels(const uint8_t *packed, int rlen, int K, char *la
 // consists of upper-case A, C, G, T only.  Returns 1 (packed: (rlen+3)/4 bytes written) or 0 (another letter: the read
 // -- and the batch it is in -- goes to the device as characters; the context scans compare raw characters,
 // context.c:8-108, so a lower-case or ambiguous base must arrive as it is).
+// 32 bases per step with AVX2 + BMI2 where the host has them (every x86-64 server a MI355X sits in does): the feeder packs
+// a batch's bases while the previous batch is on the wire, and a byte-at-a-time table walk (0.5 GB/s per thread) would
+// be the slowest stage of the PCIe pipeline.  (b >> 1) & 3 maps A C G T to 0 1 3 2; x ^ (x >> 1) turns that into the
+// Dazzler codes 0 1 2 3; a letter is valid iff "ACTG"[(b >> 1) & 3] == b.  Returns the number of bases packed (a
+// multiple of 32; the caller finishes the tail), or -1 at the first group holding another letter.
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2,bmi2"))) static int64_t pack_bases_avx2(const char *seq, int64_t n, uint8_t *packed)
+{ const __m256i tab = _mm256_setr_epi8('A','C','T','G',0,0,0,0,0,0,0,0,0,0,0,0, 'A','C','T','G',0,0,0,0,0,0,0,0,0,0,0,0);
+  const __m256i three = _mm256_set1_epi8(3);
+  int64_t i = 0;
+  for (; i+32 <= n; i += 32)
+    { const __m256i b = _mm256_loadu_si256((const __m256i *)(seq+i));
+      const __m256i idx = _mm256_and_si256(_mm256_srli_epi16(b,1),three);
+      if (_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_shuffle_epi8(tab,idx),b)) != -1) return -1;
+      const __m256i code = _mm256_xor_si256(idx,_mm256_and_si256(_mm256_srli_epi16(idx,1),_mm256_set1_epi8(1)));
+      uint64_t q[4];
+      _mm256_storeu_si256((__m256i *)q,code);
+      for (int k = 0; k < 4; k++)                             // 8 codes (one per byte, little end first) -> 16 bits, first base on top
+        { const uint64_t v = __builtin_bswap64(q[k]);        // first base in the top byte
+          const uint32_t w = (uint32_t)_pext_u64(v,0x0303030303030303ull);   // 16 bits, first base in bits 15:14
+          packed[(i >> 2)+2*k]   = (uint8_t)(w >> 8);
+          packed[(i >> 2)+2*k+1] = (uint8_t)w;
+        }
+    }
+  return i;
+}
+#endif
+
 extern "C" int cp_pack_bases(const char *seq, int rlen, uint8_t *packed)
 { if (rlen < 0 || (rlen > 0 && (!seq || !packed)))
     return set_err(CP_EINVAL,"cp_pack_bases: bad argument");
+#if defined(__x86_64__)
+  static const bool fast = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2");
+  if (fast && rlen >= 64)
+    { const int64_t done = pack_bases_avx2(seq,rlen,packed);
+      if (done < 0) return 0;
+      if (done == rlen) return 1;
+      const int rc = cp_pack_bases(seq+done,(int)(rlen-done),packed+(done >> 2));   // the tail (< 32 bases) by the table
+      return rc;
+    }
+#endif
   static const signed char code[256] = {
 #define X -1
     X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,
@@ -850,6 +890,41 @@ extern "C" int cp_pack_bases(const char *seq, int rlen, uint8_t *packed)
       packed[i >> 2] = (uint8_t)v;
     }
   return bad < 0 ? 0 : 1;
+}
+
+// cp_pack_bases for every read of a batch on `nthreads` host threads (contiguous read ranges, balanced by bases): the
+// host side of the 2-bit payload, called by a feeder on the pinned staging buffer it is about to send.
+extern "C" int cp_pack_bases_batch(const char *seq, const int64_t *seq_off, int nreads, uint8_t *packed, const int64_t *pack_off,
+                                   int nthreads)
+{ if (nreads < 0 || (nreads > 0 && (!seq || !seq_off || !packed || !pack_off)))
+    return set_err(CP_EINVAL,"cp_pack_bases_batch: bad argument");
+  if (nreads == 0) return 1;
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > nreads) nthreads = nreads;
+  std::vector<int> ok((size_t)nthreads,1);
+  auto work = [&](int t)
+    { const int64_t b0 = seq_off[0], tot = seq_off[nreads]-b0;
+      // first read whose start is at or beyond t/nthreads of the bases
+      auto cut = [&](int q) -> int
+        { const int64_t want = b0+tot*q/nthreads;
+          int lo = 0, hi = nreads;
+          while (lo < hi) { const int m = (lo+hi) >> 1; if (seq_off[m] < want) lo = m+1; else hi = m; }
+          return lo;
+        };
+      const int r0 = t == 0 ? 0 : cut(t), r1 = t == nthreads-1 ? nreads : cut(t+1);
+      int good = 1;
+      for (int r = r0; r < r1; r++)
+        good &= cp_pack_bases(seq+seq_off[r],(int)(seq_off[r+1]-seq_off[r]),packed+pack_off[r]) == 1;
+      ok[(size_t)t] = good;
+    };
+  if (nthreads == 1) work(0);
+  else
+    { std::vector<std::thread> th;
+      for (int t = 0; t < nthreads; t++) th.emplace_back(work,t);
+      for (auto &x : th) x.join();
+    }
+  for (int v : ok) if (!v) return 0;
+  return 1;
 }
 
 extern "C" int cp_seq_context(const char *d_seq, const int64_t *d_seq_off, int nreads, int64_t total_bases,

@@ -35,6 +35,11 @@ constexpr double   log_tab[256] = CP_LOG_TAB_INIT;
 CP_HD uint64_t cp_asuint64(double x) { return __builtin_bit_cast(uint64_t,x); }
 CP_HD double   cp_asdouble(uint64_t u) { return __builtin_bit_cast(double,u); }
 
+#ifdef CP_LIBM_OCML                        // diagnostic builds only (scripts/build_diag.sh): ROCm's ocml routines, to time the difference
+#include <math.h>
+CP_HD double cp_exp(double x) { return exp(x); }
+CP_HD double cp_log(double x) { return log(x); }
+#else
 // e_exp.c: exp(x) = 2^(k/128) * exp(r), x = k ln2/128 + r, |r| <= ln2/256; 2^(k/128) ~= scale*(1+tail) from the table
 CP_HD double cp_exp(double x)
 { const uint64_t ix = cp_asuint64(x);
@@ -149,3 +154,4 @@ CP_HD double cp_log(double x)
   const double y = __builtin_fma(rr2,p,lo);
   return y+hi;
 }
+#endif

@@ -162,6 +162,10 @@ int  cp_unpack_bases(const uint8_t *d_packed, const int64_t *d_pack_off, const i
  * cp_unpack_bases).  cp_unpack_labels (host) is the inverse for one read: K-1 'N', then E/R/H/D (stoc, const.c:19).
  * A batch then crosses PCIe at about 0.52 B/base in (bases + FASTK codes) and 0.25 B/base out instead of 1.27 and 1. */
 int cp_pack_bases(const char *seq, int rlen, uint8_t *packed);
+/* cp_pack_bases for every read of a host batch on `nthreads` host threads: read r's (rlen_r+3)/4 bytes go to
+ * packed[pack_off[r]]; 1 = every read packed, 0 = a read holds another letter (send the batch as characters). */
+int cp_pack_bases_batch(const char *seq, const int64_t *seq_off, int nreads, uint8_t *packed, const int64_t *pack_off,
+                        int nthreads);
 int cp_pack_labels(const char *d_labels, const int64_t *d_seq_off, const int64_t *d_pack_off, int nreads,
                    uint8_t *d_packed, void *stream);
 int cp_unpack_labels(const uint8_t *packed, int rlen, int K, char *labels);

@@ -40,14 +40,24 @@ agg = collections.defaultdict(list)
 grid = {}
 for kind in ("fetch", "write"):
     for r in csv.DictReader(open(newest(os.path.join(src, kind, "*", "*_counter_collection.csv")))):
-        agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        k = r["Kernel_Name"].split("(")[0]
+        if k.startswith("void "):                          # template kernels: "void k_classify_rel_grp<0, 128, 4>"
+            k = k[5:]
+        agg[(k.replace(" ", ""), r["Counter_Name"])].append(float(r["Counter_Value"]))
 with open(os.path.join(dst, name + "_pmc.txt"), "w") as f:
     f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 1 --warmup 1 --no-cpu --no-extras`\n")
     f.write("# values in KiB per dispatch as reported; gfx950 correction for streaming reads: bytes = 2*FETCH_SIZE*1024\n")
-    f.write("%-28s %-11s %6s %14s %14s %14s\n" % ("kernel", "counter", "n", "avg_KiB", "min_KiB", "max_KiB"))
+    f.write("%-36s %-11s %6s %14s %14s %14s\n" % ("kernel", "counter", "n", "avg_KiB", "min_KiB", "max_KiB"))
+    tot = collections.Counter()
+    nsub = max(1, len(agg[("k_find_wall", "FETCH_SIZE")]))      # sub-batches in the run (the scan also runs in the roofline loop)
     for (k, c), v in sorted(agg.items()):
-        if k.startswith("k_"):
-            f.write("%-28s %-11s %6d %14.1f %14.1f %14.1f\n" % (k, c, len(v), sum(v) / len(v), min(v), max(v)))
+        if k.startswith("k_") and "_table" not in k and not k.startswith("k_sg_"):
+            f.write("%-36s %-11s %6d %14.1f %14.1f %14.1f\n" % (k, c, len(v), sum(v) / len(v), min(v), max(v)))
+            tot[c] += sum(v) / len(v) if k == "k_scan_candidates" else sum(v) / nsub
+    f.write("# sum over the product kernels per sub-batch (%d sub-batches in the run; only the scan's FETCH_SIZE is\n" % nsub)
+    f.write("# doubled: the x2 is calibrated for 16-B-per-lane streaming reads, the other kernels' access widths are not):\n")
+    scan_f = sum(agg[("k_scan_candidates", "FETCH_SIZE")]) / len(agg[("k_scan_candidates", "FETCH_SIZE")])
+    f.write("#   FETCH_SIZE %.0f KiB raw, %.0f KiB with the scan doubled; WRITE_SIZE %.0f KiB\n" % (tot["FETCH_SIZE"], tot["FETCH_SIZE"] + scan_f, tot["WRITE_SIZE"]))
 fs = agg[("k_scan_candidates", "FETCH_SIZE")]
 wsz = agg[("k_scan_candidates", "WRITE_SIZE")]
 fetch = 2.0 * 1024 * sum(fs) / len(fs)

@@ -292,6 +292,26 @@ def test_pack_bases_and_unpack_labels_host(built):
     for bad in (b"ACGN", b"acgt", b"ACGTACGU", b"AC-T", b"ACG\x00"):
         assert pack_bases([seqs[5], bad]) is None
     assert pack_bases([b""])[1].tolist() == [0, 0]
+    # the 32-bases-per-step path (reads of >= 64 bases): every length mod 32, a foreign letter at every place of a group,
+    # and the threaded batch call against the read-by-read one
+    from classpro_amd._lib import lib
+    L = lib()
+    long_reads = [bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 64 + n)]) for n in range(70)] + [b"", b"A"]
+    pk, off = pack_bases(long_reads)
+    for i, s_ in enumerate(long_reads):
+        assert np.array_equal(pk[off[i]:off[i + 1]], dazz.pack_2bit(code[np.frombuffer(s_, np.uint8)])), i
+    for pos in range(0, 96):
+        for ch in (b"N", b"a", b"U", b"\x00", b"\xc1"):
+            bad = bytearray(long_reads[40]); bad[pos] = ch[0]
+            assert pack_bases([bytes(bad)]) is None, (pos, ch)
+    seq = np.frombuffer(b"".join(long_reads), np.uint8)
+    so = np.concatenate([[0], np.cumsum([len(x) for x in long_reads])]).astype(np.int64)
+    for nt in (1, 3, 8, 200):
+        out = np.zeros(int(off[-1]) + 1, np.uint8)
+        assert L.cp_pack_bases_batch(seq.ctypes.data, so.ctypes.data, len(long_reads), out.ctypes.data, off.ctypes.data, nt) == 1
+        assert np.array_equal(out[:off[-1]], pk[:off[-1]]), nt
+    seq2 = seq.copy(); seq2[so[33] + 5] = ord("N")
+    assert L.cp_pack_bases_batch(seq2.ctypes.data, so.ctypes.data, len(long_reads), out.ctypes.data, off.ctypes.data, 4) == 0
     # labels: K-1 'N', then E/R/H/D from the 2-bit codes (0,1,2,3), whatever sits in the N part and the padding
     K = 7
     for n in (1, 5, 6, 7, 8, 9, 100, 1001):
