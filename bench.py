@@ -71,8 +71,8 @@ def parse():
                     help="extras.pcie: this many Gbases of the resident set are staged in pinned host memory (bases as characters, FASTK codes) and streamed "
                          "through the three-slot pipeline, over and over, for at least --pcie-seconds; 8 = all of configs[2]")
     ap.add_argument("--pcie-seconds", type=float, default=1.5)
-    ap.add_argument("--pcie-batch-mbases", type=float, default=400.0)
-    ap.add_argument("--pcie-slots", type=int, default=3)
+    ap.add_argument("--pcie-batch-mbases", type=float, default=250.0)
+    ap.add_argument("--pcie-slots", type=int, default=6)
     ap.add_argument("--pcie-pack-threads", type=int, default=8, help="host threads packing a batch's bases to 2 bits (per slot, inside the timed region)")
     ap.add_argument("--only-pcie", action="store_true", help="skip the other extras (profiling the PCIe pipeline)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -515,7 +515,7 @@ def pcie_pipeline(a, ds, clf, batches, dev):
             w = C.c_void_p()
             check(L.cp_workspace_create(C.byref(w)))
             sl.append(dict(st=torch.cuda.Stream(dev), ws=w,
-                           h_pk=torch.empty(mx("npk") + 64, dtype=torch.uint8).pin_memory(),
+                           h_pk=[torch.empty(mx("npk") + 64, dtype=torch.uint8).pin_memory() for _ in range(2)], flip=0,
                            h_plab=torch.empty(mx("npk") + 64, dtype=torch.uint8).pin_memory(),
                            d_pk=torch.empty(mx("npk") + 64, dtype=torch.uint8, device=dev),
                            d_code=torch.empty(mx("ncode") + 64, dtype=torch.uint8, device=dev),
@@ -563,14 +563,18 @@ def pcie_pipeline(a, ds, clf, batches, dev):
                 for j in order:
                     x = hb[j]
                     n = x["n"]
-                    q["st"].synchronize()                   # the slot's previous batch has left (its labels are in h_plab)
+                    # the slot has two staging buffers: this batch's bases are packed while the slot's previous batch is still
+                    # on the device (its H2D copy left the other buffer long ago: the batch before it had to finish first)
+                    h_pk = q["h_pk"][q["flip"]]
+                    q["flip"] ^= 1
                     t0 = time.perf_counter()
-                    ok = L.cp_pack_bases_batch(x["h_seq"].data_ptr(), x["so"].ctypes.data, n, q["h_pk"].data_ptr(), x["pko"].ctypes.data,
+                    ok = L.cp_pack_bases_batch(x["h_seq"].data_ptr(), x["so"].ctypes.data, n, h_pk.data_ptr(), x["pko"].ctypes.data,
                                                a.pcie_pack_threads)
                     q["t_pack"] += time.perf_counter() - t0
                     if ok != 1:
                         raise RuntimeError("the synthetic reads should be pure ACGT")
-                    q["d_pk"][:x["npk"]].copy_(q["h_pk"][:x["npk"]], non_blocking=True)
+                    q["st"].synchronize()                   # the slot's previous batch has left (its labels are in h_plab)
+                    q["d_pk"][:x["npk"]].copy_(h_pk[:x["npk"]], non_blocking=True)
                     q["d_code"][:x["ncode"]].copy_(x["h_code"], non_blocking=True)
                     q["d_offs"][:4 * (n + 1)].copy_(x["offs"], non_blocking=True)
                     o = q["d_offs"].data_ptr()
