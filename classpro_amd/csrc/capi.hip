@@ -534,24 +534,31 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
                      p->dev,d_seq,d_seq_off,d_prof,d_prof_off,nreads,(const uint64_t *)ws->bitmap.p,(uint8_t *)ws->wall.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->perm.p,(int32_t *)ws->wlist.p,(task_res *)ws->tres.p,
                      (int32_t *)ws->fwc.p);
+  // find_rel_intvl inside k_find_wall (CLASSPRO_FUSE_REL=0: as a kernel of its own, always so when the call stops at
+  // the wall stage: the stage API shows find_wall's records as the reference's find_wall leaves them)
+  static const bool fuse_env = []{ const char *e = getenv("CLASSPRO_FUSE_REL"); return !e || atol(e) != 0; }();
+  const bool fuse_rel = fuse_env && last_stage >= CP_STAGE_REL;
+  ENSURE(ws->rintvl,(size_t)totalI*sizeof(cp_intvl));
+  ENSURE(ws->relmap,(size_t)totalI*4);
   hipLaunchKernelGGL(k_find_wall,dim3(nreads),dim3(WAVE),0,st,
                      p->dev,d_seq,d_seq_off,d_prof,d_prof_off,nreads,
                      (uint8_t *)ws->wall.p,(uint8_t *)ws->wall_s.p,(int32_t *)ws->hkeys.p,(double *)ws->hvals.p,(const int64_t *)ws->hoff.p,
                      (cp_eintvl *)ws->eintvl.p,(cp_eintvl *)ws->ointvl.p,
                      (const int64_t *)ws->eoff.p,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,
                      (int32_t *)ws->nintvl.p,(int32_t *)ws->err.p,(const int32_t *)ws->perm.p,(int32_t *)ws->wlist.p,
-                     (const task_res *)ws->tres.p,(const int32_t *)ws->fwc.p);
+                     (const task_res *)ws->tres.p,(const int32_t *)ws->fwc.p,
+                     (cp_intvl *)ws->rintvl.p,(int32_t *)ws->relmap.p,(int32_t *)ws->nrel.p,fuse_rel ? 1 : 0);
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_WALL)
     return CP_OK;
 
-  // ---- stage 3: find_rel_intvl -------------------------------------------------------------------
-  ENSURE(ws->rintvl,(size_t)totalI*sizeof(cp_intvl));
-  ENSURE(ws->relmap,(size_t)totalI*4);
-  hipLaunchKernelGGL(k_find_rel,dim3(nreads),dim3(WAVE),0,st,
-                     p->dev,d_seq,d_seq_off,d_prof,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,
-                     (int32_t *)ws->relmap.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,(int32_t *)ws->nrel.p);
-  HIPCHK(hipGetLastError());
+  // ---- stage 3: find_rel_intvl (on the whole-path call: done by k_find_wall on the records it emits) ----------
+  if (!fuse_rel)
+    { hipLaunchKernelGGL(k_find_rel,dim3(nreads),dim3(WAVE),0,st,
+                         p->dev,d_seq,d_seq_off,d_prof,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,
+                         (int32_t *)ws->relmap.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,(int32_t *)ws->nrel.p);
+      HIPCHK(hipGetLastError());
+    }
   if (last_stage == CP_STAGE_REL)
     return CP_OK;
 
@@ -576,11 +583,12 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->parent.p,(int32_t *)ws->eff.p,
                      (uint8_t *)ws->rpos.p,(int8_t *)ws->asgn.p,totalI);
-  hipLaunchKernelGGL((k_classify_rel_grp<REL_SMALL_MAXM,1024,1>),dim3(nreads < 2048 ? nreads : 2048),dim3(WAVE),0,ws->aux,
+  hipLaunchKernelGGL((k_classify_rel_grp<REL_SMALL_MAXM,1024,1,1>),dim3(nreads < 2048 ? nreads : 2048),dim3(WAVE),0,ws->aux,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI,(const int32_t *)ws->perm.p);
   HIPCHK(hipEventRecord(ws->ev_join,ws->aux));
-  hipLaunchKernelGGL((k_classify_rel_grp<0,REL_SMALL_MAXM,REL_SMALL_G>),dim3((nreads+REL_SMALL_G-1)/REL_SMALL_G),dim3(WAVE),0,st,
+  hipLaunchKernelGGL((k_classify_rel_grp<0,REL_SMALL_MAXM,REL_SMALL_G,REL_SMALL_WPB>),
+                     dim3((nreads+REL_SMALL_G*REL_SMALL_WPB-1)/(REL_SMALL_G*REL_SMALL_WPB)),dim3(WAVE*REL_SMALL_WPB),0,st,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI,(const int32_t *)ws->perm.p);
   HIPCHK(hipStreamWaitEvent(st,ws->ev_join,0));

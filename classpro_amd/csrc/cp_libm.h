@@ -39,9 +39,12 @@ CP_HD double   cp_asdouble(uint64_t u) { return __builtin_bit_cast(double,u); }
 #include <math.h>
 CP_HD double cp_exp(double x) { return exp(x); }
 CP_HD double cp_log(double x) { return log(x); }
+template <class TAB> CP_HD double cp_exp_t(double x, TAB) { return exp(x); }
+template <class TAB> CP_HD double cp_log_t(double x, TAB) { return log(x); }
 #else
 // e_exp.c: exp(x) = 2^(k/128) * exp(r), x = k ln2/128 + r, |r| <= ln2/256; 2^(k/128) ~= scale*(1+tail) from the table
-CP_HD double cp_exp(double x)
+template <class TAB>
+CP_HD double cp_exp_t(double x, TAB exp_tab)
 { const uint64_t ix = cp_asuint64(x);
   uint32_t abstop = (uint32_t)(ix >> 52) & 0x7ff;
   if (abstop-0x3c9u >= 0x3fu)                                   // |x| < 2^-54 or |x| >= 512 or not finite
@@ -61,8 +64,8 @@ CP_HD double cp_exp(double x)
   r = __builtin_fma(kd,CP_EXP_NEGLN2LON,r);
   const uint64_t idx = 2*(ki & 127);
   const uint64_t top = ki << 45;
-  const double tail = cp_asdouble(cp_libm::exp_tab[idx]);
-  uint64_t sbits = cp_libm::exp_tab[idx+1]+top;
+  const double tail = cp_asdouble(exp_tab[idx]);
+  uint64_t sbits = exp_tab[idx+1]+top;
   const double r2 = r*r;
   const double p23 = __builtin_fma(r,CP_EXP_C3,CP_EXP_C2);
   const double p45 = __builtin_fma(r,CP_EXP_C5,CP_EXP_C4);
@@ -96,7 +99,12 @@ CP_HD double cp_exp(double x)
 
 // e_log.c: x = 2^k z, z in [0x1.6p-1, 0x1.6p0); log(x) = log1p(z/c-1) + log(c) + k ln2 with c near the centre of z's
 // subinterval (128 of them); arguments near 1 take a degree-12 polynomial with a double-double head instead
-CP_HD double cp_log(double x)
+// (the table through a pointer of the caller's choosing: a kernel whose DP step has exp -> log on its critical path keeps
+//  a copy of both tables in LDS -- from global memory each look-up is a dependent cache miss in the middle of the chain)
+CP_HD double cp_exp(double x) { return cp_exp_t(x,cp_libm::exp_tab); }
+
+template <class TAB>
+CP_HD double cp_log_t(double x, TAB log_tab)
 { uint64_t ix = cp_asuint64(x);
   const uint32_t top = (uint32_t)(ix >> 48);
   if (ix-0x3fee000000000000ull < 0x3090000000000ull)            // 1-2^-4 <= x < 1+0x1.09p-4
@@ -136,7 +144,7 @@ CP_HD double cp_log(double x)
   const int i = (int)((tmp >> 45) & 127);
   const int k = (int)((int64_t)tmp >> 52);
   const uint64_t iz = ix-(tmp & 0xfff0000000000000ull);
-  const double invc = cp_libm::log_tab[2*i], logc = cp_libm::log_tab[2*i+1];
+  const double invc = log_tab[2*i], logc = log_tab[2*i+1];
   const double z = cp_asdouble(iz);
   const double r = __builtin_fma(z,invc,-1.0);
   const double kd = (double)k;
@@ -154,4 +162,5 @@ CP_HD double cp_log(double x)
   const double y = __builtin_fma(rr2,p,lo);
   return y+hi;
 }
+CP_HD double cp_log(double x) { return cp_log_t(x,cp_libm::log_tab); }
 #endif

@@ -798,6 +798,112 @@ __device__ __forceinline__ void fr_seq_win_load(cp_seq_lwin &sq, char *row, int 
   sq.lo = lo; sq.len = len;
 }
 
+// ---- correct_wall_cnt (wall.c:960-1014) from count windows in registers ----------------------------------------------
+// cp_rel_interval (cp_wall.h) walks its four step sums eight counts per load, each load waiting for the one before: a
+// dozen dependent round trips per interval, which is what k_find_rel spent its time on.  Here the 64 counts after the
+// interval's begin and the 64 before its end are fetched by sixteen independent 16-byte loads issued together, and the
+// sums are taken from the registers; a range that leaves its window (K > 57, a low-complexity run of more than 63
+// bases) takes cp_sum_steps as before.  Counts outside [0,plen) read 0 -- which is also hazard 8's value of profile[plen].
+struct cp_win64 { uint32_t w[32]; };                     // count q of the window = (w[q >> 1] >> 16*(q & 1)) & 0xffff
+struct __attribute__((packed, aligned(2))) cp_u32x4u { uint32_t v[4]; };
+__device__ __forceinline__ void win64_load(cp_win64 &W, const uint16_t *__restrict__ prof, int lo, int plen)
+{ if (lo >= 0 && lo+64 <= plen)
+    {
+#pragma unroll
+      for (int c = 0; c < 8; c++)
+        { const cp_u32x4u x = *reinterpret_cast<const cp_u32x4u *>(prof+lo+8*c);
+          W.w[4*c] = x.v[0]; W.w[4*c+1] = x.v[1]; W.w[4*c+2] = x.v[2]; W.w[4*c+3] = x.v[3];
+        }
+    }
+  else
+    {
+#pragma unroll
+      for (int q = 0; q < 32; q++)
+        { const int a = lo+2*q;
+          const uint32_t x0 = (a >= 0 && a < plen) ? prof[a] : 0u, x1 = (a+1 >= 0 && a+1 < plen) ? prof[a+1] : 0u;
+          W.w[q] = x0 | (x1 << 16);
+        }
+    }
+}
+// up = sum over steps q -> q+1, q in [u0,u1), of the upward steps; down = the same over [d0,d1) of the downward steps
+__device__ __forceinline__ void win64_sums(const cp_win64 &W, int u0, int u1, int d0, int d1, int &up, int &down)
+{ const uint64_t um = (u1 > u0) ? ((u1-u0 >= 64 ? ~0ull : ((1ull << (u1-u0))-1)) << u0) : 0ull;
+  const uint64_t dm = (d1 > d0) ? ((d1-d0 >= 64 ? ~0ull : ((1ull << (d1-d0))-1)) << d0) : 0ull;
+  int prev = (int)(W.w[0] & 0xffffu);
+  up = 0; down = 0;
+#pragma unroll
+  for (int q = 0; q < 63; q++)
+    { const int cur = (int)((W.w[(q+1) >> 1] >> (16*((q+1) & 1))) & 0xffffu);
+      const int d = cur-prev;
+      const int pos = d > 0 ? d : 0, neg = d < 0 ? -d : 0;
+      up   += pos*(int)((um >> q) & 1);
+      down += neg*(int)((dm >> q) & 1);
+      prev = cur;
+    }
+}
+
+// cp_rel_interval with the window sums; same filters, same order, same results (tests: stage parity, neighbours)
+template <class SEQB, class SEQE>
+__device__ __forceinline__ bool cp_rel_interval_win(const cp_dev_params *P, const uint16_t *__restrict__ prof, const SEQB &seq_b, const SEQE &seq_e,
+                                                    int rlen, cp_intvl *I, int idx)
+{ const int K = P->K;
+  const int b = I->b, e = I->e;
+  if (e-b < K)
+    return false;
+  if ((I->cb > I->ce ? I->cb : I->ce) >= P->cov[CP_REPEAT])
+    return false;
+  if (I->pe >= P->log_pe_final)
+    return false;
+  const int plen = rlen-(K-1);
+  cp_win64 W1, W2;
+  win64_load(W1,prof,b,plen);
+  win64_load(W2,prof,e-64,plen);
+  int lmax1 = 0, lmax2 = 0;                              // (the context scans run while the windows are on their way)
+  if (b+K-1 < e)
+    for (int t = 0; t < 3; t++)
+      { const int l = cp_rctx(seq_b,rlen,b+K-1,t)*(t+1);
+        if (lmax1 < l) lmax1 = l;
+      }
+  if (b < e-K+1)
+    for (int t = 0; t < 3; t++)
+      { const int l = cp_lctx(seq_e,rlen,(e-K+1)+K-2,t)*(t+1);
+        if (lmax2 < l) lmax2 = l;
+      }
+  int n_gain = 0, n_drop = 0;
+  { const int last1 = (b+K-1 < e-1) ? b+K-1 : e-1;       // up-steps over [b,last1), down-steps over [b,b+lmax1)
+    const int n1 = last1-b, n2 = (b+K-1 < e) ? lmax1 : 0;
+    int up, down;
+    win64_sums(W1,0,n1 <= 63 ? n1 : 0,0,n2 <= 63 ? n2 : 0,up,down);
+    if (n1 > 63) up = cp_sum_steps(prof,b,last1,plen,+1);
+    if (n2 > 63) down = cp_sum_steps(prof,b,b+lmax1,plen,-1);
+    n_gain = up-down;
+  }
+  { const int first1 = (e-K+1 > b) ? e-K+1 : b;          // down-steps over [first1,e-1), up-steps over [e-lmax2,e-1)
+    const int lo = e-64;
+    const bool has2 = b < e-K+1;
+    const int first2 = e-lmax2;
+    int up, down;
+    const bool in1 = first1 >= lo, in2 = !has2 || first2 >= lo;
+    win64_sums(W2,(has2 && in2) ? first2-lo : 0,(has2 && in2) ? 63 : 0,in1 ? first1-lo : 0,in1 ? 63 : 0,up,down);
+    if (!in1) down = cp_sum_steps(prof,first1,e-1,plen,-1);
+    if (has2 && !in2) up = cp_sum_steps(prof,first2,e-1,plen,+1);
+    n_drop = down-up;
+  }
+  int ccb = I->cb+(n_gain > 0 ? n_gain : 0);
+  int cce = I->ce+(n_drop > 0 ? n_drop : 0);
+  if (ccb > CP_MAX_KMER_CNT) ccb = CP_MAX_KMER_CNT;
+  if (cce > CP_MAX_KMER_CNT) cce = CP_MAX_KMER_CNT;
+  if (idx == b && e-2*K <= b && cce < (int)(W1.w[0] & 0xffffu))  // wall.c:1003-1006 with intvl index == position (cp_rel_interval)
+    cce = (int)(W1.w[0] & 0xffffu);
+  I->ccb = (uint16_t)ccb;
+  I->cce = (uint16_t)cce;
+  if (cp_logp_trans(P,b,e,ccb,cce,(ccb+cce)/2) < CP_THRES_DIFF_REL)
+    return false;
+  if ((ccb > cce ? ccb : cce) == CP_MAX_KMER_CNT)
+    return false;
+  return true;
+}
+
 #ifndef FW_WAVES_PER_EU
 #define FW_WAVES_PER_EU 4
 #endif
@@ -913,7 +1019,7 @@ k_wall_tasks(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, 
 #undef PH_STOP_EXTRA
 #define PH_STOP_EXTRA
 #ifndef FW2_WAVES_PER_EU
-#define FW2_WAVES_PER_EU 6        // (LDS, 7.4 KB per wave with the on-chip interval list, allows 5.5)
+#define FW2_WAVES_PER_EU 5        // (LDS, 7.4 KB per wave with the on-chip interval list, allows 5.4; at 6 the find_rel part spills a VGPR to scratch)
 #endif
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FW2_WAVES_PER_EU)))
 k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, const int64_t *__restrict__ seq_off,
@@ -923,7 +1029,8 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
             cp_eintvl *__restrict__ eintvl_all, cp_eintvl *__restrict__ ointvl_all, const int64_t *__restrict__ eoff,
             cp_intvl *__restrict__ intvl_all, const int64_t *__restrict__ ioff,
             int32_t *__restrict__ nintvl, int32_t *__restrict__ err, const int32_t *__restrict__ perm,
-            int32_t *__restrict__ wlist, const task_res *__restrict__ tres_all, const int32_t *__restrict__ fwc)
+            int32_t *__restrict__ wlist, const task_res *__restrict__ tres_all, const int32_t *__restrict__ fwc,
+            cp_intvl *__restrict__ rintvl_all, int32_t *__restrict__ relmap_all, int32_t *__restrict__ nrel, int do_rel)
 { if ((int)blockIdx.x >= nreads) return;
   const int r = perm[blockIdx.x];
   const int lane = lane_id();
@@ -1467,10 +1574,40 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   if (!(cf && smallc)) N = __shfl(N,0);
   if (N > icap) overflow |= 2;
   wave_sync();
-  for (int k = lane; k < N && k < icap; k += WAVE)     // wall.c:928-946, one lane per interval
-    { const int b0 = k ? (smallc ? (int)s_bnd[k-1] : bnd[k-1]) : 0, e0 = smallc ? (int)s_bnd[k] : bnd[k];
-      cp_make_interval(&R,NS,b0,e0,&intvl[k]);
-    }
+  // wall.c:928-946, one lane per interval -- and, on the whole-path call (do_rel), find_rel_intvl / correct_wall_cnt
+  // (wall.c:960-1051) on the record while it is still in the lane's registers: every interval is independent, the
+  // reliable ones are compacted in order (ballot + popcount) into rintvl / relmap.  As a kernel of its own (k_find_rel,
+  // still the stage API's) this pass re-read every record, wrote it a second time and sat 0.9 ms per 1-Gbase sub-batch
+  // between the walk and the classification.
+  { const int Ncl = N < icap ? N : icap;
+    cp_intvl *rintvl = rintvl_all+ioff[r];
+    int32_t *relmap = relmap_all+ioff[r];
+    int M = 0;
+    for (int base = 0; base < Ncl; base += WAVE)
+      { const int k = base+lane;
+        bool ok = false;
+        cp_intvl I;
+        if (k < Ncl)
+          { const int b0 = k ? (smallc ? (int)s_bnd[k-1] : bnd[k-1]) : 0, e0 = smallc ? (int)s_bnd[k] : bnd[k];
+            cp_make_interval(&R,NS,b0,e0,&I);
+            if (do_rel)
+              { ok = cp_rel_interval(P,R.prof,R.seq,R.seq,rlen,&I,k);
+                I.is_rel = ok ? 1 : 0;
+              }
+            intvl[k] = I;
+          }
+        if (do_rel)
+          { const uint64_t mask = __ballot(ok);
+            if (ok)
+              { const int rank = __popcll(mask & ((1ull << lane)-1));
+                rintvl[M+rank] = I;
+                relmap[M+rank] = k;
+              }
+            M += __popcll(mask);
+          }
+      }
+    if (do_rel && lane == 0) nrel[r] = M;
+  }
   PH_STAMP(5);
   // Leave the flag arrays all zero (capi.hip fills them only when they are allocated): every cell the walk and the
   // multi-error phase wrote is a candidate position or an end of an E-interval of the final list (the ends of O-pairs
@@ -1712,10 +1849,23 @@ struct rel_grp_rv
 
 // One DP pass (_classify_rel, class_rel.c:515-614) for every (read, direction) whose lanes have
 // active == true.  M differs per read group; the wave iterates to the largest.
-template <int MAXM, int G>
-__device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, const cp_intvl *rintvl, int M, int plen,
+// libm tables of a block in LDS (cp_libm.h): the DP step's chain is exp -> sum -> log, and from global memory each of the
+// two look-ups was a cache miss in the middle of it (k_classify_rel_grp 2.2 -> 3.2 ms per sub-batch when ocml's table-free
+// routines gave way to glibc's; with the tables on chip the look-up is an LDS read).
+struct rel_libm_lds { uint64_t exp_tab[256]; double log_tab[256]; };
+// A block of this kernel is WPB waves that share nothing but those tables: "sync" is the order of one wave's own LDS
+// operations (the hardware keeps it; the compiler is told by the fence), never a barrier across the block's waves.
+template <int WPB>
+__device__ __forceinline__ void grp_sync()
+{ if (WPB == 1) __syncthreads();
+  else { __builtin_amdgcn_fence(__ATOMIC_RELEASE,"wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE,"wavefront"); }
+}
+
+template <int MAXM, int G, int WPB>
+__device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, const rel_libm_lds &T, const cp_intvl *rintvl, int M, int plen,
                              bool active, const int *COV)
-{ // Lanes of a read: LD per direction (forward first).  With LD = 16 (G <= 2) lane (s,t) owns transition
+{ CP_LDS_PTR(const uint64_t) xt = (CP_LDS_PTR(const uint64_t))T.exp_tab;
+  CP_LDS_PTR(const double)   lt = (CP_LDS_PTR(const double))T.log_tab; // Lanes of a read: LD per direction (forward first).  With LD = 16 (G <= 2) lane (s,t) owns transition
   // s -> t; with LD = 8 (G = 4) lane (s,h) owns two, s -> H|D (a Skellam term, the expensive kind) and
   // s -> E|R (table look-ups), so that every lane of the wave has a Bessel evaluation to do.
   constexpr int L = WAVE/G, LD = (L >= 32) ? 16 : 8;
@@ -1741,20 +1891,20 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
       cp_cell c;
       cp_rel_init_cell(P,ld,I,i,plen,F,COV,&c);
       static_cast<cp_cell &>(S.cell[g][d][0][ld]) = c;
-      S.tr[g][d][ld] = cp_exp(c.dp);
+      S.tr[g][d][ld] = cp_exp_t(c.dp,xt);
       if (ld == 0)
         { S.parent[g][d][i] = 0xe4;                        // each state its own parent: 3,2,1,0
           S.eff[g][d][i] = (typename rel_grp_lds<MAXM,G>::eff_t)i;            // (rpos flag clear)
         }
     }
-  wave_sync();
+  grp_sync<WPB>();
   if (in_grp && ld < 4)                                    // :582-586
     { double psum = 0.;
       for (int x = 0; x < 4; x++)
         psum += S.tr[g][d][x];
-      S.cell[g][d][0][ld].dp = cp_log(S.tr[g][d][ld]/psum);
+      S.cell[g][d][0][ld].dp = cp_log_t(S.tr[g][d][ld]/psum,lt);
     }
-  wave_sync();
+  grp_sync<WPB>();
 
   int cur = 0;
   double pe_next = 0.;                                     // pe of the next interval (E lanes), one step ahead
@@ -1828,11 +1978,11 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
       if (is_sk)
         lp_sk = cp_logp_trans(P,tb,te,tcb,tce,tcov);
       if (on)
-        { if (live) { v_sk = cp_exp(lp_sk); v_tab = cp_exp(lp_tab); }
+        { if (live) { v_sk = cp_exp_t(lp_sk,xt); v_tab = cp_exp_t(lp_tab,xt); }
           if (t_sk >= 0)  S.tr[g][d][s*4+t_sk]  = v_sk;
           if (t_tab >= 0) S.tr[g][d][s*4+t_tab] = v_tab;
         }
-      wave_sync();
+      grp_sync<WPB>();
       double nv_sk = 0., nv_tab = 0.;
       if (on)                                              // :320-336
         { double psum = 0.;
@@ -1842,15 +1992,15 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
             { if (t_tab == CP_ERROR) v_tab = 1.;
               psum = 4.;
             }
-          if (t_sk >= 0)  nv_sk  = cp_log(v_sk/psum);
-          if (t_tab >= 0) nv_tab = cp_log(v_tab/psum);
+          if (t_sk >= 0)  nv_sk  = cp_log_t(v_sk/psum,lt);
+          if (t_tab >= 0) nv_tab = cp_log_t(v_tab/psum,lt);
         }
-      wave_sync();
+      grp_sync<WPB>();
       if (on)
         { if (t_sk >= 0)  S.tr[g][d][s*4+t_sk]  = nv_sk;
           if (t_tab >= 0) S.tr[g][d][s*4+t_tab] = nv_tab;
         }
-      wave_sync();
+      grp_sync<WPB>();
       if (on && ld < 4)                                    // :348-499: one lane per state
         { const int l16 = ld;
           const double *tr = S.tr[g][d];
@@ -1899,7 +2049,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
           if (l16 == 0)
             S.parent[g][d][i] = (uint8_t)pk;
         }
-      wave_sync();
+      grp_sync<WPB>();
       cur ^= 1;
     }
   // the buffer holding the last interval's cells: M-1 swaps happened for this read
@@ -1927,7 +2077,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
             st = (pk >> (2*st)) & 3;
           }
     }
-  wave_sync();
+  grp_sync<WPB>();
 }
 
 // size classes of the grouped classify kernels (reads per wave / largest interval count)
@@ -1959,19 +2109,29 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
 #ifndef REL_EXTRA_ATTR
 #define REL_EXTRA_ATTR
 #endif
+// waves per block of the main size class (they share the block's copy of the libm tables, 4 KB, and nothing else)
+#ifndef REL_SMALL_WPB
+#define REL_SMALL_WPB 4
+#endif
 // (4 waves per SIMD = 128 VGPRs with 32 of them spilled to scratch, against 167 and none at 3: 192 against 186 Gbases/s on the
 //  whole bench -- what this kernel waits for is latency, and a fourth wave hides more of it than the spills add; 5: 186)
 #ifndef REL_WAVES_PER_EU
 #define REL_WAVES_PER_EU 4
 #endif
 
-template <int MINM, int MAXM, int G>
-__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(REL_WAVES_PER_EU))) REL_EXTRA_ATTR
+template <int MINM, int MAXM, int G, int WPB>
+__global__ void __launch_bounds__(WAVE*WPB) __attribute__((amdgpu_waves_per_eu(REL_WAVES_PER_EU))) REL_EXTRA_ATTR
 k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ prof_off, int nreads,
                    cp_intvl *__restrict__ intvl_all, cp_intvl *__restrict__ rintvl_all, const int32_t *__restrict__ relmap_all,
                    const int64_t *__restrict__ ioff, const int32_t *__restrict__ nrel,
                    int8_t *__restrict__ asgn_all, int64_t totalI, const int32_t *__restrict__ perm)
-{ __shared__ rel_grp_lds<MAXM,G> S;
+{ __shared__ rel_grp_lds<MAXM,G> Sw[WPB];
+  __shared__ rel_libm_lds T;
+  for (int k = threadIdx.x; k < 256; k += WAVE*WPB)
+    { T.exp_tab[k] = cp_libm::exp_tab[k]; T.log_tab[k] = cp_libm::log_tab[k]; }
+  __syncthreads();                                         // the only barrier across the block's waves
+  const int wv = threadIdx.x/WAVE;
+  rel_grp_lds<MAXM,G> &S = Sw[wv];
   constexpr int L = WAVE/G;
   const int lane = lane_id();
   const int g = lane/L, ql = lane%L;
@@ -1979,7 +2139,7 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
   // the reads of a class with MINM > 0 are a prefix of it: such a class is launched with a small grid and a block
   // stops at its first group below the class (an empty class costs a few hundred blocks, not one block with this
   // kernel's LDS per read of the batch).
-  for (int blk = blockIdx.x; blk*G < nreads; blk += gridDim.x)
+  for (int blk = blockIdx.x*WPB+wv; blk*G < nreads; blk += gridDim.x*WPB)
   {
   const int slot = blk*G+g;
   const int r = (slot < nreads) ? perm[slot] : nreads;
@@ -1995,7 +2155,7 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
     { S.b[g][k] = (uint16_t)rintvl[k].b; S.e[g][k] = (uint16_t)rintvl[k].e;
       S.ccb[g][k] = rintvl[k].ccb; S.cce[g][k] = rintvl[k].cce;
     }
-  wave_sync();
+  grp_sync<WPB>();
 
   constexpr int LD = (L >= 32) ? 16 : 8;                   // lanes per direction, see rel_grp_pass
   const int d = (ql / LD) & 1, F = (d == 0);
@@ -2003,7 +2163,7 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
   const bool lead = (M > 0) && (ql < 2*LD) && ((ql % LD) == 0);
   int COV[4] = { P->cov[0], P->cov[1], P->cov[2], P->cov[3] };
   rel_grp_rv<MAXM,G> rv; rv.S = &S; rv.g = g;
-  rel_grp_pass<MAXM,G>(P,S,rintvl,M,plen,M > 0,COV);
+  rel_grp_pass<MAXM,G,WPB>(P,S,T,rintvl,M,plen,M > 0,COV);
 
   int rerun = 0;                                           // class_rel.c:629-650
   if (lead)
@@ -2013,12 +2173,12 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
   COV[CP_DIPLO] = __shfl(COV[CP_DIPLO],leadlane);
   if (M == 0 || ql >= 2*LD) rerun = 0;
   if (__ballot(rerun != 0))
-    rel_grp_pass<MAXM,G>(P,S,rintvl,M,plen,rerun != 0,COV);
+    rel_grp_pass<MAXM,G,WPB>(P,S,T,rintvl,M,plen,rerun != 0,COV);
   double hdrr = 1.;
   if (lead)
     hdrr = cp_rel_post2(P,rv,M,F,S.asgn(g,d),rerun != 0);
   const double hf = __shfl(hdrr,g*L), hb = __shfl(hdrr,g*L+LD);
-  wave_sync();
+  grp_sync<WPB>();
 
   int take_bw = 0;                                         // class_rel.c:904-938
   if (M > 0 && ql == 0)
@@ -2056,7 +2216,7 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
       rintvl[i].asgn = a;
       intvl[relmap[i]].asgn = a;
     }
-  wave_sync();                                             // the LDS record is reused by the block's next group
+  grp_sync<WPB>();                                             // the LDS record is reused by the block's next group
   }
 }
 
