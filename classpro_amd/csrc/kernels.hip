@@ -405,7 +405,9 @@ k_order_scatter(const int32_t *__restrict__ key, int n, int shift, int32_t *__re
 //  outgrows the slots moves to the read's HBM array (capacity ecap) and the same code goes on there.
 // ---------------------------------------------------------------------------------------------
 #ifndef FW_EVL
+#ifndef FW_EVL
 #define FW_EVL 96
+#endif
 #endif
 struct fw_evl
   { cp_eintvl *g;                                       // the read's array in HBM
@@ -1038,7 +1040,10 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   const int plen = (int)(prof_off[r+1]-po);
   const int rlen = (int)(seq_off[r+1]-seq_off[r]);
 
-  constexpr int LCAP0 = 256, LCAP1 = 64;                 // on-chip memo slots of the SELF / OTHERS pass
+#ifndef FW_LCAP1
+#define FW_LCAP1 64
+#endif
+  constexpr int LCAP0 = 256, LCAP1 = FW_LCAP1;           // on-chip memo slots of the SELF / OTHERS pass
   __shared__ int32_t s_mkey[LCAP0+LCAP1];
   __shared__ double  s_mval[LCAP0+LCAP1];
   __shared__ cp_eintvl s_ev[FW_EVL];                     // the E-interval list while it is short (fw_evl)
@@ -2001,19 +2006,38 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
           if (t_tab >= 0) S.tr[g][d][s*4+t_tab] = nv_tab;
         }
       grp_sync<WPB>();
-      if (on && ld < 4)                                    // :348-499: one lane per state
-        { const int l16 = ld;
-          const double *tr = S.tr[g][d];
-          double dp[4];
-          for (int x = 0; x < 4; x++) dp[x] = S.cell[g][d][cur][x].dp;
-          bool only_r = true;
-          for (int x = 0; x < 4; x++)
-            { double dummy;
-              int maxt = cp_argmax_tr(dp,tr,x,CP_N_STATE,&dummy);
-              if (maxt != CP_N_STATE && maxt != CP_REPEAT)
-                only_r = false;
+      // :348-499: one lane per state.  The four state lanes of a (read, direction) are an aligned quad; what the reference
+      // computes once per step and all four need -- "only R reachable" (four row maxima, :348-380) and the H->H / D->D
+      // equalisation (two column maxima, :382-386) -- is split over them, a row and a column each, and joined through a
+      // ballot, instead of every lane doing all six maxima (a quarter of this kernel's vector instructions).
+      const bool st_lane = on && ld < 4;
+      const int l16 = ld & 3;
+      const double *tr = S.tr[g][d];
+      double dp[4] = { 0., 0., 0., 0. };
+      bool row_r = false;
+      int  col_s = CP_N_STATE;
+      double col_logp = -INFINITY;
+      if (st_lane)
+        { for (int x = 0; x < 4; x++) dp[x] = S.cell[g][d][cur][x].dp;
+          { double best = -INFINITY;                       // best target of source l16 (cp_argmax_tr with s fixed)
+            int maxt = CP_N_STATE;
+            for (int x = 0; x < 4; x++)
+              { const double logp = dp[l16]+tr[l16*4+x];
+                if (best < logp) { best = logp; maxt = x; }
+              }
+            row_r = (maxt == CP_N_STATE || maxt == CP_REPEAT);
+          }
+          for (int x = 0; x < 4; x++)                      // best source of target l16 (t fixed), before the equalisation
+            { const double logp = dp[x]+tr[x*4+l16];
+              if (col_logp < logp) { col_logp = logp; col_s = x; }
             }
-          cp_cell c;
+        }
+      const int qsh = lane & ~3;                           // the quad's bits of a ballot
+      const bool only_r = ((__ballot(st_lane && row_r) >> qsh) & 0xf) == 0xf;
+      const bool equal  = ((__ballot(st_lane && ((l16 == CP_HAPLO || l16 == CP_DIPLO) && col_s == l16)) >> qsh) & 0xf)
+                          == ((1u << CP_HAPLO) | (1u << CP_DIPLO));
+      if (st_lane)
+        { cp_cell c;
           int pv = l16;
           if (only_r)
             { c = S.cell[g][d][cur][l16];
@@ -2022,20 +2046,16 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
                 S.eff[g][d][i] = (typename rel_grp_lds<MAXM,G>::eff_t)(S.eff[g][d][i_pred] | rel_grp_lds<MAXM,G>::RPOS);
             }
           else
-            { double dummy, max_logp = -INFINITY;
-              int maxs_h = cp_argmax_tr(dp,tr,CP_N_STATE,CP_HAPLO,&dummy);
-              int maxs_d = cp_argmax_tr(dp,tr,CP_N_STATE,CP_DIPLO,&dummy);
-              const bool equal = (maxs_h == CP_HAPLO && maxs_d == CP_DIPLO);          // :382-386
-              const double a = tr[CP_HAPLO*4+CP_HAPLO], bb = tr[CP_DIPLO*4+CP_DIPLO];
-              const double mn = a < bb ? a : bb;
-              int max_s = CP_N_STATE;
-              for (int x = 0; x < 4; x++)                  // best source of target l16 (:391)
-                { double w = tr[x*4+l16];
-                  if (equal && x == l16 && (x == CP_HAPLO || x == CP_DIPLO)) w = mn;
-                  double logp = dp[x]+w;
-                  if (max_logp < logp)
-                    { max_logp = logp;
-                      max_s = x;
+            { double max_logp = col_logp;
+              int max_s = col_s;
+              if (equal && (l16 == CP_HAPLO || l16 == CP_DIPLO))                      // :382-386, then :391 again for this target
+                { const double a = tr[CP_HAPLO*4+CP_HAPLO], bb = tr[CP_DIPLO*4+CP_DIPLO];
+                  const double mn = a < bb ? a : bb;
+                  max_logp = -INFINITY; max_s = CP_N_STATE;
+                  for (int x = 0; x < 4; x++)
+                    { const double w = (x == l16) ? mn : tr[x*4+l16];
+                      const double logp = dp[x]+w;
+                      if (max_logp < logp) { max_logp = logp; max_s = x; }
                     }
                 }
               pv = (max_s == CP_N_STATE) ? l16 : max_s;
