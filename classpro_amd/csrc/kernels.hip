@@ -800,112 +800,6 @@ __device__ __forceinline__ void fr_seq_win_load(cp_seq_lwin &sq, char *row, int 
   sq.lo = lo; sq.len = len;
 }
 
-// ---- correct_wall_cnt (wall.c:960-1014) from count windows in registers ----------------------------------------------
-// cp_rel_interval (cp_wall.h) walks its four step sums eight counts per load, each load waiting for the one before: a
-// dozen dependent round trips per interval, which is what k_find_rel spent its time on.  Here the 64 counts after the
-// interval's begin and the 64 before its end are fetched by sixteen independent 16-byte loads issued together, and the
-// sums are taken from the registers; a range that leaves its window (K > 57, a low-complexity run of more than 63
-// bases) takes cp_sum_steps as before.  Counts outside [0,plen) read 0 -- which is also hazard 8's value of profile[plen].
-struct cp_win64 { uint32_t w[32]; };                     // count q of the window = (w[q >> 1] >> 16*(q & 1)) & 0xffff
-struct __attribute__((packed, aligned(2))) cp_u32x4u { uint32_t v[4]; };
-__device__ __forceinline__ void win64_load(cp_win64 &W, const uint16_t *__restrict__ prof, int lo, int plen)
-{ if (lo >= 0 && lo+64 <= plen)
-    {
-#pragma unroll
-      for (int c = 0; c < 8; c++)
-        { const cp_u32x4u x = *reinterpret_cast<const cp_u32x4u *>(prof+lo+8*c);
-          W.w[4*c] = x.v[0]; W.w[4*c+1] = x.v[1]; W.w[4*c+2] = x.v[2]; W.w[4*c+3] = x.v[3];
-        }
-    }
-  else
-    {
-#pragma unroll
-      for (int q = 0; q < 32; q++)
-        { const int a = lo+2*q;
-          const uint32_t x0 = (a >= 0 && a < plen) ? prof[a] : 0u, x1 = (a+1 >= 0 && a+1 < plen) ? prof[a+1] : 0u;
-          W.w[q] = x0 | (x1 << 16);
-        }
-    }
-}
-// up = sum over steps q -> q+1, q in [u0,u1), of the upward steps; down = the same over [d0,d1) of the downward steps
-__device__ __forceinline__ void win64_sums(const cp_win64 &W, int u0, int u1, int d0, int d1, int &up, int &down)
-{ const uint64_t um = (u1 > u0) ? ((u1-u0 >= 64 ? ~0ull : ((1ull << (u1-u0))-1)) << u0) : 0ull;
-  const uint64_t dm = (d1 > d0) ? ((d1-d0 >= 64 ? ~0ull : ((1ull << (d1-d0))-1)) << d0) : 0ull;
-  int prev = (int)(W.w[0] & 0xffffu);
-  up = 0; down = 0;
-#pragma unroll
-  for (int q = 0; q < 63; q++)
-    { const int cur = (int)((W.w[(q+1) >> 1] >> (16*((q+1) & 1))) & 0xffffu);
-      const int d = cur-prev;
-      const int pos = d > 0 ? d : 0, neg = d < 0 ? -d : 0;
-      up   += pos*(int)((um >> q) & 1);
-      down += neg*(int)((dm >> q) & 1);
-      prev = cur;
-    }
-}
-
-// cp_rel_interval with the window sums; same filters, same order, same results (tests: stage parity, neighbours)
-template <class SEQB, class SEQE>
-__device__ __forceinline__ bool cp_rel_interval_win(const cp_dev_params *P, const uint16_t *__restrict__ prof, const SEQB &seq_b, const SEQE &seq_e,
-                                                    int rlen, cp_intvl *I, int idx)
-{ const int K = P->K;
-  const int b = I->b, e = I->e;
-  if (e-b < K)
-    return false;
-  if ((I->cb > I->ce ? I->cb : I->ce) >= P->cov[CP_REPEAT])
-    return false;
-  if (I->pe >= P->log_pe_final)
-    return false;
-  const int plen = rlen-(K-1);
-  cp_win64 W1, W2;
-  win64_load(W1,prof,b,plen);
-  win64_load(W2,prof,e-64,plen);
-  int lmax1 = 0, lmax2 = 0;                              // (the context scans run while the windows are on their way)
-  if (b+K-1 < e)
-    for (int t = 0; t < 3; t++)
-      { const int l = cp_rctx(seq_b,rlen,b+K-1,t)*(t+1);
-        if (lmax1 < l) lmax1 = l;
-      }
-  if (b < e-K+1)
-    for (int t = 0; t < 3; t++)
-      { const int l = cp_lctx(seq_e,rlen,(e-K+1)+K-2,t)*(t+1);
-        if (lmax2 < l) lmax2 = l;
-      }
-  int n_gain = 0, n_drop = 0;
-  { const int last1 = (b+K-1 < e-1) ? b+K-1 : e-1;       // up-steps over [b,last1), down-steps over [b,b+lmax1)
-    const int n1 = last1-b, n2 = (b+K-1 < e) ? lmax1 : 0;
-    int up, down;
-    win64_sums(W1,0,n1 <= 63 ? n1 : 0,0,n2 <= 63 ? n2 : 0,up,down);
-    if (n1 > 63) up = cp_sum_steps(prof,b,last1,plen,+1);
-    if (n2 > 63) down = cp_sum_steps(prof,b,b+lmax1,plen,-1);
-    n_gain = up-down;
-  }
-  { const int first1 = (e-K+1 > b) ? e-K+1 : b;          // down-steps over [first1,e-1), up-steps over [e-lmax2,e-1)
-    const int lo = e-64;
-    const bool has2 = b < e-K+1;
-    const int first2 = e-lmax2;
-    int up, down;
-    const bool in1 = first1 >= lo, in2 = !has2 || first2 >= lo;
-    win64_sums(W2,(has2 && in2) ? first2-lo : 0,(has2 && in2) ? 63 : 0,in1 ? first1-lo : 0,in1 ? 63 : 0,up,down);
-    if (!in1) down = cp_sum_steps(prof,first1,e-1,plen,-1);
-    if (has2 && !in2) up = cp_sum_steps(prof,first2,e-1,plen,+1);
-    n_drop = down-up;
-  }
-  int ccb = I->cb+(n_gain > 0 ? n_gain : 0);
-  int cce = I->ce+(n_drop > 0 ? n_drop : 0);
-  if (ccb > CP_MAX_KMER_CNT) ccb = CP_MAX_KMER_CNT;
-  if (cce > CP_MAX_KMER_CNT) cce = CP_MAX_KMER_CNT;
-  if (idx == b && e-2*K <= b && cce < (int)(W1.w[0] & 0xffffu))  // wall.c:1003-1006 with intvl index == position (cp_rel_interval)
-    cce = (int)(W1.w[0] & 0xffffu);
-  I->ccb = (uint16_t)ccb;
-  I->cce = (uint16_t)cce;
-  if (cp_logp_trans(P,b,e,ccb,cce,(ccb+cce)/2) < CP_THRES_DIFF_REL)
-    return false;
-  if ((ccb > cce ? ccb : cce) == CP_MAX_KMER_CNT)
-    return false;
-  return true;
-}
-
 #ifndef FW_WAVES_PER_EU
 #define FW_WAVES_PER_EU 4
 #endif
@@ -1583,7 +1477,10 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   // (wall.c:960-1051) on the record while it is still in the lane's registers: every interval is independent, the
   // reliable ones are compacted in order (ballot + popcount) into rintvl / relmap.  As a kernel of its own (k_find_rel,
   // still the stage API's) this pass re-read every record, wrote it a second time and sat 0.9 ms per 1-Gbase sub-batch
-  // between the walk and the classification.
+  // between the walk and the classification (fused: 2.13 ms for both against 1.53 + 0.95 alone on the machine).
+  // (Tried on top: the four step sums of correct_wall_cnt from two 64-count register windows fetched by sixteen
+  //  independent loads, instead of cp_sum_steps' eight counts per dependent load -- as an inlined body 205 registers
+  //  spilled, as a call 19 and 2.18 ms: the sums' loads are not what this pass waits for.)
   { const int Ncl = N < icap ? N : icap;
     cp_intvl *rintvl = rintvl_all+ioff[r];
     int32_t *relmap = relmap_all+ioff[r];
