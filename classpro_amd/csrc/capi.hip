@@ -946,6 +946,18 @@ extern "C" int cp_seq_context(const char *d_seq, const int64_t *d_seq_off, int n
   return CP_OK;
 }
 
+#ifdef CP_BOUNDS
+// -DCP_BOUNDS diagnostic builds only (cp_bounds.h): accesses outside a read counted since the last call, and the first
+// one (kind 1 / 9: a count / a run of counts, 2 / 10: a base / a run of bases, 3 / 4: the seed kernel's counts / bases).
+extern "C" int cp_debug_bounds(unsigned long long *out4)
+{ HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out4,HIP_SYMBOL(g_bounds),sizeof(unsigned long long)*4));
+  unsigned long long z[4] = { 0, 0, 0, 0 };
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_bounds),z,sizeof(z)));
+  return CP_OK;
+}
+#endif
+
 #if defined(CP_SEED_DEBUG) || defined(CP_SEED_DEBUG_TAKES)
 extern "C" int cp_debug_seed_set(int read)
 { HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_seed_dbg_read),&read,sizeof(int))); return CP_OK; }

@@ -318,8 +318,10 @@ template <int STRIDE, class ROT, class CODE>
 __device__ __forceinline__ int sw_hash_at(const char *seq, int j, int K, int rlen, const ROT rot, const CODE code_of)
 { if (K > SW_KMAX) return cp_kmer_hash(seq,j,K);
   uint64_t fh = 0, rh = 0;
+  CP_BCHK(4,j,rlen-K+1);                                 // a k-mer of the read
   if (j+SW_KMAX <= rlen)
     { uint32_t w[SW_KMAX/4];
+      CP_BCHK(4,j+SW_KMAX-1,rlen);
 #pragma unroll
       for (int q = 0; q < SW_KMAX/16; q++)
         { const cp_u8x16 x = *reinterpret_cast<const cp_u8x16 *>(seq+j+16*q);
@@ -551,7 +553,7 @@ __device__ __attribute__((noinline)) void sw_segments(int C_, int nrep_, int rep
         const int idx = mv ? nv+__popcll(vb & lt) : ni+__popcll(ib & lt);
         const int ep = sw_from_below(e,prev_e), pidx = sw_from_below(idx,prev_idx);    // the segment before mine ends where mine begins
         int cnt = 0;
-        if (a && mv) cnt = (int)R.prof[p];
+        if (a && mv) { CP_BCHK(3,p,plen); cnt = (int)R.prof[p]; }
         if (a)
           { if (ep >= 0 && pidx < R.cap) { if (ep & 1) R.rec[pidx].y = p; else R.orec[pidx].y = p; }
             if (idx < R.cap)                                 // (z: the begin of my predecessor of either kind, until the window count replaces it)
@@ -576,6 +578,7 @@ __device__ __attribute__((noinline)) void sw_segments(int C_, int nrep_, int rep
         for (int u = 0; u < SW_STEP; u++)
           { const int p = e0+u*WAVE+lane;
             const bool in = p < plen;
+            if (in) CP_BCHK(3,p,plen);
             ncnt[u] = in ? (int)R.prof[p] : 0;
             ncl[u] = in ? R.cls[p] : (char)0;
             nst[u] = (in && rep) ? R.state[p] : (char)'E';

@@ -23,6 +23,7 @@
 #define CP_HDM inline
 #endif
 #endif
+#include "cp_bounds.h"
 
 // dense store: the reference's layout (used by tests/host_harness.cpp)
 struct cp_perr_dense
@@ -130,7 +131,7 @@ struct cp_ev_ptr
 
 // SEQ / PROF / LF: anything indexable like the read's bases, its counts and the log-factorial table
 // (plain pointers, or the LDS-window accessors of kernels.hip).  EVL: the interval lists (cp_ev_ptr or fw_evl).
-template <class PE, class SEQ = const char *, class PROF = const uint16_t *, class LF = const double *, class EVL = cp_ev_ptr>
+template <class PE, class SEQ = CP_SEQ_T, class PROF = CP_PROF_T, class LF = const double *, class EVL = cp_ev_ptr>
 struct cp_read_t
   { const cp_dev_params *P;
     PROF                 prof;
@@ -190,7 +191,8 @@ CP_HD double cp_logp_diff_pair(const RD *R, int i, int j)
 
 // eight consecutive counts from position lo (only 2-byte aligned; gfx9 global loads take unaligned addresses)
 struct __attribute__((packed, aligned(2))) cp_u16x8 { uint16_t v[8]; };
-CP_HD cp_u16x8 cp_load_u16x8(const uint16_t *prof, int lo) { return *reinterpret_cast<const cp_u16x8 *>(prof+lo); }
+template <class PROF>
+CP_HD cp_u16x8 cp_load_u16x8(const PROF &prof, int lo) { return *reinterpret_cast<const cp_u16x8 *>(CP_SPAN(prof,lo,8)); }
 
 // wall.c:324-329
 CP_HD bool cp_cthres_ng(int e, int cin, int ct)
@@ -726,12 +728,13 @@ CP_HD void cp_make_interval(const RD *R, int NS, int b, int e, cp_intvl *out)
 // hi may equal plen (wall.c:976-978, `last = I.b+lmax` with a low-complexity run that reaches the end of the read):
 // the reference then reads profile[plen], a cell no read owns -- fresh heap for the first read of a thread.  Here
 // that cell reads 0 whatever follows the read in memory, so a read's result is a function of the read alone.
-CP_HD int cp_sum_steps(const uint16_t *prof, int lo, int hi, int plen, int sgn)
+template <class PROF>
+CP_HD int cp_sum_steps(const PROF &prof, int lo, int hi, int plen, int sgn)
 { int acc = 0, i = lo;
   if (lo >= hi) return 0;
   int prev = prof[lo];
   while (i+8 <= hi && i+8 < plen)
-    { const cp_u16x8 x = *reinterpret_cast<const cp_u16x8 *>(prof+i+1);
+    { const cp_u16x8 x = cp_load_u16x8(prof,i+1);
 #ifdef __HIPCC__
 #pragma unroll
 #endif
@@ -755,8 +758,8 @@ CP_HD int cp_sum_steps(const uint16_t *prof, int lo, int hi, int plen, int sgn)
 // its index equals its start position (SURVEY.md hazard 2); that case is applied explicitly.
 // seq_b / seq_e: the read's bases as seen by the context scan after the interval's begin / before its end (the same
 // pointer on the host; on the device two short LDS windows backed by the pointer, kernels.hip).
-template <class SEQB, class SEQE>
-CP_HD bool cp_rel_interval(const cp_dev_params *P, const uint16_t *prof, const SEQB &seq_b, const SEQE &seq_e, int rlen,
+template <class PROF, class SEQB, class SEQE>
+CP_HD bool cp_rel_interval(const cp_dev_params *P, const PROF &prof, const SEQB &seq_b, const SEQE &seq_e, int rlen,
                            cp_intvl *I, int idx)
 { const int K = P->K;
   if (I->e-I->b < K)

@@ -33,6 +33,9 @@
 #include "cp_class.h"
 #include "cp_seed.h"
 
+#ifdef CP_BOUNDS
+__device__ unsigned long long g_bounds[4];               // cp_bounds.h
+#endif
 #define WAVE 64
 #define REL_MAXM 1024           // reads with more reliable intervals use the sequential kernel
 #define UNREL_MAXN 1024         // reads with more intervals use the sequential kernel
@@ -757,7 +760,7 @@ struct task_res { double own_pe, lc_v, hc_pe; int lc_j, hc;  };   // hc: lc_kind
 #define FW_SEQ_WIN    96
 #define FW_SEQ_STRIDE 100            // bytes per lane: 25 dwords, an odd number of banks apart
 struct cp_seq_lwin
-  { const char *g; CP_LDS_PTR(const char) w; int lo, len;
+  { CP_SEQ_T g; CP_LDS_PTR(const char) w; int lo, len;
     __device__ __forceinline__ char operator[](int p) const
     { const unsigned d = (unsigned)(p-lo); return d < (unsigned)len ? w[d] : g[p]; }
   };
@@ -772,7 +775,7 @@ __device__ __forceinline__ void fw_seq_win_load(cp_seq_lwin &sq, char *row, int 
     {
 #pragma unroll
       for (int k = 0; k < FW_SEQ_WIN/16; k++)
-        { const cp_u8x16 x = *reinterpret_cast<const cp_u8x16 *>(sq.g+lo+16*k);
+        { const cp_u8x16 x = *reinterpret_cast<const cp_u8x16 *>(CP_SPAN(sq.g,lo+16*k,16));
           rw[4*k] = x.v[0]; rw[4*k+1] = x.v[1]; rw[4*k+2] = x.v[2]; rw[4*k+3] = x.v[3];
         }
     }
@@ -791,7 +794,7 @@ __device__ __forceinline__ void fr_seq_win_load(cp_seq_lwin &sq, char *row, int 
     {
 #pragma unroll
       for (int k = 0; k < 2; k++)
-        { const cp_u8x16 x = *reinterpret_cast<const cp_u8x16 *>(sq.g+lo+16*k);
+        { const cp_u8x16 x = *reinterpret_cast<const cp_u8x16 *>(CP_SPAN(sq.g,lo+16*k,16));
           rw[4*k] = x.v[0]; rw[4*k+1] = x.v[1]; rw[4*k+2] = x.v[2]; rw[4*k+3] = x.v[3];
         }
     }
@@ -819,8 +822,8 @@ k_wall_tasks(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, 
   const int rlen = (int)(seq_off[r+1]-seq_off[r]);
   __shared__ __attribute__((aligned(4))) char s_win[WAVE*FW_SEQ_STRIDE];
   cp_read_t<cp_perr_hybrid,cp_seq_lwin> R;
-  R.P = P; R.prof = prof+po; R.lf = P->logfact; R.plen = plen; R.rlen = rlen;
-  R.seq.g = seq+seq_off[r]; R.seq.w = (CP_LDS_PTR(const char))(s_win+lane*FW_SEQ_STRIDE); R.seq.lo = 0; R.seq.len = 0;
+  R.P = P; R.prof = CP_PROF_VIEW(prof+po,plen); R.lf = P->logfact; R.plen = plen; R.rlen = rlen;
+  R.seq.g = CP_SEQ_VIEW(seq+seq_off[r],rlen); R.seq.w = (CP_LDS_PTR(const char))(s_win+lane*FW_SEQ_STRIDE); R.seq.lo = 0; R.seq.len = 0;
   R.wall = wall_all+po+r; R.wall_s = R.wall;
   R.eintvl = R.ointvl = nullptr; R.ecap = 0; R.eidx = R.oidx = 0; R.overflow = 0;
   const int icap = (int)(ioff[r+1]-ioff[r]);
@@ -937,12 +940,16 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
 #ifndef FW_LCAP1
 #define FW_LCAP1 64
 #endif
+  if (plen <= 0)                                         // a read shorter than K has no k-mer: no interval (ClassPro.c:209-226 prints
+    { if (lane == 0) { nintvl[r] = 0; if (do_rel) nrel[r] = 0; }      // its N's and goes on).  Found by the -DCP_BOUNDS build: the
+      return;                                            // emission below made one interval [0,0) of it and read prof[0], prof[-1]
+    }                                                    // -- another read's counts, or the cells around the batch's buffer.
   constexpr int LCAP0 = 256, LCAP1 = FW_LCAP1;           // on-chip memo slots of the SELF / OTHERS pass
   __shared__ int32_t s_mkey[LCAP0+LCAP1];
   __shared__ double  s_mval[LCAP0+LCAP1];
   __shared__ cp_eintvl s_ev[FW_EVL];                     // the E-interval list while it is short (fw_evl)
-  cp_read_t<cp_perr_hybrid,const char *,const uint16_t *,const double *,fw_evl> R;
-  R.P = P; R.prof = prof+po; R.seq = seq+seq_off[r]; R.lf = P->logfact; R.plen = plen; R.rlen = rlen;
+  cp_read_t<cp_perr_hybrid,CP_SEQ_T,CP_PROF_T,const double *,fw_evl> R;
+  R.P = P; R.prof = CP_PROF_VIEW(prof+po,plen); R.seq = CP_SEQ_VIEW(seq+seq_off[r],rlen); R.lf = P->logfact; R.plen = plen; R.rlen = rlen;
   R.wall = wall_all+po+r;
   R.wall_s = walls_all+po+r;
   { const int64_t ho = hoff[r], hc = (hoff[r+1]-ho) >> 1;     // two tables, one per error type
@@ -1549,8 +1556,8 @@ k_find_rel(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, co
   const int lane = lane_id();
   const int N = nintvl[r];
   const int rlen = (int)(seq_off[r+1]-seq_off[r]);
-  const uint16_t *pr = prof+prof_off[r];
-  const char *sq = seq+seq_off[r];
+  const CP_PROF_T pr = CP_PROF_VIEW(prof+prof_off[r],rlen-(P->K-1));
+  const CP_SEQ_T sq = CP_SEQ_VIEW(seq+seq_off[r],rlen);
   cp_intvl *intvl = intvl_all+ioff[r], *rintvl = rintvl_all+ioff[r];
   int32_t *relmap = relmap_all+ioff[r];
   __shared__ __attribute__((aligned(4))) char s_ctx[WAVE*FR_STRIDE];

@@ -76,3 +76,21 @@ def small_ds():
 
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """scripts/bounds_check.sh: with a -DCP_BOUNDS build of the library loaded (cp_bounds.h), report how many accesses of the
+    per-read kernels fell outside their read during the whole session -- it must be none -- and fail the run otherwise."""
+    rep = os.environ.get("CP_BOUNDS_REPORT")
+    if not rep:
+        return
+    import ctypes as C
+    from classpro_amd import _lib
+    L = _lib.lib()
+    out = (C.c_ulonglong * 4)()
+    rc = L.cp_debug_bounds(out)
+    with open(rep, "w") as f:
+        f.write("cp_debug_bounds rc=%d: %d accesses outside a read (first: kind %d, index %d, length %d)\n"
+                % (rc, out[0], out[1], C.c_longlong(out[2]).value, out[3]))
+    if rc != 0 or out[0] != 0:
+        session.exitstatus = 1
