@@ -2161,6 +2161,7 @@ struct unrel_grp_lds
     int8_t   asgn[G][MAXN];
     uint8_t  isrel[G][MAXN];
     int16_t  ord[G][MAXN];               // sorted index, bit 14 = fixed
+    uint16_t key[G][MAXN+4];             // min(cb,ce), padded with 0xffff to a multiple of four (the sort reads four per load)
     uint64_t rel[G][2][MAXN/64];         // [0] reliable & H, [1] reliable & D
     int16_t  mail_idx[G][8];             // interval and new class of each speculative slot of a round
     int8_t   mail_s[G][8];
@@ -2236,24 +2237,40 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
         }
     }
   wave_sync();
-  for (int k = ql; k < N; k += L)                          // stable sort by min(cb,ce), class_unrel.c:252-258
-    { const int key = S.cb[g][k] < S.ce[g][k] ? S.cb[g][k] : S.ce[g][k];
+  // stable sort by min(cb,ce), class_unrel.c:252-258: rank = keys below mine + equal keys before me.  The keys go to LDS
+  // once, padded to a multiple of four with 0xffff (above every count), and a lane compares four per 8-byte load (the
+  // first form recomputed min(cb,ce) from two loads per comparison: a quarter of this kernel's instructions were this loop).
+  for (int k = ql; k < ((N+3) & ~3); k += L)
+    S.key[g][k] = (k < N) ? (S.cb[g][k] < S.ce[g][k] ? S.cb[g][k] : S.ce[g][k]) : (uint16_t)0xffff;
+  wave_sync();
+  for (int k = ql; k < N; k += L)
+    { const unsigned key = S.key[g][k];
       int rank = 0;
-      for (int m = 0; m < N; m++)
-        { int km = S.cb[g][m] < S.ce[g][m] ? S.cb[g][m] : S.ce[g][m];
-          rank += (km < key || (km == key && m < k)) ? 1 : 0;
+      for (int m = 0; m < N; m += 4)
+        { const uint2 q = *reinterpret_cast<const uint2 *>(&S.key[g][m]);
+          const unsigned k0 = q.x & 0xffffu, k1 = q.x >> 16, k2 = q.y & 0xffffu, k3 = q.y >> 16;
+          rank += (k0 < key || (k0 == key && m   < k)) ? 1 : 0;
+          rank += (k1 < key || (k1 == key && m+1 < k)) ? 1 : 0;
+          rank += (k2 < key || (k2 == key && m+2 < k)) ? 1 : 0;
+          rank += (k3 < key || (k3 == key && m+3 < k)) ? 1 : 0;
         }
       int fixed = (S.isrel[g][k] && (S.asgn[g][k] == CP_HAPLO || S.asgn[g][k] == CP_DIPLO)) ? 1 : 0;
       S.ord[g][rank] = (int16_t)(k | (fixed << 14));
     }
   wave_sync();
-  int nnf = 0;                                             // keep only the non-fixed intervals, order preserved
-  if (ql == 0)
-    for (int i = 0; i < N; i++)
-      { const int16_t oi = S.ord[g][i];
-        if (!(oi & (1 << 14)))
-          S.ord[g][nnf++] = oi;
-      }
+  int nnf = 0;                                             // keep only the non-fixed intervals, order preserved: L at a time,
+  for (int base = 0; base < maxN; base += L)               // every lane placing its own (a target never lies beyond its source)
+    { const int i = base+ql;
+      int16_t oi = 0;
+      bool keep = false;
+      if (i < N) { oi = S.ord[g][i]; keep = !(oi & (1 << 14)); }
+      const uint64_t lm = (L == 64) ? ~0ull : ((1ull << L)-1);
+      const uint64_t mk = (__ballot(keep) >> gbase) & lm;
+      wave_sync();
+      if (keep) S.ord[g][nnf+__popcll(mk & ((1ull << ql)-1))] = oi;
+      nnf += __popcll(mk);
+      wave_sync();
+    }
   nnf = __shfl(nnf,gbase);
   int maxNF = nnf;
   for (int o = 32; o > 0; o >>= 1)
