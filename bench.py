@@ -530,28 +530,35 @@ def pcie_pipeline(a, ds, clf, batches, dev):
         dbuf = torch.empty(big["bases"], dtype=torch.uint8, device=dev)
         hback = torch.empty(big["bases"], dtype=torch.uint8).pin_memory()
 
-        def rate(fn, nbytes, reps=6):
-            fn(); torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                fn()
-            torch.cuda.synchronize()
-            return nbytes * reps / (time.perf_counter() - t0) / 1e9
-        s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        def rate(fn, nbytes, reps=6, trials=3):         # best of three: the first pinned copies of a process run slow now and then
+            best = 0.0
+            for _ in range(trials):
+                fn(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize()
+                best = max(best, nbytes * reps / (time.perf_counter() - t0) / 1e9)
+            return best
+        NCS = 4                                             # copy streams per direction: the pipeline has several copies in flight too
+        ss1, ss2 = [torch.cuda.Stream(dev) for _ in range(NCS)], [torch.cuda.Stream(dev) for _ in range(NCS)]
+        nb4 = big["bases"] // NCS
 
         def h2d():
-            with torch.cuda.stream(s1):
-                dbuf.copy_(big["h_seq"], non_blocking=True)
+            for k, st_ in enumerate(ss1):
+                with torch.cuda.stream(st_):
+                    dbuf[k * nb4:(k + 1) * nb4].copy_(big["h_seq"][k * nb4:(k + 1) * nb4], non_blocking=True)
 
         def d2h():
-            with torch.cuda.stream(s2):
-                hback.copy_(dbuf, non_blocking=True)
+            for k, st_ in enumerate(ss2):
+                with torch.cuda.stream(st_):
+                    hback[k * nb4:(k + 1) * nb4].copy_(dbuf[k * nb4:(k + 1) * nb4], non_blocking=True)
 
         def both():
             h2d(); d2h()
-        res["pinned_h2d_peak_gb_per_s"] = round(rate(h2d, big["bases"]), 1)
-        res["pinned_d2h_peak_gb_per_s"] = round(rate(d2h, big["bases"]), 1)
-        res["pinned_bidirectional_gb_per_s_each_way"] = round(rate(both, big["bases"]), 1)
+        res["pinned_h2d_peak_gb_per_s"] = round(rate(h2d, nb4 * NCS), 1)
+        res["pinned_d2h_peak_gb_per_s"] = round(rate(d2h, nb4 * NCS), 1)
+        res["pinned_both_ways_gb_per_s_in_plus_out"] = round(2 * rate(both, nb4 * NCS), 1)
         del dbuf, hback
 
         # ---- the pipeline ----
@@ -613,7 +620,7 @@ def pcie_pipeline(a, ds, clf, batches, dev):
         t1 = time.perf_counter() - t0
         passes = 1
         if t1 < a.pcie_seconds:                             # repeat the staged set until the span is long enough
-            more = int(np.ceil(a.pcie_seconds / t1))
+            more = int(np.ceil(1.6 * a.pcie_seconds / t1))  # (the first pass is the slowest)
             for q in sl:
                 q["t_pack"] = 0.0
             t0 = time.perf_counter()
@@ -644,7 +651,10 @@ def pcie_pipeline(a, ds, clf, batches, dev):
                     "bytes_per_base_in_out": [round(in_bytes / tot_bases, 3), round(out_bytes / tot_bases, 3)],
                     "h2d_gb_per_s": round(in_bytes / t1 / 1e9, 2), "d2h_gb_per_s": round(out_bytes / t1 / 1e9, 2),
                     "labels_match_resident_run": ok})
-        res["frac_of_pinned_h2d_peak"] = round(res["h2d_gb_per_s"] / res["pinned_h2d_peak_gb_per_s"], 3)
+        # the pipeline moves data both ways at once: it is judged against what pinned copies both ways at once reach
+        res["link_gb_per_s_in_plus_out"] = round((in_bytes + out_bytes) / t1 / 1e9, 2)
+        res["frac"] = round(res["link_gb_per_s_in_plus_out"] / max(res["pinned_both_ways_gb_per_s_in_plus_out"], res["pinned_h2d_peak_gb_per_s"]), 3)
+        res["frac_of"] = "pinned copies both ways at once (in + out), %d streams each way, measured in this run" % NCS
         for q in sl:
             L.cp_workspace_destroy(q["ws"])
     finally:

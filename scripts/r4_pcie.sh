@@ -7,7 +7,7 @@ run() { name=$1; shift; timeout -k 10 300 "$@" > $O/$name.json 2> $O/$name.err; 
 import json,sys
 try:
     j=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); p=j["extras"].get("pcie") or j["extras"]
-    print("%-22s %8.1f Mbases/s h2d %.1f d2h %.1f GB/s  peaks h2d %.1f d2h %.1f bidi %.1f  pack %s batch %.0f" % (sys.argv[2], p["mbases_per_s"], p["h2d_gb_per_s"], p["d2h_gb_per_s"], p["pinned_h2d_peak_gb_per_s"], p["pinned_d2h_peak_gb_per_s"], p["pinned_bidirectional_gb_per_s_each_way"], p["host_pack_seconds_per_slot"], p["batch_mbases"]))
+    print("%-22s %8.1f Mbases/s h2d %.1f d2h %.1f GB/s  peaks h2d %.1f d2h %.1f both ways in+out %.1f  pack %s batch %.0f" % (sys.argv[2], p["mbases_per_s"], p["h2d_gb_per_s"], p["d2h_gb_per_s"], p["pinned_h2d_peak_gb_per_s"], p["pinned_d2h_peak_gb_per_s"], p["pinned_both_ways_gb_per_s_in_plus_out"], p["host_pack_seconds_per_slot"], p["batch_mbases"]))
 except Exception as e:
     print(sys.argv[2], "failed", e)
 PY
