@@ -765,6 +765,7 @@ struct cp_seq_lwin
     { const unsigned d = (unsigned)(p-lo); return d < (unsigned)len ? w[d] : g[p]; }
   };
 struct __attribute__((packed, aligned(1))) cp_u8x16 { uint32_t v[4]; };
+struct __attribute__((packed, aligned(1))) cp_u8x4 { uint32_t v; };
 __device__ __forceinline__ void fw_seq_win_load(cp_seq_lwin &sq, char *row, int i, int rlen)
 { int lo = i-32;
   if (lo > rlen-FW_SEQ_WIN) lo = rlen-FW_SEQ_WIN;
@@ -2642,19 +2643,35 @@ k_decode_profiles(const uint8_t *__restrict__ codes, const int64_t *__restrict__
 __global__ void __launch_bounds__(256)
 k_unpack_bases(const uint8_t *__restrict__ packed, const int64_t *__restrict__ pack_off,
                const int64_t *__restrict__ seq_off, int nreads, char *__restrict__ seq)
-{ const int r = blockIdx.x;
+{ // a thread turns four packed bytes (one 4-byte load) into sixteen letters (one 16-byte store; byte by byte -- one byte in,
+  // four single-byte stores out -- this kernel ran at 0.3 TB/s, a millisecond per 250-Mbase batch of the PCIe pipeline)
+  __shared__ uint32_t s_tab[256];                        // the four letters of a packed byte, first base in the low byte
+  { const unsigned b = threadIdx.x;
+    const char *L = "ACGT";
+    s_tab[b] = (unsigned)L[(b >> 6) & 3] | ((unsigned)L[(b >> 4) & 3] << 8) | ((unsigned)L[(b >> 2) & 3] << 16) | ((unsigned)L[b & 3] << 24);
+  }
+  __syncthreads();
+  const int r = blockIdx.x;
   if (r >= nreads) return;
   const uint8_t *src = packed+pack_off[r];
   char *dst = seq+seq_off[r];
   const int rlen = (int)(seq_off[r+1]-seq_off[r]);
   const int clen = (rlen+3) >> 2;
-  for (int k = threadIdx.x; k < clen; k += blockDim.x)
-    { const unsigned b = src[k];
-      const int p = 4*k;
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-        if (p+q < rlen)
-          dst[p+q] = "ACGT"[(b >> (6-2*q)) & 3];
+  for (int k = 4*threadIdx.x; k < clen; k += 4*blockDim.x)
+    { if (k+4 <= clen && 4*k+16 <= rlen)
+        { const unsigned w = reinterpret_cast<const cp_u8x4 *>(src+k)->v;
+          cp_u8x16 o;
+          o.v[0] = s_tab[w & 0xff]; o.v[1] = s_tab[(w >> 8) & 0xff]; o.v[2] = s_tab[(w >> 16) & 0xff]; o.v[3] = s_tab[w >> 24];
+          *reinterpret_cast<cp_u8x16 *>(dst+4*k) = o;
+        }
+      else
+        for (int kk = k; kk < k+4 && kk < clen; kk++)
+          { const unsigned b = src[kk];
+            const int p = 4*kk;
+            for (int q = 0; q < 4; q++)
+              if (p+q < rlen)
+                dst[p+q] = "ACGT"[(b >> (6-2*q)) & 3];
+          }
     }
 }
 
@@ -2664,7 +2681,6 @@ k_unpack_bases(const uint8_t *__restrict__ packed, const int64_t *__restrict__ p
 //  read's payload of the .class.data track (ClassPro.c:291-300): labels then cross PCIe at 0.25 B/base instead of 1.
 //  One block per read, one output byte (four labels, one unaligned 4-byte load) per thread and step.
 // ---------------------------------------------------------------------------------------------
-struct __attribute__((packed, aligned(1))) cp_u8x4 { uint32_t v; };
 __device__ __forceinline__ unsigned cp_label_code(unsigned c) { return c == 'R' ? 1u : c == 'H' ? 2u : c == 'D' ? 3u : 0u; }
 __global__ void __launch_bounds__(256)
 k_pack_labels(const char *__restrict__ labels, const int64_t *__restrict__ seq_off, const int64_t *__restrict__ pack_off,
@@ -2675,20 +2691,23 @@ k_pack_labels(const char *__restrict__ labels, const int64_t *__restrict__ seq_o
   uint8_t *dst = packed+pack_off[r];
   const int rlen = (int)(seq_off[r+1]-seq_off[r]);
   const int clen = (rlen+3) >> 2;
-  for (int k = threadIdx.x; k < clen; k += blockDim.x)
-    { const int p = 4*k;
-      unsigned b;
-      if (p+4 <= rlen)
-        { const unsigned w = reinterpret_cast<const cp_u8x4 *>(src+p)->v;
-          b = (cp_label_code(w & 0xff) << 6) | (cp_label_code((w >> 8) & 0xff) << 4) | (cp_label_code((w >> 16) & 0xff) << 2)
-              | cp_label_code(w >> 24);
+  auto four = [](unsigned w) -> unsigned
+    { return (cp_label_code(w & 0xff) << 6) | (cp_label_code((w >> 8) & 0xff) << 4) | (cp_label_code((w >> 16) & 0xff) << 2) | cp_label_code(w >> 24); };
+  for (int k = 4*threadIdx.x; k < clen; k += 4*blockDim.x)       // sixteen labels in (one 16-byte load), four bytes out (one store)
+    { if (k+4 <= clen && 4*k+16 <= rlen)
+        { const cp_u8x16 x = *reinterpret_cast<const cp_u8x16 *>(src+4*k);
+          cp_u8x4 o;
+          o.v = four(x.v[0]) | (four(x.v[1]) << 8) | (four(x.v[2]) << 16) | (four(x.v[3]) << 24);
+          *reinterpret_cast<cp_u8x4 *>(dst+k) = o;
         }
       else
-        { b = 0;
-          for (int q = 0; q < 4; q++)
-            if (p+q < rlen) b |= cp_label_code((unsigned char)src[p+q]) << (6-2*q);
-        }
-      dst[k] = (uint8_t)b;
+        for (int kk = k; kk < k+4 && kk < clen; kk++)
+          { const int p = 4*kk;
+            unsigned b = 0;
+            for (int q = 0; q < 4; q++)
+              if (p+q < rlen) b |= cp_label_code((unsigned char)src[p+q]) << (6-2*q);
+            dst[kk] = (uint8_t)b;
+          }
     }
 }
 
