@@ -43,6 +43,9 @@ template <class TAB> CP_HD double cp_exp_t(double x, TAB) { return exp(x); }
 template <class TAB> CP_HD double cp_log_t(double x, TAB) { return log(x); }
 #else
 // e_exp.c: exp(x) = 2^(k/128) * exp(r), x = k ln2/128 + r, |r| <= ln2/256; 2^(k/128) ~= scale*(1+tail) from the table
+// (Tried: the main paths computed unconditionally and the special values -- exp(-inf), log(0), both common on the DP's
+//  impossible transitions -- selected afterwards, log's two evaluations both computed: same bits, fewer exec-mask
+//  instructions, but k_classify_rel_grp 1.41 -> 1.52 ms: the second polynomial costs more than the branches.)
 template <class TAB>
 CP_HD double cp_exp_t(double x, TAB exp_tab)
 { const uint64_t ix = cp_asuint64(x);

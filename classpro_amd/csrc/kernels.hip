@@ -2038,10 +2038,11 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
 #ifndef REL_SMALL_WPB
 #define REL_SMALL_WPB 4
 #endif
-// (4 waves per SIMD = 128 VGPRs with 32 of them spilled to scratch, against 167 and none at 3: 192 against 186 Gbases/s on the
-//  whole bench -- what this kernel waits for is latency, and a fourth wave hides more of it than the spills add; 5: 186)
+// (round 3: 4 waves per SIMD = 128 VGPRs with 32 of them spilled to scratch, against 167 and none at 3: 192 against 186
+//  Gbases/s.  Round 4: the four-wave blocks with the libm tables in LDS, 52 KB, fit three to a CU = 3 waves per SIMD, so
+//  the register target is 3 as well: 159 VGPRs, nothing spilled)
 #ifndef REL_WAVES_PER_EU
-#define REL_WAVES_PER_EU 4
+#define REL_WAVES_PER_EU 3
 #endif
 
 template <int MINM, int MAXM, int G, int WPB>
