@@ -181,6 +181,7 @@ struct Window
       if (ftruncate(fd,(off_t)hi) != 0) die("%s: cannot size the output\n",PROG);
       void *m = mmap(nullptr,(size_t)(hi-base),PROT_READ|PROT_WRITE,MAP_SHARED,fd,(off_t)base);
       if (m == MAP_FAILED) die("%s: cannot map the output file\n",PROG);
+      remember_mapping(m,(size_t)(hi-base));
       if (track) { tmap = (char *)m; tmap_len = (size_t)(hi-base); tmap_base = base; trk_lo = lo; trk_hi = hi; }
       else       { omap = (char *)m; omap_len = (size_t)(hi-base); omap_base = base; out_lo = lo; out_hi = hi; }
     }
@@ -261,8 +262,27 @@ struct Run
 static char g_out_files[4][1024];
 static void remember_output(const std::string &p)
 { for (auto &f : g_out_files) if (!f[0]) { snprintf(f,sizeof(f),"%s",p.c_str()); return; } }
-static void on_sigbus(int)
-{ static const char msg[] = "ClassPro: no space left on the output device (a page of the mapped output could not be allocated)\n";
+// The mapped ranges of the outputs (map_out registers them): a SIGBUS is "no space" only when it comes from a store into
+// one of them.  From anywhere else -- a truncated or changed mapped INPUT, a hardware error -- the default action is
+// restored and the signal raised again, so the diagnosis and the core are the real ones and no output is deleted on a guess.
+static struct { volatile uintptr_t lo, hi; } g_out_maps[64];
+static volatile int g_n_out_maps = 0;
+static std::mutex g_out_maps_m;
+static void remember_mapping(const void *m, size_t len)
+{ std::lock_guard<std::mutex> g(g_out_maps_m);
+  const int k = g_n_out_maps;
+  if (k < 64) { g_out_maps[k].lo = (uintptr_t)m; g_out_maps[k].hi = (uintptr_t)m+len; g_n_out_maps = k+1; }
+}
+static void on_sigbus(int sig, siginfo_t *si, void *)
+{ const uintptr_t a = (uintptr_t)si->si_addr;
+  bool ours = false;
+  for (int k = 0; k < g_n_out_maps; k++) if (a >= g_out_maps[k].lo && a < g_out_maps[k].hi) ours = true;
+  if (!ours)
+    { signal(sig,SIG_DFL);
+      raise(sig);
+      return;
+    }
+  static const char msg[] = "ClassPro: no space left on the output device (a page of the mapped output could not be allocated)\n";
   ssize_t w = write(2,msg,sizeof(msg)-1); (void)w;
   for (auto &f : g_out_files) if (f[0]) unlink(f);
   _exit(1);
@@ -670,7 +690,7 @@ int main(int argc, char **argv)
   R.out_fd = open(out_path.c_str(),O_RDWR|O_CREAT|O_TRUNC,0644);
   if (R.out_fd < 0) die("Cannot open %s\n",out_path.c_str());
   remember_output(out_path);
-  { struct sigaction sa; memset(&sa,0,sizeof(sa)); sa.sa_handler = on_sigbus; sigaction(SIGBUS,&sa,nullptr); }
+  { struct sigaction sa; memset(&sa,0,sizeof(sa)); sa.sa_sigaction = on_sigbus; sa.sa_flags = SA_SIGINFO; sigaction(SIGBUS,&sa,nullptr); }
   if (is_db)
     { // .anno: int nreads, int size = 8, int64 0, then the end offset of every read's data (what merge_anno, io.c:15-68,
       // makes of the per-thread pieces); the offsets only depend on the read lengths, so the file is written up front
