@@ -54,6 +54,8 @@
 #include "thread_pool.h"
 #include "fastx_index.h"
 
+static void remember_mapping(const void *m, size_t len);      // (SIGBUS handling, below)
+
 static const char *USAGE = "[-vs] [-T<int(4)>] [-c<int>] [-r<int(20000)>] "
                            "[-P<tmp_dir(./)>] [-N<fastk_root>] [-M<model_path>] "
                            "<source>[.db|.dam|.f[ast][aq][.gz]";                      // const.c:14-17
