@@ -21,3 +21,9 @@ import json
 j=json.loads(open("gpurun_out/validate/n2.json").read().strip().splitlines()[-1])
 print("2 ranks (gloo, one GPU):", j["value"], j["n_gpus"], j["config"]["workload"][:200], j["extras"]["resident_windows_per_rank"])
 PY
+# two ranks with the default 30-Gbase windows on ONE card: the pre-flight check must stop all of them with exit code 2 and a sentence
+set +e
+python bench.py --gpus 2 --backend gloo --no-cpu --no-extras --steps 1 --warmup 1 > $O/n2_default.json 2> $O/n2_default.err; rc=$?
+set -e
+echo "2 ranks, default windows, one card: exit code $rc (2 expected)"; grep "bench.py: rank" $O/n2_default.err | head -2
+python bench.py --gpus 1 --backend nccl --force-dist --no-cpu --no-extras --steps 3 --warmup 1 > $O/nccl1.json 2> $O/nccl1.err && echo "nccl world 1 ok: $(cut -c1-120 $O/nccl1.json)"
