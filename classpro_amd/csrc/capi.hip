@@ -536,8 +536,8 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
                      (int32_t *)ws->fwc.p);
   // find_rel_intvl inside k_find_wall (CLASSPRO_FUSE_REL=0: as a kernel of its own, always so when the call stops at
   // the wall stage: the stage API shows find_wall's records as the reference's find_wall leaves them)
-  static const bool fuse_env = []{ const char *e = getenv("CLASSPRO_FUSE_REL"); return !e || atol(e) != 0; }();
-  const bool fuse_rel = fuse_env && last_stage >= CP_STAGE_REL;
+  const char *fuse_e = getenv("CLASSPRO_FUSE_REL");       // (read per call: the parity test runs both forms in one process)
+  const bool fuse_rel = (!fuse_e || atol(fuse_e) != 0) && last_stage >= CP_STAGE_REL;
   ENSURE(ws->rintvl,(size_t)totalI*sizeof(cp_intvl));
   ENSURE(ws->relmap,(size_t)totalI*4);
   hipLaunchKernelGGL(k_find_wall,dim3(nreads),dim3(WAVE),0,st,

@@ -1484,7 +1484,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   // wall.c:928-946, one lane per interval -- and, on the whole-path call (do_rel), find_rel_intvl / correct_wall_cnt
   // (wall.c:960-1051) on the record while it is still in the lane's registers: every interval is independent, the
   // reliable ones are compacted in order (ballot + popcount) into rintvl / relmap.  As a kernel of its own (k_find_rel,
-  // still the stage API's) this pass re-read every record, wrote it a second time and sat 0.9 ms per 1-Gbase sub-batch
+  // now only with CLASSPRO_FUSE_REL=0) this pass re-read every record, wrote it a second time and sat 0.9 ms per 1-Gbase sub-batch
   // between the walk and the classification (fused: 2.13 ms for both against 1.53 + 0.95 alone on the machine).
   // (Tried on top: the four step sums of correct_wall_cnt from two 64-count register windows fetched by sixteen
   //  independent loads, instead of cp_sum_steps' eight counts per dependent load -- as an inlined body 205 registers

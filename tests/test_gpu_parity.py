@@ -557,6 +557,47 @@ def test_adversarial_inputs(torch_dev, seed):
     clf.close()
 
 
+def test_find_rel_fused_and_as_a_kernel(torch_dev, ds_a, monkeypatch):
+    """find_rel_intvl runs inside k_find_wall on the whole-path call (CLASSPRO_FUSE_REL unset) or as k_find_rel
+    (CLASSPRO_FUSE_REL=0): same labels, same interval records byte for byte, both equal to the oracle's labels."""
+    from classpro_amd.api import Classifier, Batch, INTVL_DTYPE, STAGE_CLASS_ALL
+    from classpro_amd._lib import check
+    from oracle.oracle import Oracle
+    from adversarial import adversarial_reads, tail_run_reads
+    ds, h, d = ds_a
+    a_s, a_p = adversarial_reads(12, n=120)
+    t_s, t_p = tail_run_reads(13, n=60)
+    O = Oracle(K, 20000, h, d)
+    seqs, profs = list(ds["seqs"][:150]), list(ds["profiles"][:150])
+    for s_, p_ in zip(a_s + t_s, a_p + t_p):
+        try:
+            O.classify_read(s_, p_)
+        except OverflowError:
+            continue
+        seqs.append(s_); profs.append(p_)
+    want = b"".join(O.classify_read(s_, p_) for s_, p_ in zip(seqs, profs))
+    out = []
+    for env in (None, "0"):
+        if env is None:
+            monkeypatch.delenv("CLASSPRO_FUSE_REL", raising=False)
+        else:
+            monkeypatch.setenv("CLASSPRO_FUSE_REL", env)
+        clf = Classifier(K, 20000, h, d)
+        b = Batch.from_reads(seqs, profs)
+        lab = clf.classify(b).tobytes()
+        clf.run(b, STAGE_CLASS_ALL)
+        nc, ni, nr, off = clf.counts(b)
+        tot = int(off[-1])
+        iv = np.zeros((tot, INTVL_DTYPE.itemsize), np.uint8)
+        rv = np.zeros((tot, INTVL_DTYPE.itemsize), np.uint8)
+        check(clf.L.cp_get_intervals(clf.ws, iv.ctypes.data, rv.ctypes.data, tot))
+        idx = np.arange(tot) - off[np.searchsorted(off, np.arange(tot), side="right") - 1]
+        out.append((lab, iv[idx < np.repeat(ni, np.diff(off))].tobytes(), rv[idx < np.repeat(nr, np.diff(off))].tobytes(), nr.tobytes()))
+        clf.close()
+    assert out[0][0] == want
+    assert out[0] == out[1]
+
+
 def test_fuzz_regressions(torch_dev):
     """Reads that the fuzz soak (scripts/fuzz_parity.py) once found different.  fuzz305_34: classify_unrel's argmax meets
     log(px*py) against log(px)+log(py); with ocml's log the device said E where the oracle (glibc) says D."""
