@@ -459,6 +459,10 @@ def pcie_pipeline(a, ds, clf, batches, dev):
         os.sched_setaffinity(0, cpus & aff0)                # feeder / packing threads and first-touch of the pinned buffers on the GPU's node
         pinned_to = len(cpus & aff0)
     res["feeder_cpus_on_gpu_node"] = pinned_to
+    # a box that gives this process few cores: the slots' packing threads share them instead of oversubscribing them sixfold
+    ncpu = pinned_to or len(aff0)
+    if a.pcie_slots * (a.pcie_pack_threads + 1) > ncpu:
+        a.pcie_pack_threads = max(1, ncpu // max(1, a.pcie_slots) - 1)
     try:
         # ---- stage the inputs in pinned memory (untimed) ----
         want = int(a.pcie_gbases * 1e9)
