@@ -527,7 +527,15 @@ def pcie_pipeline(a, ds, clf, batches, dev):
                            d_seq=torch.empty(mx("bases") + 64, dtype=torch.uint8, device=dev),
                            d_prof=torch.empty(mx("kmers") + 64, dtype=torch.int16, device=dev),
                            d_lab=torch.empty(mx("bases") + 64, dtype=torch.uint8, device=dev),
-                           d_plab=torch.empty(mx("npk") + 64, dtype=torch.uint8, device=dev), t_pack=0.0, done=[]))
+                           d_plab=torch.empty(mx("npk") + 64, dtype=torch.uint8, device=dev), t_pack=0.0, done=[],
+                           # labels as runs: (end, class) per run at the capacity offsets of the interval arrays (about 0.01 entries per base)
+                           rcap=int(0.03 * mx("bases")) + 4096,
+                           d_rend=torch.empty(int(0.03 * mx("bases")) + 4096, dtype=torch.int32, device=dev),
+                           d_rcls=torch.empty(int(0.03 * mx("bases")) + 4096, dtype=torch.uint8, device=dev),
+                           d_rmeta=torch.empty(3 * (mx("n") + 1), dtype=torch.int64, device=dev),      # cap_off[n+1] | nruns[n] (int32 pairs)
+                           h_rend=torch.empty(int(0.03 * mx("bases")) + 4096, dtype=torch.int32).pin_memory(),
+                           h_rcls=torch.empty(int(0.03 * mx("bases")) + 4096, dtype=torch.uint8).pin_memory(),
+                           h_rmeta=torch.empty(3 * (mx("n") + 1), dtype=torch.int64).pin_memory(), out_b=0, last_cap=0))
 
         # ---- the pinned-copy peaks of this box, this process, these buffers ----
         big = max(hb, key=lambda x: x["bases"])
@@ -566,6 +574,8 @@ def pcie_pipeline(a, ds, clf, batches, dev):
         del dbuf, hback
 
         # ---- the pipeline ----
+        mode = {"labels": "2bit"}                            # "2bit": cp_pack_labels; "runs": cp_label_runs (no painted string at all)
+
         def feed(k, order):
             q = sl[k]
             torch.cuda.set_device(dev)
@@ -592,10 +602,26 @@ def pcie_pipeline(a, ds, clf, batches, dev):
                     d_so, d_po, d_co, d_pko = o, o + 8 * (n + 1), o + 16 * (n + 1), o + 24 * (n + 1)
                     check(L.cp_unpack_bases(q["d_pk"].data_ptr(), d_pko, d_so, n, q["d_seq"].data_ptr(), sp))
                     check(L.cp_decode_profiles(q["ws"], q["d_code"].data_ptr(), d_co, d_po, n, q["d_prof"].data_ptr(), sp))
-                    check(L.cp_classify_batch(clf.p, q["ws"], q["d_seq"].data_ptr(), d_so, q["d_prof"].data_ptr(), d_po, n,
-                                              x["bases"], x["kmers"], q["d_lab"].data_ptr(), sp))
-                    check(L.cp_pack_labels(q["d_lab"].data_ptr(), d_so, d_pko, n, q["d_plab"].data_ptr(), sp))
-                    q["h_plab"][:x["npk"]].copy_(q["d_plab"][:x["npk"]], non_blocking=True)
+                    if mode["labels"] == "2bit":
+                        check(L.cp_classify_batch(clf.p, q["ws"], q["d_seq"].data_ptr(), d_so, q["d_prof"].data_ptr(), d_po, n,
+                                                  x["bases"], x["kmers"], q["d_lab"].data_ptr(), sp))
+                        check(L.cp_pack_labels(q["d_lab"].data_ptr(), d_so, d_pko, n, q["d_plab"].data_ptr(), sp))
+                        q["h_plab"][:x["npk"]].copy_(q["d_plab"][:x["npk"]], non_blocking=True)
+                        q["out_b"] += x["npk"]
+                    else:
+                        check(L.cp_run_stages(clf.p, q["ws"], q["d_seq"].data_ptr(), d_so, q["d_prof"].data_ptr(), d_po, n,
+                                              x["bases"], x["kmers"], None, 5, sp))                 # CP_STAGE_CLASS_ALL: no label string
+                        cap = int(L.cp_label_runs_capacity(q["ws"]))
+                        if cap > q["rcap"]:
+                            raise RuntimeError("label-run buffers too small: %d > %d" % (cap, q["rcap"]))
+                        m = q["d_rmeta"].data_ptr()
+                        check(L.cp_label_runs(clf.p, q["ws"], q["d_rend"].data_ptr(), q["d_rcls"].data_ptr(), m + 8 * (n + 1), m, sp))
+                        q["h_rend"][:cap].copy_(q["d_rend"][:cap], non_blocking=True)
+                        q["h_rcls"][:cap].copy_(q["d_rcls"][:cap], non_blocking=True)
+                        nm = (n + 1) + (n + 1) // 2 + 1
+                        q["h_rmeta"][:nm].copy_(q["d_rmeta"][:nm], non_blocking=True)
+                        q["out_b"] += 5 * cap + 8 * nm
+                        q["last_cap"] = cap
                     q["done"].append(j)
                 q["st"].synchronize()
 
@@ -616,49 +642,70 @@ def pcie_pipeline(a, ds, clf, batches, dev):
             if errs:
                 raise errs[0]
         nbt = len(hb)
-        run(list(range(min(nbt, 2 * NS))))                  # warm-up: workspaces grow, pages are touched
-        for q in sl:
-            q["t_pack"] = 0.0
-        t0 = time.perf_counter()
-        run(list(range(nbt)))
-        t1 = time.perf_counter() - t0
-        passes = 1
-        if t1 < a.pcie_seconds:                             # repeat the staged set until the span is long enough
-            more = int(np.ceil(1.6 * a.pcie_seconds / t1))  # (the first pass is the slowest)
+        from classpro_amd.api import unpack_labels, expand_label_runs
+        for lab_mode in ("2bit", "runs"):
+            mode["labels"] = lab_mode
             for q in sl:
-                q["t_pack"] = 0.0
+                q["done"] = []
+            run(list(range(min(nbt, 2 * NS))))              # warm-up: workspaces grow, pages are touched
+            for q in sl:
+                q["t_pack"], q["out_b"] = 0.0, 0
             t0 = time.perf_counter()
-            run(list(range(nbt)) * more)
+            run(list(range(nbt)))
             t1 = time.perf_counter() - t0
-            passes = more
-        for q in sl:
-            check(L.cp_workspace_check(q["ws"]))
-        tot_bases = sum(x["bases"] for x in hb) * passes
-        in_bytes = sum(x["npk"] + x["ncode"] + 32 * (x["n"] + 1) for x in hb) * passes
-        out_bytes = sum(x["npk"] for x in hb) * passes
-        # every slot's last batch: the 2-bit labels that came back == the resident run's labels, packed by the same layout
-        ok = True
-        from classpro_amd.api import unpack_labels
-        for q in sl:
-            j = q["done"][-1]
-            x = hb[j]
-            rd, b, r0, r1 = x["src"]
-            so_all = rd["seq_off_h"]
-            want_lab = b.labels[so_all[r0]:so_all[r1]].cpu().numpy()
-            got = unpack_labels(q["h_plab"].numpy(), x["pko"], np.diff(x["so"]), K)
-            ok &= bool(np.array_equal(got, want_lab))
-        res.update({"mbases_per_s": round(tot_bases / t1 / 1e6, 1), "seconds": round(t1, 3), "bases": tot_bases,
-                    "distinct_gbases_staged": round(sum(x["bases"] for x in hb) / 1e9, 2), "passes_over_staged_set": passes,
-                    "batches": nbt * passes, "batch_mbases": round(np.mean([x["bases"] for x in hb]) / 1e6, 1), "slots": NS,
-                    "pack_threads_per_slot": a.pcie_pack_threads,
-                    "host_pack_seconds_per_slot": [round(q["t_pack"], 3) for q in sl],
-                    "bytes_per_base_in_out": [round(in_bytes / tot_bases, 3), round(out_bytes / tot_bases, 3)],
-                    "h2d_gb_per_s": round(in_bytes / t1 / 1e9, 2), "d2h_gb_per_s": round(out_bytes / t1 / 1e9, 2),
-                    "labels_match_resident_run": ok})
-        # the pipeline moves data both ways at once: it is judged against what pinned copies both ways at once reach
-        res["link_gb_per_s_in_plus_out"] = round((in_bytes + out_bytes) / t1 / 1e9, 2)
-        res["frac"] = round(res["link_gb_per_s_in_plus_out"] / max(res["pinned_both_ways_gb_per_s_in_plus_out"], res["pinned_h2d_peak_gb_per_s"]), 3)
-        res["frac_of"] = "pinned copies both ways at once (in + out), %d streams each way, measured in this run" % NCS
+            passes = 1
+            if t1 < a.pcie_seconds:                         # repeat the staged set until the span is long enough
+                more = int(np.ceil(1.6 * a.pcie_seconds / t1))  # (the first pass is the slowest)
+                for q in sl:
+                    q["t_pack"], q["out_b"] = 0.0, 0
+                t0 = time.perf_counter()
+                run(list(range(nbt)) * more)
+                t1 = time.perf_counter() - t0
+                passes = more
+            for q in sl:
+                check(L.cp_workspace_check(q["ws"]))
+            tot_bases = sum(x["bases"] for x in hb) * passes
+            in_bytes = sum(x["npk"] + x["ncode"] + 32 * (x["n"] + 1) for x in hb) * passes
+            out_bytes = sum(q["out_b"] for q in sl)
+            # every slot's last batch: the labels that came back == the resident run's labels
+            ok = True
+            for q in sl:
+                j = q["done"][-1]
+                x = hb[j]
+                rd, b, r0, r1 = x["src"]
+                so_all = rd["seq_off_h"]
+                want_lab = b.labels[so_all[r0]:so_all[r1]].cpu().numpy()
+                if lab_mode == "2bit":
+                    got = unpack_labels(q["h_plab"].numpy(), x["pko"], np.diff(x["so"]), K)
+                    ok &= bool(np.array_equal(got, want_lab))
+                else:
+                    n = x["n"]
+                    meta = q["h_rmeta"].numpy()
+                    coff = meta[:n + 1]
+                    nr = meta[n + 1:n + 1 + (n + 1) // 2 + 1].view(np.int32)[:n]
+                    ends, cls = q["h_rend"].numpy(), q["h_rcls"].numpy()
+                    for r in range(0, n, max(1, n // 200)):  # a sample of the batch's reads, expanded on the host
+                        got = expand_label_runs(ends[coff[r]:coff[r] + nr[r]], cls[coff[r]:coff[r] + nr[r]], int(x["so"][r + 1] - x["so"][r]), K)
+                        ok &= got == want_lab[x["so"][r]:x["so"][r + 1]].tobytes()
+            one = {"mbases_per_s": round(tot_bases / t1 / 1e6, 1), "seconds": round(t1, 3), "bases": tot_bases,
+                   "distinct_gbases_staged": round(sum(x["bases"] for x in hb) / 1e9, 2), "passes_over_staged_set": passes,
+                   "batches": nbt * passes, "batch_mbases": round(np.mean([x["bases"] for x in hb]) / 1e6, 1), "slots": NS,
+                   "pack_threads_per_slot": a.pcie_pack_threads,
+                   "host_pack_seconds_per_slot": [round(q["t_pack"], 3) for q in sl],
+                   "bytes_per_base_in_out": [round(in_bytes / tot_bases, 3), round(out_bytes / tot_bases, 3)],
+                   "h2d_gb_per_s": round(in_bytes / t1 / 1e9, 2), "d2h_gb_per_s": round(out_bytes / t1 / 1e9, 2),
+                   "labels_match_resident_run": ok}
+            # the pipeline moves data both ways at once: it is judged against what pinned copies both ways at once reach
+            one["link_gb_per_s_in_plus_out"] = round((in_bytes + out_bytes) / t1 / 1e9, 2)
+            one["frac"] = round(one["link_gb_per_s_in_plus_out"] / max(res["pinned_both_ways_gb_per_s_in_plus_out"], res["pinned_h2d_peak_gb_per_s"]), 3)
+            one["h2d_frac_of_one_way_peak"] = round(one["h2d_gb_per_s"] / res["pinned_h2d_peak_gb_per_s"], 3)
+            if lab_mode == "2bit":
+                one["labels_out"] = "2-bit codes (cp_pack_labels), the .class.data payload"
+                res.update(one)
+                res["frac_of"] = "pinned copies both ways at once (in + out), %d streams each way, measured in this run" % NCS
+            else:
+                one["labels_out"] = "runs (cp_label_runs): (end, class) per stretch of one class; the label string is never painted on the device"
+                res["label_runs"] = one
         for q in sl:
             L.cp_workspace_destroy(q["ws"])
     finally:

@@ -16,6 +16,7 @@ SYMBOLS = [
     "cp_get_intervals", "cp_get_rel_asgn", "cp_get_bitmap", "cp_seq_context", "cp_scan_candidates",
     "cp_encode_profile", "cp_decode_profiles", "cp_params_create_model", "cp_load_error_model", "cp_unpack_bases",
     "cp_find_seeds_batch", "cp_get_rep_masks", "cp_rep_masks_capacity", "cp_params_tables", "cp_pack_bases", "cp_pack_labels", "cp_unpack_labels", "cp_math_eval", "cp_pack_bases_batch",
+    "cp_label_runs", "cp_label_runs_capacity", "cp_expand_label_runs",
 ]
 
 _lib = None
@@ -55,6 +56,10 @@ def lib():
     L.cp_params_export.argtypes = [vp] + [vp] * 7
     L.cp_params_tables.argtypes = [vp, vp, vp, vp]
     L.cp_math_eval.argtypes = [i32, vp, vp, vp, i64, vp]
+    L.cp_label_runs.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.cp_label_runs_capacity.argtypes = [vp]
+    L.cp_label_runs_capacity.restype = i64
+    L.cp_expand_label_runs.argtypes = [vp, vp, i32, i32, i32, vp]
     L.cp_pack_bases.argtypes = [vp, i32, vp]
     L.cp_pack_bases_batch.argtypes = [vp, vp, i32, vp, vp, i32]
     L.cp_pack_labels.argtypes = [vp, vp, vp, i32, vp, vp]

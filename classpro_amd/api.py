@@ -98,6 +98,16 @@ def math_eval(fn, x, x2=None, device="cuda:0"):
     return yd.cpu().numpy()
 
 
+def expand_label_runs(ends, cls, rlen, K):
+    """cp_expand_label_runs: one read's label string from its runs."""
+    ends = np.ascontiguousarray(ends, np.int32)
+    cls = np.ascontiguousarray(cls, np.uint8)
+    out = np.zeros(max(rlen, 1), np.uint8)
+    check(lib().cp_expand_label_runs(ends.ctypes.data if len(ends) else None, cls.ctypes.data if len(cls) else None, len(ends), rlen, K,
+                                     out.ctypes.data))
+    return out[:rlen].tobytes()
+
+
 class Batch:
     """A batch of reads resident in HBM in the flat layout of include/classpro_amd.h."""
 
@@ -201,6 +211,21 @@ class Classifier:
 
     def check(self):
         check(self.L.cp_workspace_check(self.ws))
+
+    def label_runs(self, b):
+        """The batch's labels as runs (cp_label_runs): classification without painting the label string, then per read
+        (ends int32[n], cls uint8[n]); `expand_label_runs` rebuilds the strings on the host."""
+        self.run(b, STAGE_CLASS_ALL)
+        cap = int(self.L.cp_label_runs_capacity(self.ws))
+        dev = self.device
+        d_end = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+        d_cls = torch.empty(max(cap, 1), dtype=torch.uint8, device=dev)
+        d_nr = torch.empty(max(b.nreads, 1), dtype=torch.int32, device=dev)
+        d_off = torch.empty(b.nreads + 1, dtype=torch.int64, device=dev)
+        check(self.L.cp_label_runs(self.p, self.ws, d_end.data_ptr(), d_cls.data_ptr(), d_nr.data_ptr(), d_off.data_ptr(), self._stream()))
+        check(self.L.cp_workspace_check(self.ws))
+        ends, cls, nr, off = d_end.cpu().numpy(), d_cls.cpu().numpy(), d_nr.cpu().numpy(), d_off.cpu().numpy()
+        return [(ends[off[r]:off[r] + nr[r]].copy(), cls[off[r]:off[r] + nr[r]].copy()) for r in range(b.nreads)]
 
     def find_seeds(self, b):
         """-s (seed.c:966-1032) on a batch already labelled by classify()/run(): returns (seed labels as host bytes

@@ -935,6 +935,42 @@ extern "C" int cp_pack_bases_batch(const char *seq, const int64_t *seq_off, int 
   return 1;
 }
 
+// Labels as runs (kernels.hip: k_label_runs) of the batch last classified on `ws` (cp_run_stages up to CP_STAGE_CLASS_ALL or
+// cp_classify_batch): d_ends / d_cls take cp_label_runs_capacity(ws) entries, d_nruns nreads, d_cap_off nreads+1 (a copy of the
+// capacity offsets: read r's runs start at index d_cap_off[r]).
+extern "C" int64_t cp_label_runs_capacity(const cp_workspace *ws) { return ws ? ws->totalI : 0; }
+
+extern "C" int cp_label_runs(const cp_params *p, cp_workspace *ws, int32_t *d_ends, uint8_t *d_cls, int32_t *d_nruns, int64_t *d_cap_off,
+                             void *stream)
+{ if (!p || !ws || (ws->nreads > 0 && (!d_ends || !d_cls || !d_nruns || !d_cap_off)))
+    return set_err(CP_EINVAL,"cp_label_runs: bad argument");
+  if (ws->nreads == 0) return CP_OK;
+  if (ws->last_stage < CP_STAGE_CLASS_ALL)
+    return set_err(CP_EINVAL,"cp_label_runs: the batch on this workspace was not classified (run at least CP_STAGE_CLASS_ALL)");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_label_runs,dim3(ws->nreads),dim3(WAVE),0,st,p->dev,ws->nreads,(const cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,
+                     (const int32_t *)ws->nintvl.p,d_ends,d_cls,d_nruns);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(d_cap_off,ws->ioff.p,((size_t)ws->nreads+1)*8,hipMemcpyDeviceToDevice,st));
+  return CP_OK;
+}
+
+// host: the label string of one read from its runs (K-1 'N', then run j = labels [ends[j-1], ends[j]) of class cls[j])
+extern "C" int cp_expand_label_runs(const int32_t *ends, const uint8_t *cls, int nruns, int rlen, int K, char *labels)
+{ if (rlen < 0 || nruns < 0 || K < 1 || (rlen > 0 && !labels) || (nruns > 0 && (!ends || !cls)))
+    return set_err(CP_EINVAL,"cp_expand_label_runs: bad argument");
+  int pos = K-1 < rlen ? K-1 : rlen;
+  memset(labels,'N',(size_t)pos);
+  for (int j = 0; j < nruns; j++)
+    { const int e = ends[j];
+      if (e < pos || e > rlen) return set_err(CP_EINVAL,"cp_expand_label_runs: runs out of order or beyond the read");
+      memset(labels+pos,(int)cls[j],(size_t)(e-pos));
+      pos = e;
+    }
+  if (nruns > 0 && pos != rlen) return set_err(CP_EINVAL,"cp_expand_label_runs: the runs do not cover the read");
+  return CP_OK;
+}
+
 extern "C" int cp_seq_context(const char *d_seq, const int64_t *d_seq_off, int nreads, int64_t total_bases,
                               uint8_t *d_lctx, uint8_t *d_rctx, void *stream)
 { if (!d_seq || !d_seq_off || !d_lctx || !d_rctx || nreads < 0)

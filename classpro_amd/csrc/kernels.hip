@@ -2677,6 +2677,41 @@ k_unpack_bases(const uint8_t *__restrict__ packed, const int64_t *__restrict__ p
 }
 
 // ---------------------------------------------------------------------------------------------
+//  k_label_runs: the label string of a read as RUNS -- (end, class) per maximal stretch of one class, the K-1 'N' in
+//  front implicit.  A read has ~100 intervals and fewer runs, so labels cross PCIe at ~0.05 B/base instead of 1 (characters)
+//  or 0.25 (2-bit codes), and the painted string (1 B/base of HBM writes) is not needed at all: the caller stops the
+//  pipeline at the classification stage.  One wave per read, a lane per interval, ordered compaction by ballot; read r's
+//  runs go to index ioff[r] .. of `ends` / `cls` (the capacity offsets of the interval arrays: runs <= intervals).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WAVE)
+k_label_runs(const cp_dev_params *__restrict__ P, int nreads, const cp_intvl *__restrict__ intvl_all, const int64_t *__restrict__ ioff,
+             const int32_t *__restrict__ nintvl, int32_t *__restrict__ ends, uint8_t *__restrict__ cls, int32_t *__restrict__ nruns)
+{ const int r = blockIdx.x;
+  if (r >= nreads) return;
+  const int lane = lane_id();
+  const int Km1 = P->K-1;
+  const int64_t o = ioff[r];
+  const cp_intvl *intvl = intvl_all+o;
+  const int N = nintvl[r];
+  int nr = 0;
+  for (int base = 0; base < N; base += WAVE)
+    { const int k = base+lane;
+      int e = 0; unsigned c = 0; bool last = false;
+      if (k < N)
+        { e = intvl[k].e+Km1; c = cp_label_char(intvl[k].asgn);
+          last = (k == N-1) || cp_label_char(intvl[k+1].asgn) != c;
+        }
+      const uint64_t m = __ballot(last);
+      if (last)
+        { const int64_t at = o+nr+__popcll(m & ((1ull << lane)-1));
+          ends[at] = e; cls[at] = (uint8_t)c;
+        }
+      nr += __popcll(m);
+    }
+  if (lane == 0) nruns[r] = nr;
+}
+
+// ---------------------------------------------------------------------------------------------
 //  k_pack_labels: the label string of a read as 2-bit codes, four per byte, first label in the top bits --
 //  ctos (const.c:21-36: N, E -> 0, R -> 1, H -> 2, D -> 3) followed by Compress_Read (gene_core.c:235-254), i.e. the
 //  read's payload of the .class.data track (ClassPro.c:291-300): labels then cross PCIe at 0.25 B/base instead of 1.

@@ -170,6 +170,18 @@ int cp_pack_labels(const char *d_labels, const int64_t *d_seq_off, const int64_t
                    uint8_t *d_packed, void *stream);
 int cp_unpack_labels(const uint8_t *packed, int rlen, int K, char *labels);
 
+/* Labels as RUNS, the smallest form in which a batch's result crosses PCIe (~0.05 B/base): the label string of a read
+ * (ClassPro.c:265-271: K-1 'N', then the class of every interval over its k-mers) is K-1 'N' followed by runs; run j
+ * covers label positions [ends[j-1], ends[j]) (ends[-1] = K-1) with the character cls[j] (stoc, const.c:19).  After
+ * cp_classify_batch -- or cp_run_stages(..., CP_STAGE_CLASS_ALL, ...), which skips painting the 1 B/base label string
+ * altogether -- cp_label_runs writes the runs of read r at index d_cap_off[r] .. d_cap_off[r]+d_nruns[r] of d_ends /
+ * d_cls; the arrays take cp_label_runs_capacity(ws) entries (a loose bound: the interval capacity of the batch, about
+ * 0.01 per base), d_nruns nreads, d_cap_off nreads+1 entries.  cp_expand_label_runs (host) rebuilds one read's string. */
+int64_t cp_label_runs_capacity(const cp_workspace *ws);
+int cp_label_runs(const cp_params *p, cp_workspace *ws, int32_t *d_ends, uint8_t *d_cls, int32_t *d_nruns, int64_t *d_cap_off,
+                  void *stream);
+int cp_expand_label_runs(const int32_t *ends, const uint8_t *cls, int nruns, int rlen, int K, char *labels);
+
 /* -s: replaces find_seeds (src/seed.c:966-1032; call site ClassPro.c:281-282) for every read of a batch that
  * cp_classify_batch has labelled.  d_labels is that call's output; d_seeds[total_bases] receives, in the same layout,
  * 'N' for the first K-1 bases of a read and per k-mer 'E' (no seed) or the class of the seed, 'H' / 'D' / 'R' (a seed

@@ -8,13 +8,15 @@ import numpy as np
 from classpro_amd.api import Classifier, Batch
 from classpro_amd._lib import ClassProError
 from oracle.oracle import Oracle
-from adversarial import adversarial_reads
+from adversarial import adversarial_reads, tail_run_reads
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 covs = [(20, 40), (19, 38), (30, 60), (45, 90), (12, 25), (60, 120)]
 nreads = nbad = nrej = 0
 for seed in range(first, first + count):
     seqs, profs = adversarial_reads(seed)
+    ts, tp = tail_run_reads(seed, n=60)                     # reads that end in a low-complexity run (hazard 8)
+    seqs, profs = seqs + ts, profs + tp
     hc, dc = covs[seed % len(covs)]
     O = Oracle(40, 20000, hc, dc)
     clf = Classifier(K=40, read_len=20000, hcov=hc, dcov=dc)

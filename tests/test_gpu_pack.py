@@ -59,3 +59,52 @@ def test_two_bit_round_trip(built):
     got2 = clf.classify(Batch(seq2, so2, prof2, po2))
     assert np.array_equal(got2, Oracle(K, 20000, 15, 30).classify_batch(seq2, so2, prof2, po2, nthreads=2))
     clf.close()
+
+
+def test_label_runs(built):
+    """cp_label_runs + cp_expand_label_runs: the labels of a batch as (end, class) runs equal the painted label string and the
+    oracle's, read by read -- long reads, adversarial ones (hundreds of intervals, overflow-free), reads shorter than K,
+    a read of exactly K bases; the runs of a read are strictly increasing, neighbouring runs differ in class, and the
+    whole batch needs far fewer bytes than the 2-bit form."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from adversarial import adversarial_reads, tail_run_reads
+    from classpro_amd import synth
+    from classpro_amd.api import Classifier, Batch, expand_label_runs
+    from classpro_amd._lib import ClassProError, check
+    from oracle.oracle import Oracle
+    ds = synth.make_dataset(genome_len=150000, cov=30, read_len=7000, seed=22)
+    O = Oracle(K, 20000, 15, 30)
+    seqs, profs = list(ds["seqs"]), list(ds["profiles"])
+    a_s, a_p = adversarial_reads(31, n=120)
+    t_s, t_p = tail_run_reads(32, n=40)
+    for s_, p_ in zip(a_s + t_s, a_p + t_p):
+        try:
+            O.classify_read(s_, p_)
+        except OverflowError:
+            continue
+        seqs.append(s_); profs.append(p_)
+    seqs += [b"ACGT" * 9 + b"ACG", b"A" * 40, b"ACGTT" * 8 + b"A", b"C"]
+    profs += [np.zeros(0, np.uint16), np.array([5], np.uint16), np.array([3, 3], np.uint16), np.zeros(0, np.uint16)]
+    seq, so, prof, po = synth.pack_batch(seqs, profs)
+    clf = Classifier(K=K, read_len=20000, hcov=15, dcov=30)
+    b = Batch(seq, so, prof, po)
+    want = clf.classify(b).copy()
+    assert np.array_equal(want, O.classify_batch(seq, so, prof, po, nthreads=4))
+    runs = clf.label_runs(Batch(seq, so, prof, po))
+    nbytes = 0
+    for r, (ends, cls) in enumerate(runs):
+        rlen = int(so[r + 1] - so[r])
+        assert expand_label_runs(ends, cls, rlen, K) == want[so[r]:so[r + 1]].tobytes(), r
+        assert np.all(np.diff(ends) > 0) and np.all(cls[1:] != cls[:-1]), r
+        assert (len(ends) == 0) == (rlen < K)
+        nbytes += 5 * len(ends) + 12
+    assert nbytes * 8 < int(so[-1])                                             # < 0.125 B/base even on this adversarial mix
+    # the expander refuses runs that do not cover the read
+    ends, cls = runs[0]
+    with pytest.raises(ClassProError):
+        expand_label_runs(ends[:-1], cls[:-1], int(so[1] - so[0]), K)
+    clf.close()

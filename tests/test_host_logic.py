@@ -323,3 +323,16 @@ def test_pack_bases_and_unpack_labels_host(built):
         pk = dazz.pack_2bit(codes)
         got = unpack_labels(pk, [0], [n], K)
         assert got.tobytes() == lab.tobytes(), n
+
+
+def test_expand_label_runs_host(built):
+    """cp_expand_label_runs: K-1 'N', then the runs; refuses runs that are out of order, beyond the read or do not cover it."""
+    from classpro_amd.api import expand_label_runs
+    from classpro_amd._lib import ClassProError
+    K = 5
+    assert expand_label_runs([7, 9, 12], np.frombuffer(b"DEH", np.uint8), 12, K) == b"NNNNDDDEEHHH"
+    assert expand_label_runs([], [], 3, K) == b"NNN"                       # a read shorter than K
+    assert expand_label_runs([5], np.frombuffer(b"R", np.uint8), 5, K) == b"NNNNR"
+    for ends, rlen in (([7, 6, 12], 12), ([7, 13], 12), ([7, 9], 12)):
+        with pytest.raises(ClassProError):
+            expand_label_runs(ends, np.frombuffer(b"DEH", np.uint8)[:len(ends)], rlen, K)
