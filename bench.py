@@ -194,7 +194,15 @@ def main():
         dist.all_reduce(fr, op=dist.ReduceOp.MIN)           # (the ranks look at different moments: take the lowest figure)
         free_b = int(fr.item()) if sharers > 1 else free_b
     need *= sharers
-    if need > free_b:
+    short = need > free_b
+    if use_dist:                                            # leave together: a rank that went on alone would wait at the next barrier for ever
+        fl = torch.tensor([1 if short else 0], dtype=torch.int64, device=rdev or dev)
+        dist.all_reduce(fl, op=dist.ReduceOp.MAX)
+        if int(fl.item()) and not short:
+            sys.stderr.write("bench.py: rank %d: another rank does not have the device memory it needs; leaving with it\n" % rank)
+            dist.destroy_process_group()
+            sys.exit(2)
+    if short:
         sys.stderr.write("bench.py: rank %d: %d rank(s) on device %d need about %.0f GB of device memory (a %.1f-Gbase resident window + %d workspaces + "
                          "tables each), but the device has %.0f GB free of %.0f GB: lower --window-gbases (now %.0f), or give every rank its own GPU\n"
                          % (rank, sharers, local, need / 1e9, win_max / 1e9, nst, free_b / 1e9, total_b / 1e9, a.window_gbases))
