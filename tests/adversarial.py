@@ -11,6 +11,7 @@ def adversarial_reads(seed, n=250, K=40):
     seqs, profs = [], []
     for _ in range(n):
         L = int(rng.choice([60, 90, 300, 1500, 4000, 9000]) + rng.integers(0, 40))
+        L = max(L, K + 1)                                               # (K > 59: at least two k-mers)
         s = rng.integers(0, 4, L)
         for _r in range(int(rng.integers(0, 6))):                       # low-complexity runs
             unit = rng.integers(0, 4, int(rng.integers(1, 4)))

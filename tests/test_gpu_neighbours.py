@@ -176,3 +176,33 @@ def test_batch_limit_is_refused(torch_dev):
     from oracle.oracle import Oracle
     assert clf.classify(b).tobytes() == _oracle_labels(Oracle(K, 20000, 20, 40), seqs, profs)     # and the workspace is fine
     clf.close()
+
+
+@pytest.mark.parametrize("Kx", [21, 25, 63])
+def test_other_k(torch_dev, Kx):
+    """The whole path at k-mer lengths other than 40: labels, interval ends, reliable flags and corrected counts equal the
+    oracle's on generated, adversarial and tail-run reads made for that K -- alone in poisoned buffers and all in one batch."""
+    from classpro_amd import synth
+    from classpro_amd.api import Classifier
+    from oracle.oracle import Oracle
+    from adversarial import tail_run_reads, adversarial_reads
+    ds = synth.make_dataset(genome_len=80000, cov=30, read_len=6000, K=Kx, seed=70 + Kx)
+    a_s, a_p = adversarial_reads(80 + Kx, n=120, K=Kx)
+    t_s, t_p = tail_run_reads(90 + Kx, n=60, K=Kx)
+    O = Oracle(Kx, 20000, 15, 30)
+    S, P, want = [], [], []
+    for s_, p_ in zip(list(ds["seqs"]) + a_s + t_s, list(ds["profiles"]) + a_p + t_p):
+        try:
+            lab, iv, M = O.classify_read(s_, p_, want_intvl=True)
+        except OverflowError:
+            continue
+        rel = iv[iv["is_rel"] != 0]
+        S.append(s_); P.append(p_); want.append((lab, pick(iv, IV_F), pick(rel, RV_F)))
+    assert len(S) > 200
+    clf = Classifier(K=Kx, read_len=20000, hcov=15, dcov=30)
+    got = records(clf, poisoned_batch(torch_dev, S, P, front=16))
+    for i in range(len(S)):
+        assert got[i] == want[i], "K = %d, read %d of the batch" % (Kx, i)
+    for r in range(0, len(S), 7):
+        assert records(clf, poisoned_batch(torch_dev, [S[r]], [P[r]]))[0] == want[r], "K = %d, read %d alone" % (Kx, r)
+    clf.close()

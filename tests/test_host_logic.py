@@ -336,3 +336,28 @@ def test_expand_label_runs_host(built):
     for ends, rlen in (([7, 6, 12], 12), ([7, 13], 12), ([7, 9], 12)):
         with pytest.raises(ClassProError):
             expand_label_runs(ends, np.frombuffer(b"DEH", np.uint8)[:len(ends)], rlen, K)
+
+
+@pytest.mark.parametrize("Kx", [21, 25, 63])
+def test_device_functions_other_k(harness, Kx):
+    """The path at k-mer lengths other than 40 (FASTK's -k; K = 25 / 63 are the ends of the reference's seed tables): the
+    product's scalar code against the oracle on generated, adversarial and tail-run reads made for that K."""
+    from adversarial import adversarial_reads, tail_run_reads
+    ds = synth.make_dataset(genome_len=60000, cov=30, read_len=5000, K=Kx, seed=40 + Kx)
+    a_s, a_p = adversarial_reads(50 + Kx, n=60, K=Kx)
+    t_s, t_p = tail_run_reads(60 + Kx, n=40, K=Kx)
+    O = Oracle(Kx, 20000, 15, 30)
+    P = harness.hh_params_new(Kx, 20000, 15, 30)
+    n = 0
+    for s, p in zip(list(ds["seqs"]) + a_s + t_s, list(ds["profiles"]) + a_p + t_p):
+        if len(p) != len(s) - Kx + 1:
+            continue
+        try:
+            want = O.classify_read(s, p)
+        except OverflowError:
+            continue
+        N, lab, *_ = run_harness_read(harness, P, s, p)
+        assert lab == want
+        n += 1
+    assert n > 100
+    harness.hh_params_free(C.c_void_p(P))
