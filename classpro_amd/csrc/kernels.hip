@@ -1710,8 +1710,8 @@ k_classify_unrel(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__re
 //  recurrence.  Interval fields (16-bit), DP cells, back-pointers and both assignments live in LDS;
 //  HBM is touched for pe (once per step) and for the results.
 // ---------------------------------------------------------------------------------------------
-// LDS record of a wave (G reads).  Sized for waves: with MAXM = 128, G = 4 it is 11 KB (14 waves per CU), so the
-// kernel's 168 VGPRs (3 waves per SIMD), not its LDS, set the occupancy:
+// LDS record of a wave (G reads).  Sized for waves: with MAXM = 112, G = 4 and the compact cells it is 9.2 KB, and four
+// four-wave blocks (with their 4 KB of libm tables each) fit a CU:
 //   * `eff` (index of the interval whose data stands in for path index k) and the "absolutely repeat" flag rpos share
 //     one element: the index in the low bits, the flag in the top bit (one byte while MAXM <= 128);
 //   * the traceback overwrites a back-pointer byte with the assignment of the same interval once it has read it, so
@@ -1729,7 +1729,25 @@ struct rel_grp_lds
     // that the groups' copies of one field fall on different banks -- unpadded, the 64-byte cells of the 16 (group,
     // state) pairs of a half shared 2-4 banks and 58 % of the kernel's LDS cycles were conflict cycles
     // (profiles/r03_sq_counters.txt: SQ_LDS_BANK_CONFLICT 3.3e8 of SQ_LDS_IDX_ACTIVE 5.7e8 per sub-batch).
-    struct cell_t : cp_cell { int pad_[REL_CELL_PAD]; };                          // 72-byte stride
+    // a DP cell as the wave keeps it: the E entries of pos / cnt are never read, counts are 16 bits, the four anchor
+    // indices are interval numbers (< MAXM): 40 bytes instead of cp_cell's 64 -- with the size class at 96 intervals the
+    // wave's record is 8.9 KB and four four-wave blocks (with their libm tables) fit a CU: 4 waves per SIMD
+    typedef typename std::conditional<(MAXM <= 128),int8_t,int16_t>::type idx_t;
+    struct alignas(8) cell_t
+      { double dp, dhr; int32_t pos_[3]; uint16_t cnt_[3]; idx_t last_[4];
+        __device__ __forceinline__ operator cp_cell() const
+        { cp_cell c; c.dp = dp; c.dhr = dhr;
+          c.pos[0] = 0; c.cnt[0] = 0;
+          for (int k = 0; k < 3; k++) { c.pos[k+1] = pos_[k]; c.cnt[k+1] = cnt_[k]; }
+          c.lastH = last_[0]; c.lastD = last_[1]; c.lastHbD = last_[2]; c.lastDbH = last_[3];
+          return c;
+        }
+        __device__ __forceinline__ void set(const cp_cell &c)
+        { dp = c.dp; dhr = c.dhr;
+          for (int k = 0; k < 3; k++) { pos_[k] = c.pos[k+1]; cnt_[k] = (uint16_t)c.cnt[k+1]; }
+          last_[0] = (idx_t)c.lastH; last_[1] = (idx_t)c.lastD; last_[2] = (idx_t)c.lastHbD; last_[3] = (idx_t)c.lastDbH;
+        }
+      };
     uint16_t b[G][MAXM+REL_ROW_PAD], e[G][MAXM+REL_ROW_PAD], ccb[G][MAXM+REL_ROW_PAD], cce[G][MAXM+REL_ROW_PAD];
     uint8_t  parent[G][2][MAXM];         // back-pointers of the 4 cells of an interval, 2 bits each; then the assignment
     eff_t    eff[G][2][MAXM];            // eff | RPOS flag
@@ -1800,7 +1818,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
       I.pe = rintvl[i].pe;
       cp_cell c;
       cp_rel_init_cell(P,ld,I,i,plen,F,COV,&c);
-      static_cast<cp_cell &>(S.cell[g][d][0][ld]) = c;
+      S.cell[g][d][0][ld].set(c);
       S.tr[g][d][ld] = cp_exp_t(c.dp,xt);
       if (ld == 0)
         { S.parent[g][d][i] = 0xe4;                        // each state its own parent: 3,2,1,0
@@ -1839,7 +1857,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
         { I = rv(i);
           if (t_tab == CP_ERROR && k+1 < M)
             pe_next = rintvl[F ? k+1 : M-2-k].pe;
-          const cp_cell &pr = S.cell[g][d][cur][s];
+          const auto &pr = S.cell[g][d][cur][s];
           live = pr.dp != -INFINITY;
           if (live)
             { if (t_tab == CP_ERROR)                       // logp_e, class_rel.c:158-170
@@ -1847,7 +1865,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
                   f0 = cp_check_cnt(I.ccb); f1 = cp_check_cnt(I.cce); li = COV[CP_ERROR];
                 }
               else if (t_tab == CP_REPEAT)                 // logp_r, class_rel.c:172-211
-                { const int beg_cnt = cp_beg_cnt(I,F), prc = pr.cnt[CP_REPEAT];
+                { const int beg_cnt = cp_beg_cnt(I,F), prc = pr.cnt_[CP_REPEAT-1];
                   if (beg_cnt < prc)
                     { r_tab = true;
                       rk = cp_check_cnt(beg_cnt); rn = cp_check_cnt(prc);
@@ -1858,11 +1876,11 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
                 { is_sk = true;                            // logp_h / logp_d, class_rel.c:213-270
                   const int beg_pos = cp_beg_pos(I,F), beg_cnt = cp_beg_cnt(I,F);
                   if (t_sk == CP_HAPLO && pr.dhr == -INFINITY)
-                    { tb = cp_pred(pr.pos[CP_HAPLO],F); te = beg_pos; tcb = pr.cnt[CP_HAPLO]; tce = beg_cnt; tcov = pr.cnt[CP_HAPLO]; }
+                    { tb = cp_pred(pr.pos_[CP_HAPLO-1],F); te = beg_pos; tcb = pr.cnt_[CP_HAPLO-1]; tce = beg_cnt; tcov = pr.cnt_[CP_HAPLO-1]; }
                   else
-                    { tb = cp_pred(pr.pos[CP_DIPLO],F); te = beg_pos; tcb = pr.cnt[CP_DIPLO];
+                    { tb = cp_pred(pr.pos_[CP_DIPLO-1],F); te = beg_pos; tcb = pr.cnt_[CP_DIPLO-1];
                       tce = (t_sk == CP_HAPLO) ? (int)(pr.dhr*beg_cnt) : beg_cnt;
-                      tcov = pr.cnt[CP_DIPLO];
+                      tcov = pr.cnt_[CP_DIPLO-1];
                     }
                 }
             }
@@ -1875,11 +1893,11 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
                 lp_tab = (po > I.pe) ? po : I.pe;
               }
             else if (t_tab == CP_REPEAT)
-              { const cp_cell &pr = S.cell[g][d][cur][s];
+              { const auto &pr = S.cell[g][d][cur][s];
                 double l = r_tab ? (A - B - C + rk * P->r_lp + (rn-rk) * P->r_l1mp) : -INFINITY;   // prob.c:67-73
                 if (!(l > CP_R_LOGP))
                   { int max_cc = I.ccb > I.cce ? I.ccb : I.cce;
-                    if (max_cc >= COV[CP_REPEAT] || max_cc >= pr.cnt[CP_REPEAT]) l = CP_R_LOGP;
+                    if (max_cc >= COV[CP_REPEAT] || max_cc >= pr.cnt_[CP_REPEAT-1]) l = CP_R_LOGP;
                   }
                 lp_tab = l;
               }
@@ -1945,7 +1963,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
         { cp_cell c;
           int pv = l16;
           if (only_r)
-            { c = S.cell[g][d][cur][l16];
+            { c = (cp_cell)S.cell[g][d][cur][l16];
               cp_rel_only_r_cell(l16,i,&c);
               if (l16 == 0)
                 S.eff[g][d][i] = (typename rel_grp_lds<MAXM,G>::eff_t)(S.eff[g][d][i_pred] | rel_grp_lds<MAXM,G>::RPOS);
@@ -1968,7 +1986,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
                 S.eff[g][d][i] = (typename rel_grp_lds<MAXM,G>::eff_t)i;
               cp_rel_target_cell(P,l16,i,I,F,COV,max_s,max_logp,&S.cell[g][d][cur][0],view,&c);
             }
-          static_cast<cp_cell &>(S.cell[g][d][cur^1][l16]) = c;
+          S.cell[g][d][cur^1][l16].set(c);
           const int l0 = lane-l16;                         // pack the four back-pointers into one byte
           const int pk = pv | (__shfl(pv,l0+1) << 2) | (__shfl(pv,l0+2) << 4) | (__shfl(pv,l0+3) << 6);
           if (l16 == 0)
@@ -2017,7 +2035,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
 #define REL_SMALL_G 4
 #endif
 #ifndef REL_SMALL_MAXM
-#define REL_SMALL_MAXM 128
+#define REL_SMALL_MAXM 112
 #endif
 // (unrel, later, with K = 64/G/8 speculative update slots per read: G = 4 4.28 ms per step, G = 2 4.07, G = 1 4.04)
 #ifndef UNREL_SMALL_G
@@ -2039,10 +2057,11 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
 #define REL_SMALL_WPB 4
 #endif
 // (round 3: 4 waves per SIMD = 128 VGPRs with 32 of them spilled to scratch, against 167 and none at 3: 192 against 186
-//  Gbases/s.  Round 4: the four-wave blocks with the libm tables in LDS, 52 KB, fit three to a CU = 3 waves per SIMD, so
-//  the register target is 3 as well: 159 VGPRs, nothing spilled)
+//  Gbases/s.  Round 4: four-wave blocks with the libm tables in LDS; with 64-byte cells and a size class of 128 a block was
+//  52 KB, three to a CU = 3 waves per SIMD (149 VGPRs, nothing spilled): 194.4 Gbases/s; with the 40-byte cell_t and a
+//  size class of 112 a block is 40.7 KB, four to a CU = 4 waves per SIMD at 128 VGPRs, 14 spilled: 198.6-199.7)
 #ifndef REL_WAVES_PER_EU
-#define REL_WAVES_PER_EU 3
+#define REL_WAVES_PER_EU 4
 #endif
 
 template <int MINM, int MAXM, int G, int WPB>
