@@ -32,6 +32,7 @@ struct cp_params
     cp_dev_params *dev;
     int            device;                 // HIP device the tables live on
     double        *skel;                   // device table of logp_trans values (cp_types.h), or NULL
+    double        *eskel;                  // exp() of them, or NULL
     double        *uerr;                   // device table of classify_unrel's binomial-test logs, or NULL
     double        *petab;                  // device table of the walk's P(error in) values, or NULL
     size_t         skel_bytes, uerr_bytes, petab_bytes;
@@ -128,7 +129,7 @@ extern "C" int cp_params_create_model(int K, int read_len, int hcov, int dcov, c
       free(p);
       return set_err(rc,buf);
     }
-  p->dev = NULL; p->skel = p->uerr = p->petab = NULL; p->skel_bytes = p->uerr_bytes = p->petab_bytes = 0;
+  p->dev = NULL; p->skel = p->eskel = p->uerr = p->petab = NULL; p->skel_bytes = p->uerr_bytes = p->petab_bytes = 0;
   p->device = 0;
   hipStream_t st = NULL;
   hipError_t e = hipGetDevice(&p->device);
@@ -159,6 +160,15 @@ extern "C" int cp_params_create_model(int K, int read_len, int hcov, int dcov, c
           p->skel = tab_acquire(p->device,"skel r"+std::to_string(read_len),bytes,[&](double *t, hipStream_t s)
             { hipLaunchKernelGGL(k_skellam_table,dim3(4096),dim3(256),0,s,dP,t,kmax,cdmax); });
           if (p->skel) { p->host.skel = p->skel; p->host.skel_kmax = kmax; p->host.skel_cdmax = cdmax; p->skel_bytes = bytes; }
+          // exp() of the same entries for the DP step of classify_rel (CLASSPRO_EXP_TABLE=0: none; cp_exp_logp_trans, cp_math.h)
+          const char *xe = getenv("CLASSPRO_EXP_TABLE");
+          if (p->skel && (!xe || atol(xe) != 0))
+            { const double *src = p->skel;
+              const long long n = (cdmax+1)*(long long)(kmax+1);
+              p->eskel = tab_acquire(p->device,"eskel r"+std::to_string(read_len)+" "+std::to_string(bytes),bytes,[&](double *t, hipStream_t s)
+                { hipLaunchKernelGGL(k_eskel_table,dim3(4096),dim3(256),0,s,src,t,n); });
+              if (p->eskel) p->host.eskel = p->eskel;
+            }
         }
       const int emax = 1023;                                   // 1024 x 1024 doubles
       { const size_t bytes = (size_t)(emax+1)*(emax+1)*8;
@@ -177,7 +187,7 @@ extern "C" int cp_params_create_model(int K, int read_len, int hcov, int dcov, c
       e = hipMemcpyAsync(p->dev,&p->host,sizeof(cp_dev_params),hipMemcpyHostToDevice,st);
       if (e == hipSuccess) e = hipStreamSynchronize(st);
       if (e != hipSuccess)
-        { tab_release(p->skel); tab_release(p->uerr); tab_release(p->petab);
+        { tab_release(p->skel); tab_release(p->eskel); tab_release(p->uerr); tab_release(p->petab);
           (void)hipFree(p->dev); (void)hipStreamDestroy(st); free(p);
           return set_err(CP_EHIP,std::string("cp_params_create: ")+hipGetErrorString(e));
         }
@@ -189,7 +199,7 @@ extern "C" int cp_params_create_model(int K, int read_len, int hcov, int dcov, c
 
 extern "C" void cp_params_destroy(cp_params *p)
 { if (!p) return;
-  tab_release(p->skel); tab_release(p->uerr); tab_release(p->petab);
+  tab_release(p->skel); tab_release(p->eskel); tab_release(p->uerr); tab_release(p->petab);
   if (p->dev) (void)hipFree(p->dev);
   free(p);
 }

@@ -211,6 +211,25 @@ CP_HD double cp_logp_trans(const cp_dev_params *P, int b, int e, int cb, int ce,
   return cp_logp_trans_calc(P,ce-cb,(double)cov*d);
 }
 
+// exp(logp_trans(...)): what the DP step of classify_rel needs of a transition (class_rel.c:300-319 exponentiates every
+// one of them).  Inside the table the value was computed by cp_exp_t(cp_logp_trans_calc(...)) -- this very expression;
+// outside it runs here.  `xt`: the caller's exp table (cp_libm.h).
+template <class TAB>
+CP_HD double cp_exp_logp_trans(const cp_dev_params *P, int b, int e, int cb, int ce, int cov, TAB xt)
+{ cov &= 0xffff;
+  int d = e-b;
+  if (d < 0) d = -d;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int k = ce-cb < 0 ? cb-ce : ce-cb;
+  const long long cd = (long long)cov*d;
+  if (k <= P->skel_kmax && cd <= P->skel_cdmax)
+    { if (P->eskel) return P->eskel[cd*(P->skel_kmax+1)+k];
+      if (P->skel)  return cp_exp_t(P->skel[cd*(P->skel_kmax+1)+k],xt);
+    }
+#endif
+  return cp_exp_t(cp_logp_trans_calc(P,ce-cb,(double)cov*d),xt);
+}
+
 // ---- p_errorin with one of the model's own error rates pe[t][l] (every call of the candidate walk) ----
 #if defined(__HIPCC__)
 __host__ __device__ __attribute__((noinline))

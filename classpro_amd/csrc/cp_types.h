@@ -62,6 +62,7 @@ struct cp_dev_params
     // |ce-cb| <= skel_kmax and cov*|e-b| <= skel_cdmax, computed once on the device by the same code
     // (skel[cd*(skel_kmax+1)+k]); NULL = always computed on the spot
     const double *skel;
+    const double *eskel;                   // exp() of the same entries (same sizes), for the DP step of k_classify_rel_grp; NULL = none
     int     skel_kmax;
     long long skel_cdmax;
     // classify_unrel's log(binom_test(count | estimated count, 0.1)) (class_unrel.c:137-147) is a function of two

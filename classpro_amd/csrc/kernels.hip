@@ -1851,7 +1851,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
       bool live = false, is_sk = false, r_tab = false;
       int tb = 0, te = 0, tcb = 0, tce = 0, tcov = 0;
       int f0 = 0, f1 = 0, f2 = 0, li = 1, rk = 0, rn = 0;
-      double lp_sk = -INFINITY, lp_tab = -INFINITY;
+      double lp_tab = -INFINITY;
       const double pe_now = pe_next;                       // fetched one step ahead
       if (on)
         { I = rv(i);
@@ -1903,10 +1903,10 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
               }
           }
       }
-      if (is_sk)
-        lp_sk = cp_logp_trans(P,tb,te,tcb,tce,tcov);
+      if (is_sk)                                           // exp(logp_trans) straight from its table (cp_math.h): one exp per lane and step less
+        v_sk = cp_exp_logp_trans(P,tb,te,tcb,tce,tcov,xt);
       if (on)
-        { if (live) { v_sk = cp_exp_t(lp_sk,xt); v_tab = cp_exp_t(lp_tab,xt); }
+        { if (live) v_tab = cp_exp_t(lp_tab,xt);           // (is_sk implies live; a lane without a Skellam term keeps v_sk = 0 = exp(-inf))
           if (t_sk >= 0)  S.tr[g][d][s*4+t_sk]  = v_sk;
           if (t_tab >= 0) S.tr[g][d][s*4+t_tab] = v_tab;
         }
@@ -2800,6 +2800,12 @@ k_skellam_table(const cp_dev_params *__restrict__ P, double *__restrict__ tab, i
 }
 
 // the table of the walk's P(error in) values (cp_types.h), by the function the kernels would otherwise run
+__global__ void __launch_bounds__(256)
+k_eskel_table(const double *__restrict__ skel, double *__restrict__ tab, long long n)      // exp of the logp_trans table, by the kernels' own exp
+{ for (long long i = (long long)blockIdx.x*blockDim.x+threadIdx.x; i < n; i += (long long)gridDim.x*blockDim.x)
+    tab[i] = cp_exp(skel[i]);
+}
+
 __global__ void __launch_bounds__(256)
 k_pe_table(const cp_dev_params *__restrict__ P, double *__restrict__ tab, int cmax)
 { const long long per = (long long)(cmax+1)*(cmax+1), n = 2*63*per;

@@ -72,7 +72,8 @@ int cp_hist_covs(const int64_t *hist, int low, int high, int64_t ilowcnt, int64_
  * (src/ClassPro.c:544-548) and calc_init_thres(NULL) (src/wall.c:167-244): builds the read-only
  * tables on the host and uploads them to the current HIP device.  It also has the device fill a table of
  * logp_trans values (util.c:35-44: a function of |ce-cb| and the integer cov*|e-b| alone; 1 GB of device memory by
- * default, environment CLASSPRO_SKELLAM_TABLE_MB, 0 = no such table) and two small ones (classify_unrel's
+ * default, environment CLASSPRO_SKELLAM_TABLE_MB, 0 = no such table; and a second table of the same size with their
+ * exponentials, which is what classify_rel's DP step uses of a transition -- CLASSPRO_EXP_TABLE=0: without it) and two small ones (classify_unrel's
  * binomial-test logs, the walk's P(error in): 74 MB) with the code the kernels otherwise run on the spot, so results
  * are the same bits with or without them (CLASSPRO_TABLES=0: none of the three).  The tables depend on READ_LEN / the
  * error model only, so all cp_params of a process that agree on those share one reference-counted copy per device.
