@@ -180,7 +180,7 @@ def main():
     # two ranks sharing one GPU, or a window sized for another card, end here with a message instead of a raw hipMalloc
     # failure in the middle of the run
     win_max = max((int(ds.seq_off_all[f + c] - ds.seq_off_all[f]) for f, c in windows if c), default=0)
-    need = 4.05 * win_max + nst * 11.5 * min(win_max, a.batch_mbases * 1e6) + 1.3e9
+    need = 4.05 * win_max + nst * 11.5 * min(win_max, a.batch_mbases * 1e6) + 2.4e9
     torch.cuda.empty_cache()
     free_b, total_b = torch.cuda.mem_get_info(dev)
     sharers = 1
