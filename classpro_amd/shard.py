@@ -8,15 +8,28 @@ per-thread temp files (io.c:70-112).
 import numpy as np
 
 
-def plan_shards(seq_off, world):
-    """Boundaries b[0..world] (read indices): shard r = reads [b[r], b[r+1]), about equal in bases."""
+def plan_shards(seq_off, world, part_first=None, slack=0.05):
+    """Boundaries b[0..world] (read indices): shard r = reads [b[r], b[r+1]), about equal in bases.
+    `part_first`: first read of every FASTK profile part (`.pidx.N` headers, libfastk.c:1305-1308, 1330-1335); a shard
+    boundary then moves to the nearest part boundary when that costs at most `slack` of a shard's bases, so that a
+    shard streams whole `.prof.N` files where the parts allow it ("ideally aligned to FASTK's own
+    part boundaries")."""
     seq_off = np.asarray(seq_off, dtype=np.int64)
     n = len(seq_off) - 1
     total = int(seq_off[-1]) if n > 0 else 0
+    parts = np.unique(np.asarray(part_first, dtype=np.int64)) if part_first is not None and len(part_first) else None
     b = [0]
     for r in range(1, world):
         target = total * r // world
-        b.append(int(np.searchsorted(seq_off, target, side="left")) if n else 0)
+        k = int(np.searchsorted(seq_off, target, side="left")) if n else 0
+        if parts is not None and n:
+            j = int(np.searchsorted(parts, k))
+            cand = [int(parts[x]) for x in (j - 1, j) if 0 <= x < len(parts) and 0 <= parts[x] <= n]
+            if cand:
+                best = min(cand, key=lambda q: abs(int(seq_off[q]) - target))
+                if abs(int(seq_off[best]) - target) * world <= slack * total:
+                    k = best
+        b.append(k)
     b.append(n)
     for i in range(1, len(b)):
         b[i] = min(max(b[i], b[i - 1]), n)

@@ -67,3 +67,21 @@ def test_plan_shards_balances_bases():
         per = [so[b[i + 1]] - so[b[i]] for i in range(w)]
         assert max(per) - min(per) <= 2 * 60000
     assert plan_shards(np.array([0]), 4) == [0, 0, 0, 0, 0]
+
+
+def test_plan_shards_snaps_to_fastk_parts():
+    """With the first reads of the FASTK profile parts given, a boundary moves to a part boundary when that costs at most
+    5 % of a shard's bases -- and stays where the bases put it when no part boundary is near."""
+    from classpro_amd.shard import plan_shards
+    rng = np.random.default_rng(3)
+    lens = rng.integers(3000, 30000, 4000)
+    so = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    plain = plan_shards(so, 4)
+    near = [0, plain[1] + 7, plain[2] - 11, 3000]             # parts that begin a few reads away from boundaries 1 and 2
+    b = plan_shards(so, 4, part_first=near)
+    assert b[1] == plain[1] + 7 and b[2] == plain[2] - 11 and b[3] == plain[3] and b[0] == 0 and b[4] == 4000
+    share = np.diff(so[b])
+    assert share.max() - share.min() < 0.1 * so[-1] / 4
+    far = [0, 100, 3900]
+    assert plan_shards(so, 4, part_first=far) == plain
+    assert plan_shards(so, 4, part_first=[]) == plain
