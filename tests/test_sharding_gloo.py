@@ -77,7 +77,7 @@ def test_plan_shards_snaps_to_fastk_parts():
     lens = rng.integers(3000, 30000, 4000)
     so = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     plain = plan_shards(so, 4)
-    near = [0, plain[1] + 7, plain[2] - 11, 3000]             # parts that begin a few reads away from boundaries 1 and 2
+    near = [0, plain[1] + 7, plain[2] - 11, 3500]             # parts that begin a few reads away from boundaries 1 and 2 (and one far from 3)
     b = plan_shards(so, 4, part_first=near)
     assert b[1] == plain[1] + 7 and b[2] == plain[2] - 11 and b[3] == plain[3] and b[0] == 0 and b[4] == 4000
     share = np.diff(so[b])
