@@ -725,9 +725,11 @@ CP_HD void cp_make_interval(const RD *R, int NS, int b, int e, cp_intvl *out)
 // Sum over i in [lo,hi) of the upward (sgn = +1) or downward (sgn = -1) steps prof[i+1]-prof[i] of a count
 // profile, eight counts per load where that stays inside the read's plen counts (the addresses are only
 // 2-byte aligned; gfx9 global loads take unaligned addresses).  Same terms as the loops of wall.c:972-1001.
-// hi may equal plen (wall.c:976-978, `last = I.b+lmax` with a low-complexity run that reaches the end of the read):
-// the reference then reads profile[plen], a cell no read owns -- fresh heap for the first read of a thread.  Here
-// that cell reads 0 whatever follows the read in memory, so a read's result is a function of the read alone.
+// hi may equal plen (wall.c:976-978, `last = I.b+lmax` with a low-complexity run that reaches the end of the read) and
+// even exceed it by up to 126 (a homopolymer of more than 127 bases: rctx holds a reversed copy of capped values there,
+// context.c:24-25, so lmax can be 127 with fewer bases left): the reference then reads profile[plen ..], cells no read
+// owns -- fresh heap for the first read of a thread.  Here every count at or beyond plen reads 0 whatever follows the
+// read in memory (the tail loop below never dereferences them), so a read's result is a function of the read alone.
 template <class PROF>
 CP_HD int cp_sum_steps(const PROF &prof, int lo, int hi, int plen, int sgn)
 { int acc = 0, i = lo;

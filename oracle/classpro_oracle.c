@@ -1104,11 +1104,13 @@ int cpo_find_rel_intvl(const cpo_params *p, cpo_intvl *intvl, int N, cpo_intvl *
               }
             last = I.b+lmax;
             /* wall.c:976-978 reads profile[plen] when the low-complexity run that starts at read base b+K-1
-               reaches the end of the read (last == plen).  In the reference that cell is whatever the thread's
-               profile buffer holds there: 0 on fresh heap (the first read of a thread), else a longer earlier
-               read's count.  DEFINED here (hazard 8): profile[plen] == 0. */
+               reaches the end of the read (last == plen) -- and cells beyond it when that run is a homopolymer of
+               more than 127 bases: context.c:24-25 fills rctx with a reversed copy of CAPPED values there, so lmax can
+               be 127 with fewer than 127 bases left (last > plen, by up to 126).  In the reference those cells are
+               whatever the thread's profile buffer holds: 0 on fresh heap (the first read of a thread), else a
+               longer earlier read's counts.  DEFINED here (hazard 8): profile[x] == 0 for x >= plen. */
             for (int i = I.b; i < last; i++)
-              n_gain -= MAXI((int)profile[i]-(i+1 < plen ? (int)profile[i+1] : 0),0);
+              n_gain -= MAXI((i < plen ? (int)profile[i] : 0)-(i+1 < plen ? (int)profile[i+1] : 0),0);
           }
         first = MAXI(I.e-K+1,I.b);
         for (int i = first; i < I.e-1; i++)

@@ -41,7 +41,9 @@ def tail_run_reads(seed, n=200, K=40):
     for k in range(n):
         body = int(rng.integers(200, 1500))
         ulen = 1 + k % 3
-        run = int(rng.integers(K + 2, 121))                    # <= 127: the context values are capped there
+        run = int(rng.integers(K + 2, 121))                    # <= 127: the context values are capped there ...
+        if k % 8 == 7:                                         # ... except here: a homopolymer of 130-320 bases, where rctx holds the
+            ulen, run = 1, int(rng.integers(130, 321))         # reversed copy of CAPPED values (context.c:24-25): lmax > bases left
         s = rng.integers(0, 4, body)
         unit = rng.permutation(4)[:ulen]                       # distinct bases: a true period-`ulen` unit
         s[-1] = (unit[-1] + 1 + int(rng.integers(0, 3))) % 4   # the base before the run breaks its period
