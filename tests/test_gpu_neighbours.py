@@ -206,3 +206,47 @@ def test_other_k(torch_dev, Kx):
     for r in range(0, len(S), 7):
         assert records(clf, poisoned_batch(torch_dev, [S[r]], [P[r]]))[0] == want[r], "K = %d, read %d alone" % (Kx, r)
     clf.close()
+
+
+def _many_intervals(rng, nint, seglen, noisy):
+    """A read of `nint` stretches alternating between the diploid and the haploid level (each a reliable interval when it
+    is K or longer); `noisy`: a third of the stretches shorter than K, some at error / repeat levels."""
+    lens = np.full(nint, seglen)
+    lv = np.where(np.arange(nint) % 2 == 0, 40, 20) + rng.integers(-2, 3, nint)
+    if noisy:
+        short = rng.random(nint) < 0.33
+        lens = np.where(short, rng.integers(5, K - 2, nint), lens)
+        lv = np.where(rng.random(nint) < 0.1, rng.choice([1, 2, 90, 300], nint), lv)
+    c = np.repeat(lv, lens)
+    s = bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, len(c) + K - 1)])
+    return s, c.astype(np.uint16)
+
+
+def test_large_interval_counts(torch_dev):
+    """Every size class of the classify kernels against the oracle: M (reliable intervals) of 150 and 600 (the one-read-per-wave
+    class above 112), 1100 and 1400 (beyond 1024: the sequential kernel), N (all intervals) up to ~2000 with short and
+    odd-level stretches in between, and a read beyond 65535 k-mers -- alone and together in one batch."""
+    from classpro_amd.api import Classifier
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(77)
+    O = Oracle(K, 20000, 20, 40)
+    S, P, want, sizes = [], [], [], []
+    for nint, seglen, noisy in ((150, 60, False), (600, 60, False), (1100, 45, False), (1400, 45, False), (1500, 60, False),
+                                (300, 60, True), (900, 50, True), (2000, 44, True), (120, 60, True), (40, 70, False)):
+        s_, p_ = _many_intervals(rng, nint, seglen, noisy)
+        try:
+            lab, iv, M = O.classify_read(s_, p_, want_intvl=True)
+        except OverflowError:
+            continue
+        rel = iv[iv["is_rel"] != 0]
+        S.append(s_); P.append(p_); want.append((lab, pick(iv, IV_F), pick(rel, RV_F))); sizes.append((len(iv), M, len(p_)))
+    Ms, Ns = [m for _, m, _ in sizes], [n for n, _, _ in sizes]
+    assert max(Ms) > 1024 and any(112 < m <= 1024 for m in Ms) and max(Ns) > 1024 and any(256 < n <= 1024 for n in Ns)
+    assert any(pl > 65535 for _, _, pl in sizes)
+    clf = Classifier(K=K, read_len=20000, hcov=20, dcov=40)
+    got = records(clf, poisoned_batch(torch_dev, S, P, front=16))
+    for i in range(len(S)):
+        assert got[i] == want[i], "read %d of the batch (N, M, plen = %s)" % (i, sizes[i])
+    for i in range(len(S)):
+        assert records(clf, poisoned_batch(torch_dev, [S[i]], [P[i]]))[0] == want[i], "read %d alone (N, M, plen = %s)" % (i, sizes[i])
+    clf.close()
