@@ -16,6 +16,11 @@ rm -f tests/_*.srchash classpro_amd/.tools.srchash          # helpers are rebuil
 set +e
 LD_PRELOAD="$ASAN:$UBSAN" python -m pytest tests -x -q -m "not gpu" -p no:cacheprovider "$@"
 rc=$?
+# ... and the parameter-space soak of the same two implementations (K 15-63, -r 1000-60000, coverages (5,10)-(50,100))
+if [ $rc -eq 0 ] && [ $# -eq 0 ]; then
+  LD_PRELOAD="$ASAN:$UBSAN" python scripts/fuzz_host.py 2 | tail -1
+  rc=${PIPESTATUS[0]}
+fi
 for f in "$REP"/*; do [ -f "$f" ] && { echo "== sanitizer report $f"; head -40 "$f"; rc=1; }; done
 rm -rf "$REP"
 rm -f tests/_*.srchash classpro_amd/.tools.srchash          # ... and without them by the next ordinary run
