@@ -11,15 +11,18 @@ from oracle.oracle import Oracle
 from adversarial import adversarial_reads, tail_run_reads
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+vary = len(sys.argv) > 3 and sys.argv[3] == "params"        # K and -r change with the seed too (K 21-63, -r 1000-60000)
 covs = [(20, 40), (19, 38), (30, 60), (45, 90), (12, 25), (60, 120)]
 nreads = nbad = nrej = 0
 for seed in range(first, first + count):
-    seqs, profs = adversarial_reads(seed)
-    ts, tp = tail_run_reads(seed, n=60)                     # reads that end in a low-complexity run (hazard 8)
+    Kx = (21, 32, 40, 50, 63)[seed % 5] if vary else 40
+    rl = (1000, 20000, 60000)[(seed // 5) % 3] if vary else 20000
+    seqs, profs = adversarial_reads(seed, K=Kx)
+    ts, tp = tail_run_reads(seed, n=60, K=Kx)               # reads that end in a low-complexity run (hazard 8)
     seqs, profs = seqs + ts, profs + tp
     hc, dc = covs[seed % len(covs)]
-    O = Oracle(40, 20000, hc, dc)
-    clf = Classifier(K=40, read_len=20000, hcov=hc, dcov=dc)
+    O = Oracle(Kx, rl, hc, dc)
+    clf = Classifier(K=Kx, read_len=rl, hcov=hc, dcov=dc)
     keep_s, keep_p, want = [], [], []
     for s_, p_ in zip(seqs, profs):
         try:
