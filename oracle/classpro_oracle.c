@@ -346,6 +346,7 @@ void cpo_params_free(cpo_params *p) { free(p); }
 const uint8_t *cpo_params_cthres(const cpo_params *p) { return &p->cthres[0][0][0][0][0]; }
 const double  *cpo_params_logfact(const cpo_params *p) { return p->logfact; }
 const double  *cpo_params_pe(const cpo_params *p) { return &p->pe[0][0]; }
+const int     *cpo_params_lmax(const cpo_params *p) { return &p->lmax[0]; }
 void cpo_params_scalars(const cpo_params *p, int *cov4, double *dr_ratio, int *cmax, double *hc_erate)
 { for (int i = 0; i < 4; i++) cov4[i] = p->cov[i];
   *dr_ratio = p->dr_ratio; *cmax = p->cmax; *hc_erate = p->hc_erate;

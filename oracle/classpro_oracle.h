@@ -11,11 +11,14 @@
  *     FASTK profile decoding are PINNED against the reference's own code compiled from
  *     /root/reference/src (oracle/_ref, built by oracle/Makefile) and the golden vectors
  *     under tests/golden/ generated from that build (oracle/gen_golden.py).
- *   - find_wall / find_rel_intvl / calc_init_thres (reference src/wall.c) are
- *     **parity unpinned**: wall.c includes <gsl/gsl_multifit.h>, GSL is absent from this
- *     image and its tarball is a missing blob, so that file is unbuildable here and no
- *     stand-in header was written.  Those functions are restated line-by-line below with
- *     file:line citations.
+ *   - find_wall / find_rel_intvl (reference src/wall.c:245-1051) are PINNED since round 5 against the reference's
+ *     own text: the GSL-free line ranges of wall.c are compiled into oracle/_ref (oracle/Makefile `ref`,
+ *     oracle/ref_driver.c), golden vectors tests/golden/wall.npz and labels.npz, live legs in
+ *     tests/test_oracle_wall.py.
+ *   - calc_init_thres (wall.c:167-243) and the -M fit (wall.c:11-115) are **parity unpinned**: they reach
+ *     load_himodel -> GSL (wall.c:9-115), GSL is absent from this image and its tarball is a missing blob, and no
+ *     stand-in header was written.  The threshold table is pinned by exact integer arithmetic instead
+ *     (tests/test_first_principles.py).
  */
 #ifndef CLASSPRO_ORACLE_H
 #define CLASSPRO_ORACLE_H
@@ -68,6 +71,7 @@ void        cpo_params_free(cpo_params *p);
 const uint8_t *cpo_params_cthres(const cpo_params *p);     /* flat [3][21][256][2][2] */
 const double  *cpo_params_logfact(const cpo_params *p);
 const double  *cpo_params_pe(const cpo_params *p);         /* flat [3][21] */
+const int     *cpo_params_lmax(const cpo_params *p);       /* [3] */
 void        cpo_params_scalars(const cpo_params *p, int *cov4, double *dr_ratio, int *cmax, double *hc_erate);
 
 /* numeric primitives (prob.c, bessel.c, util.c) */

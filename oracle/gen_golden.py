@@ -12,6 +12,12 @@ Vectors (inputs + the reference's outputs; data only, no reference source):
                 (the interval sets are produced by the oracle's find_wall/find_rel_intvl on seeded synthetic reads)
   fastk.npz     process_global_hist (H,D) and Fetch_Profile output for FASTK files written by classpro_amd.fastk
   seeds.npz     find_seeds (seed.c, the -s path): seed labels, repeat-mask intervals and canonical ntHash values
+  wall.npz      find_wall + find_rel_intvl (wall.c:570-958, 960-1051; the GSL-free part of wall.c compiled as it
+                stands, oracle/Makefile): per read the reference's Intvl[N] and rintvl[M] records, doubles included;
+                reads on which the reference's own exit(1) fires ("# E-intvls >= plen") carry status 1 and no records
+  labels.npz    whole reads through reference text ONLY (context.c -> wall.c slice -> class_rel.c -> class_unrel.c ->
+                paint, ClassPro.c:229-271): label strings and the final interval classes
+Both also hold the threshold tables handed to find_wall (calc_init_thres itself needs GSL: DESIGN 3.2).
 """
 import os
 import sys
@@ -21,7 +27,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:] = [q for q in sys.path if os.path.abspath(q or ".") != os.path.join(ROOT, "oracle")]
 sys.path.insert(0, ROOT)
-from oracle.oracle import Oracle, Ref, INTVL_DTYPE, ref_available  # noqa: E402
+from oracle.oracle import Oracle, Ref, INTVL_DTYPE, ref_available, ref_wall_available  # noqa: E402
 from classpro_amd import synth, fastk  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -229,10 +235,138 @@ def seeds():
     np.savez_compressed(os.path.join(OUT, "seeds.npz"), **out)
 
 
+def _param_sets():
+    """(K, -r, H, D) of the wall / label vectors."""
+    return [(40, 20000, 20, 40), (40, 20000, 30, 60), (40, 2000, 20, 40), (21, 20000, 20, 40), (25, 25000, 30, 60),
+            (63, 20000, 12, 25)]
+
+
+def _edge_cases(K, rng):
+    """tests/test_gpu_parity.py::test_edge_reads' inputs for any K: shortest legal reads, flat / repeat / error / ramp
+    profiles, homopolymer and micro-satellite reads -- several of them end in the reference's exit(1)."""
+    AL = np.frombuffer(b"ACGT", np.uint8)
+    cases = []
+    for plen in (1, 2, 3, K - 1, K, K + 1, 200, 1000):
+        rlen = plen + K - 1
+        seq = bytes(AL[rng.integers(0, 4, rlen)])
+        cases += [(seq, np.full(plen, 40, np.uint16)), (seq, np.full(plen, 500, np.uint16)), (seq, np.full(plen, 1, np.uint16)),
+                  (seq, (1 + np.arange(plen) % 90).astype(np.uint16)),
+                  (b"A" * rlen, rng.integers(1, 80, plen).astype(np.uint16)),
+                  ((b"AC" * rlen)[:rlen], rng.integers(1, 80, plen).astype(np.uint16)),
+                  ((b"ACG" * rlen)[:rlen], rng.integers(1, 300, plen).astype(np.uint16))]
+    p = np.full(3000, 40, np.uint16)
+    p[1000:1000 + K - 1] = 1
+    p[2000:2500] = 20
+    cases.append((bytes(AL[rng.integers(0, 4, 3000 + K - 1)]), p))
+    p = np.full(5000, 32767, np.uint16)
+    p[100:150] = 3
+    cases.append((bytes(AL[rng.integers(0, 4, 5000 + K - 1)]), p))
+    return cases
+
+
+def wall_label_cases(which):
+    """[(set index, seq, profile)] for wall.npz ('wall') / labels.npz ('labels'): disjoint seeds, the same kinds."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from adversarial import adversarial_reads, tail_run_reads
+    w = which == "wall"
+    out = []
+    for si, (K, rl, h, d) in enumerate(_param_sets()):
+        rng = np.random.default_rng(500 + si + (0 if w else 50))
+        ds = synth.make_dataset(genome_len=60000, cov=d, read_len=min(rl, 9000) if w else min(rl, 14000), K=K,
+                                seed=(60 if w else 160) + si, het=0.004 if si % 2 else 0.001, n_repeats=6)
+        n_syn = (10 if w else 16) if si < 2 else (5 if w else 8)
+        out += [(si, s_, p_) for s_, p_ in list(zip(ds["seqs"], ds["profiles"]))[:n_syn]]
+        S, P = adversarial_reads((1 if w else 11) + si, n=(36 if w else 30), K=K)
+        out += [(si, s_, p_) for s_, p_ in zip(S, P)]
+        S, P = tail_run_reads((21 if w else 31) + si, n=(24 if w else 24), K=K)
+        out += [(si, s_, p_) for s_, p_ in zip(S, P)]
+        if si in (0, 3, 5):
+            out += [(si, s_, p_) for s_, p_ in _edge_cases(K, rng)]
+        AL = np.frombuffer(b"ACGT", np.uint8)                 # tiny reads with jumping counts: about a fifth of them
+        for it in range(30 if si in (0, 3, 5) else 9):         # end in the reference's exit(1) ("# E-intvls >= plen")
+            plen = int(rng.integers(1, 12)); rlen = plen + K - 1
+            seq = [bytes(AL[rng.integers(0, 4, rlen)]), b"A" * rlen, (b"AC" * rlen)[:rlen]][it % 3]
+            out.append((si, seq, rng.choice([1, 2, 5, 20, 40, 80, 300], plen).astype(np.uint16)))
+    return out
+
+
+def _tables(psets):
+    """Per parameter set the threshold tables find_wall gets (from the oracle; checked entry by entry with exact integer
+    arithmetic in tests/test_first_principles.py) -- stored so the tests can see that the product uses the same ones."""
+    O = [Oracle(K, rl, h, d) for K, rl, h, d in psets]
+    return O, dict(psets=np.array(psets, np.int32),
+                   cthres=np.stack([o.cthres() for o in O]), pe=np.stack([o.pe() for o in O]),
+                   lmax=np.stack([o.lmax() for o in O]),
+                   cmax=np.array([o.scalars()[2] for o in O], np.int32), hc_erate=np.array([o.scalars()[3] for o in O]))
+
+
+def _refs(psets, O):
+    return [Ref(rl, h, d).wall_setup_from(o) for (K, rl, h, d), o in zip(psets, O)]
+
+
+def wall():
+    psets = _param_sets()
+    O, arrs = _tables(psets)
+    R = _refs(psets, O)
+    cases = wall_label_cases("wall")
+    seqs, profs, sets, status, ivs, rvs = [], [], [], [], [], []
+    for si, s, p in cases:
+        K = psets[si][0]
+        st = R[si].find_wall_exit_status(s, p, K)
+        assert st in (0, 1), st
+        if st == 0:
+            iv, rv = R[si].find_wall_rel(s, p, K)
+        else:
+            iv = rv = np.zeros(0, INTVL_DTYPE)
+        seqs.append(np.frombuffer(s, np.uint8)); profs.append(p); sets.append(si); status.append(st)
+        ivs.append(iv); rvs.append(rv)
+    def cat(L, dt):                          # (np.concatenate would repack the padded record dtype)
+        out = np.zeros(sum(len(x) for x in L), dt)
+        o = 0
+        for x in L:
+            out[o:o + len(x)] = x
+            o += len(x)
+        return out
+    off = lambda L: np.concatenate([[0], np.cumsum([len(x) for x in L])]).astype(np.int64)
+    np.savez_compressed(os.path.join(OUT, "wall.npz"), set=np.array(sets, np.int32), status=np.array(status, np.int8),
+                        seq=cat(seqs, np.uint8), seq_off=off(seqs), prof=cat(profs, np.uint16), prof_off=off(profs),
+                        intvl=cat(ivs, INTVL_DTYPE).view(np.uint8), intvl_off=off(ivs),
+                        rintvl=cat(rvs, INTVL_DTYPE).view(np.uint8), rintvl_off=off(rvs), **arrs)
+    print("wall.npz: %d reads, %d exit(1), %d intervals, %d reliable" % (len(cases), sum(status), sum(map(len, ivs)), sum(map(len, rvs))))
+
+
+def labels():
+    psets = _param_sets()
+    O, arrs = _tables(psets)
+    R = _refs(psets, O)
+    cases = wall_label_cases("labels")
+    seqs, profs, sets, status, labs, asg = [], [], [], [], [], []
+    for si, s, p in cases:
+        K = psets[si][0]
+        st = R[si].find_wall_exit_status(s, p, K)
+        assert st in (0, 1), st
+        if st == 0:
+            lab, iv = R[si].classify_read(s, p, K, want_intvl=True)
+            assert lab[:K - 1] == b"N" * (K - 1) and len(lab) == len(s)
+        else:
+            lab, iv = b"", np.zeros(0, INTVL_DTYPE)
+        seqs.append(np.frombuffer(s, np.uint8)); profs.append(p); sets.append(si); status.append(st)
+        labs.append(np.frombuffer(lab, np.uint8)); asg.append(iv["asgn"].copy())
+    cat = lambda L, dt: np.concatenate(L) if len(L) else np.zeros(0, dt)
+    off = lambda L: np.concatenate([[0], np.cumsum([len(x) for x in L])]).astype(np.int64)
+    np.savez_compressed(os.path.join(OUT, "labels.npz"), set=np.array(sets, np.int32), status=np.array(status, np.int8),
+                        seq=cat(seqs, np.uint8), seq_off=off(seqs), prof=cat(profs, np.uint16), prof_off=off(profs),
+                        labels=cat(labs, np.uint8), labels_off=off(labs), asgn=cat(asg, np.int8), asgn_off=off(asg), **arrs)
+    print("labels.npz: %d reads, %d exit(1), %d bases labelled" % (len(cases), sum(status), sum(map(len, labs))))
+
+
 if __name__ == "__main__":
     if not ref_available() and not os.path.exists("/root/reference/src/ClassPro.h"):
         sys.exit("oracle/_ref is not built and /root/reference is absent")
     os.makedirs(OUT, exist_ok=True)
-    prims(); context(); classify(); fastk_files(); eval_tools(); dazz_db(); seeds()
+    only = sys.argv[1:]
+    for f in (prims, context, classify, fastk_files, eval_tools, dazz_db, seeds, wall, labels):
+        if not only or f.__name__ in only:
+            f()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

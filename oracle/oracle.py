@@ -69,7 +69,7 @@ class Oracle:
         L.cpo_params_new.restype = C.c_void_p
         L.cpo_params_new.argtypes = [C.c_int] * 4
         L.cpo_params_free.argtypes = [C.c_void_p]
-        for f in ("cpo_params_cthres", "cpo_params_logfact", "cpo_params_pe"):
+        for f in ("cpo_params_cthres", "cpo_params_logfact", "cpo_params_pe", "cpo_params_lmax"):
             getattr(L, f).restype = C.c_void_p
             getattr(L, f).argtypes = [C.c_void_p]
         L.cpo_bessi.restype = C.c_double
@@ -122,6 +122,10 @@ class Oracle:
     def pe(self):
         ptr = self.L.cpo_params_pe(self.p)
         return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(3, 21)).copy()
+
+    def lmax(self):
+        ptr = self.L.cpo_params_lmax(self.p)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int)), shape=(3,)).copy()
 
     def scalars(self):
         cov = (C.c_int * 4)()
@@ -248,6 +252,15 @@ def ref_available():
     return os.path.exists(os.path.join(_HERE, "_ref", "libclasspro_ref.so"))
 
 
+def ref_wall_available():
+    """True when oracle/_ref holds the GSL-free part of the reference's wall.c (find_wall, find_rel_intvl)."""
+    if not ref_available():
+        return False
+    build()
+    L = C.CDLL(os.path.join(_HERE, "_ref", "libclasspro_ref.so"))
+    return hasattr(L, "ref_have_wall") and L.ref_have_wall() == 1
+
+
 class Ref:
     """The reference's own code (GSL-free files) via oracle/_ref/libclasspro_ref.so."""
 
@@ -268,9 +281,107 @@ class Ref:
         L.ref_profiles_nreads.argtypes = [C.c_void_p]
         L.ref_profiles_kmer.argtypes = [C.c_void_p]
         L.ref_fetch_profile.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.POINTER(C.c_uint16)]
+        self._setup = (read_len, hcov, dcov)
+        self._wall = None
         L.ref_setup(read_len, hcov, dcov)
+        Ref._current = self
+
+    _current = None
+
+    def _activate(self):
+        """The reference keeps its parameters in process-wide globals: make this instance's the live ones."""
+        if Ref._current is not self:
+            self.L.ref_setup(*self._setup)
+            if self._wall is not None:
+                self._wall_apply()
+            Ref._current = self
+
+    # ---- wall.c:245-1051 (GSL-free part): find_wall, find_rel_intvl, the whole per-read path ----
+    def wall_setup(self, cthres, pe, lmax, cmax, hc_erate):
+        """Fill the Error_Model find_wall takes as a parameter (what calc_init_thres, wall.c:167-243, would leave):
+        cthres uint8[3][21][256][2][2], pe float64[3][21], lmax int[3], CMAX, HC_ERATE."""
+        self._wall = (np.ascontiguousarray(cthres, np.uint8).copy(), np.ascontiguousarray(pe, np.float64).copy(),
+                      np.ascontiguousarray(lmax, np.int32).copy(), int(cmax), float(hc_erate))
+        self._wall_apply()
+        return self
+
+    def wall_setup_from(self, O):
+        """Tables of an Oracle built for the same (read_len, H, D) -- the ones tests/test_first_principles.py checks
+        entry by entry with exact integer arithmetic."""
+        cov, _, cmax, hc = O.scalars()
+        assert (cov[2], cov[3]) == self._setup[1:] and O.read_len == self._setup[0]
+        return self.wall_setup(O.cthres(), O.pe(), O.lmax(), cmax, hc)
+
+    def _wall_apply(self):
+        ct, pe, lm, cmax, hc = self._wall
+        self.L.ref_wall_setup.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double]
+        self.L.ref_wall_setup(ct.ctypes.data, pe.ctypes.data, lm.ctypes.data, cmax, hc)
+
+    def find_wall_rel(self, seq, profile, K=40):
+        """find_wall + find_rel_intvl on fresh, zeroed buffers: (intvl[N] after find_rel_intvl, rintvl[M])."""
+        self._activate()
+        s = (seq if isinstance(seq, bytes) else seq.encode()) + b"\0"
+        rlen = len(s) - 1
+        profile = np.ascontiguousarray(profile, np.uint16)
+        assert len(profile) == rlen - K + 1
+        cap = len(profile) + 2
+        iv = np.zeros(cap, INTVL_DTYPE)
+        rv = np.zeros(cap, INTVL_DTYPE)
+        M = C.c_int()
+        self.L.ref_find_wall_rel.restype = C.c_int
+        n = self.L.ref_find_wall_rel(C.c_char_p(s), C.c_int(rlen), _p(profile, C.c_uint16), C.c_int(K),
+                                     iv.ctypes.data_as(C.c_void_p), C.c_int(cap), C.byref(M),
+                                     rv.ctypes.data_as(C.c_void_p))
+        if n < 0:
+            raise RuntimeError("ref_find_wall_rel: %d" % n)
+        return iv[:n].copy(), rv[:M.value].copy()
+
+    def find_wall_exit_status(self, seq, profile, K=40):
+        """The same call in a child process: 0 = returned, 1 = the reference's own exit(1) ('# E-intvls >= plen')."""
+        self._activate()
+        s = (seq if isinstance(seq, bytes) else seq.encode()) + b"\0"
+        profile = np.ascontiguousarray(profile, np.uint16)
+        self.L.ref_find_wall_exit_status.restype = C.c_int
+        return self.L.ref_find_wall_exit_status(C.c_char_p(s), C.c_int(len(s) - 1), _p(profile, C.c_uint16), C.c_int(K))
+
+    def classify_read(self, seq, profile, K=40, want_intvl=False):
+        """The whole per-read path in reference text only (context.c -> wall.c slice -> class_rel.c -> class_unrel.c ->
+        paint, ClassPro.c:229-271) on fresh buffers: the label string."""
+        self._activate()
+        s = (seq if isinstance(seq, bytes) else seq.encode()) + b"\0"
+        rlen = len(s) - 1
+        profile = np.ascontiguousarray(profile, np.uint16)
+        lab = np.zeros(max(rlen, 1), np.uint8)
+        cap = max(rlen, 1) + 2
+        iv = np.zeros(cap, INTVL_DTYPE)
+        self.L.ref_classify_read.restype = C.c_int
+        n = self.L.ref_classify_read(C.c_char_p(s), C.c_int(rlen), _p(profile, C.c_uint16), C.c_int(K), _p(lab, C.c_char),
+                                     iv.ctypes.data_as(C.c_void_p), C.c_int(cap))
+        if n < 0:
+            raise RuntimeError("ref_classify_read: %d" % n)
+        out = lab[:rlen].tobytes()
+        return (out, iv[:n].copy()) if want_intvl else out
+
+    def classify_batch(self, seq, seq_off, prof, prof_off, K=40, nthreads=1, rlen_max=0, defined=True):
+        """The reference's thread loop without its I/O (ref_classify_batch): labels, (alloc seconds, run seconds)."""
+        self._activate()
+        seq = np.ascontiguousarray(seq, np.uint8)
+        prof = np.ascontiguousarray(prof, np.uint16)
+        seq_off = np.ascontiguousarray(seq_off, np.int64)
+        prof_off = np.ascontiguousarray(prof_off, np.int64)
+        labels = np.zeros(len(seq), np.uint8)
+        sec = np.zeros(2, np.float64)
+        self.L.ref_classify_batch.restype = C.c_int
+        rc = self.L.ref_classify_batch(_p(seq, C.c_char), _p(seq_off, C.c_longlong), _p(prof, C.c_uint16),
+                                       _p(prof_off, C.c_longlong), C.c_int(len(seq_off) - 1), C.c_int(K),
+                                       _p(labels, C.c_char), C.c_int(nthreads), C.c_int(rlen_max),
+                                       C.c_int(1 if defined else 0), _p(sec, C.c_double))
+        if rc != 0:
+            raise RuntimeError("ref_classify_batch: %d" % rc)
+        return labels, (float(sec[0]), float(sec[1]))
 
     def globals(self):
+        self._activate()
         cov = (C.c_int * 4)()
         dr = C.c_double()
         self.L.ref_globals(cov, C.byref(dr))
@@ -285,7 +396,10 @@ class Ref:
     def logp_skellam(self, k, lam): return self.L.ref_logp_skellam(k, lam)
     def logp_binom(self, k, n, pr): return self.L.ref_logp_binom(k, n, pr)
     def binom_test_g(self, k, n, pe, exact=0): return self.L.ref_binom_test_g(k, n, pe, exact)
-    def logp_trans(self, b, e, cb, ce, cov): return self.L.ref_logp_trans(b, e, cb, ce, cov)
+    def logp_trans(self, b, e, cb, ce, cov):
+        self._activate()
+        return self.L.ref_logp_trans(b, e, cb, ce, cov)
+
     def p_errorin(self, e, erate, cout, cin): return self.L.ref_p_errorin(e, erate, cout, cin)
 
     def hist_covs(self, fk_root, coverage=0):
@@ -316,6 +430,7 @@ class Ref:
         return l, r
 
     def classify(self, rintvl, intvl, plen, stage=2):
+        self._activate()
         rintvl, intvl = rintvl.copy(), intvl.copy()
         self.L.ref_classify(rintvl.ctypes.data_as(C.c_void_p), C.c_int(len(rintvl)),
                             intvl.ctypes.data_as(C.c_void_p), C.c_int(len(intvl)), C.c_int(plen), C.c_int(stage))
@@ -337,6 +452,7 @@ class Ref:
         return sas[:plen].astype(np.uint8), rep[:n].copy(), hsh[:plen].copy()
 
     def classify_rel_dir(self, rintvl, plen, forward):
+        self._activate()
         rintvl = rintvl.copy()
         M = len(rintvl)
         out = np.zeros(max(M, 1), np.int8)
