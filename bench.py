@@ -76,8 +76,14 @@ def parse():
     ap.add_argument("--pcie-batch-mbases", type=float, default=250.0)
     ap.add_argument("--pcie-slots", type=int, default=6)
     ap.add_argument("--pcie-pack-threads", type=int, default=8, help="host threads packing a batch's bases to 2 bits (per slot, inside the timed region)")
+    ap.add_argument("--host-feed-gbases", type=float, default=1.0, help="source reads per feeder group of extras.host_feed")
+    ap.add_argument("--host-feed-seconds", type=float, default=1.5, help="span of each extras.host_feed leg")
+    ap.add_argument("--no-rank-pcie", action="store_true", help="N > 1: skip the PCIe-inclusive leg that all ranks run at once")
     ap.add_argument("--only-pcie", action="store_true", help="skip the other extras (profiling the PCIe pipeline)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu-ref", action="store_true", help="cpu_baseline from the port only (skip the reference-function legs)")
+    ap.add_argument("--cpu-ref-max-threads", type=int, default=64,
+                    help="thread count of the reference's -T<all> leg: every thread allocates ~1 GB of DP scratch (alloc_rel_arg for MAX_READ_LEN)")
     ap.add_argument("--no-extras", action="store_true", help="skip the MHC-like / PCIe / CLI extras (profiling runs)")
     return ap.parse_args()
 
@@ -98,6 +104,17 @@ def scan_kernel_id():
     src = open(os.path.join(_ROOT, "classpro_amd", "csrc", "kernels.hip")).read()
     m = re.search(r"typedef unsigned cp_u4v.*?\n// -{20,}\n//  Candidate count per read", src, re.S)
     return hashlib.sha1((m.group(0) if m else src).encode()).hexdigest()[:12]
+
+
+def tables_estimate():
+    """Device bytes of the look-up tables cp_params_create will ask for (capi.hip: the Skellam table, its exp() twin unless
+    CLASSPRO_EXP_TABLE=0, 8 MB + 66 MB of small ones), from the same environment knobs -- for the pre-flight check, which runs
+    before a cp_params exists; cp_params_tables() reports the real figures afterwards (extras.tables_bytes)."""
+    if os.environ.get("CLASSPRO_TABLES", "1") == "0":
+        return 2e6
+    mb = int(os.environ.get("CLASSPRO_SKELLAM_TABLE_MB", "1024"))
+    twin = os.environ.get("CLASSPRO_EXP_TABLE", "1") != "0"
+    return mb * 2.0 ** 20 * (2 if twin else 1) + 80e6
 
 
 def main():
@@ -180,7 +197,7 @@ def main():
     # two ranks sharing one GPU, or a window sized for another card, end here with a message instead of a raw hipMalloc
     # failure in the middle of the run
     win_max = max((int(ds.seq_off_all[f + c] - ds.seq_off_all[f]) for f, c in windows if c), default=0)
-    need = 4.05 * win_max + nst * 11.5 * min(win_max, a.batch_mbases * 1e6) + 2.4e9
+    need = 4.05 * win_max + nst * 11.5 * min(win_max, a.batch_mbases * 1e6) + tables_estimate()
     torch.cuda.empty_cache()
     free_b, total_b = torch.cuda.mem_get_info(dev)
     sharers = 1
@@ -281,6 +298,27 @@ def main():
         total_bases_all = my_bases
     value = total_bases_all * a.steps / dt / 1e6
 
+    # ---- N > 1: every rank runs a short PCIe-inclusive leg AT THE SAME TIME (its own GPU, its own feeders, one shared
+    #      host): `value` above is kernels on resident data and scales by construction; this is where 8 feeders contending
+    #      for the host's cores and DRAM would show.  Reported per rank in extras.pcie_all_ranks, never as `value`. ----
+    pcie_ranks = None
+    if world > 1 and not a.no_extras and not a.no_rank_pcie:
+        import copy
+        a2 = copy.copy(a)
+        a2.pcie_gbases, a2.pcie_seconds = min(a.pcie_gbases, 1.0), min(a.pcie_seconds, 1.0)
+        barrier()
+        try:
+            r_ = pcie_pipeline(a2, ds, clf, batches, dev)
+            mine = {"rank": rank, "mbases_per_s": r_.get("mbases_per_s"), "runs_mbases_per_s": r_.get("label_runs", {}).get("mbases_per_s"),
+                    "frac": r_.get("frac"), "pinned_h2d_peak_gb_per_s": r_.get("pinned_h2d_peak_gb_per_s"),
+                    "gpu_numa_node": r_.get("gpu_numa_node"), "feeder_cpus_on_gpu_node": r_.get("feeder_cpus_on_gpu_node"),
+                    "pack_threads_per_slot": r_.get("pack_threads_per_slot"), "labels_match_resident_run": r_.get("labels_match_resident_run")}
+        except Exception as e:                              # never takes the bench line down
+            mine = {"rank": rank, "error": repr(e)[:200]}
+        barrier()
+        pcie_ranks = [None] * world
+        dist.all_gather_object(pcie_ranks, mine)
+
     if rank == 0:
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         # ---- roofline of the profile-scan kernel: HIP events on the launch stream; every launch streams one
@@ -321,7 +359,10 @@ def main():
                 "working_set_bytes": 2.0 * win_kmers}
 
         rd0, b0 = batches[0]
-        extras = {"per_gpu_mbases_per_s": round(total_bases_all * a.steps / dt / 1e6 / world, 1),
+        extras = {"pcie_all_ranks": None if pcie_ranks is None else
+                  {"what": "PCIe-inclusive pipeline (host packing + H2D + format kernels + classification + 2-bit labels D2H), all ranks at once, 1 Gbase staged per rank",
+                   "sum_mbases_per_s": round(sum((x.get("mbases_per_s") or 0) for x in pcie_ranks), 1), "ranks": pcie_ranks},
+                  "per_gpu_mbases_per_s": round(total_bases_all * a.steps / dt / 1e6 / world, 1),
                   "rank0_mbases_per_s_own_clock": round(my_bases * a.steps / my_dt / 1e6, 1),
                   "process_group": ("%s, world %d" % (a.backend, world)) if use_dist else None,
                   "whole_step_algorithmic_gb_per_s": round((2.0 * my_kmers + 2.0 * my_bases) * world / (dt / a.steps) / 1e9, 1),
@@ -356,8 +397,12 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "u16/f64",
             "data": "synthetic",
+            "timed_region": "classification kernels only (cp_classify_batch per sub-batch): bases, uint16 count profiles and labels are "
+                            "resident in HBM; H2D, D2H, profile decode, file I/O and the host are OUTSIDE the timed region.  The other rates "
+                            "of the same run: extras.pcie.mbases_per_s (host packing + PCIe + format kernels + kernels + labels back), "
+                            "extras.cli_end_to_end_mbases_per_s (the ClassPro binary on files, process start to exit), extras.host_feed (the host side alone)",
             "config": {"workload": "synthetic %.0f Mbp diploid, %dx HiFi, r=%d, k=40 (%s): %d distinct reads, %.2f Gbases%s; a rank's share resident in HBM "
-                                   "%s, sub-batches of at most %.0f Mbases"
+                                   "%s, sub-batches of at most %.0f Mbases; value = kernels on HBM-resident inputs (see timed_region)"
                                    % (G / 1e6, a.cov, a.read_len, cfg, ds.n_reads, ds.total_bases / 1e9,
                                       (", of which shard %d of %d (%.2f Gbases) in this process" % (shard_r, shard_n, my_bases / 1e9)) if a.shard else "",
                                       "whole" if len(windows) == 1 else "in %d windows (each generated untimed, then warm-up + timed steps over it; a step = the sum over windows)" % len(windows),
@@ -378,12 +423,19 @@ def main():
 
 
 def cpu_baseline(a, ds, batches, hcov, dcov):
-    """-T1, -T16 and -T<all cores> of the CPU port (oracle/classpro_oracle.c), each on about --cpu-seconds of work."""
-    from oracle.oracle import Oracle
+    """The CPU beside the GPU number, on bounded samples of the same resident read set, every label compared with the
+    HIP result.  Two implementations, -T1 / -T16 / -T<all> each (about --cpu-seconds of work per leg):
+      * "reference": the reference's OWN per-read functions -- calc_seq_context (context.c), find_wall + find_rel_intvl
+        (the GSL-free part of wall.c), classify_rel, classify_unrel, the paint loop -- in the reference's thread loop
+        without its file I/O (oracle/ref_driver.c: ref_classify_batch = ClassPro.c:114-143 scratch once per thread,
+        146-271 per read).  oracle/_ref/libclasspro_ref.so is built in the build container and travels with the snapshot.
+        The allocation phase (alloc_rel_arg: 240 000 mallocs of 60 KB per thread, SURVEY hazard 7) is timed apart.
+      * "port": the oracle's restatement (oracle/classpro_oracle.c).
+    `value` is the reference's -T16 when that library is present, else the port's."""
+    from oracle.oracle import Oracle, Ref, ref_wall_available
     O = Oracle(K, a.read_len, hcov, dcov)
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     rd0, b0 = batches[0]
-    so_all, po_all = rd0["seq_off_h"], rd0["prof_off_h"]
 
     def host_sample(rd, b, nreads):
         so, po = rd["seq_off_h"][:nreads + 1], rd["prof_off_h"][:nreads + 1]
@@ -400,9 +452,10 @@ def cpu_baseline(a, ds, batches, hcov, dcov):
     # calibrate on 64 reads, then size each leg for ~cpu_seconds
     cal = host_sample(rd0, b0, min(64, b0.nreads))
     r1, _, _, _ = run(cal, 1)
+    thread_legs = (("T1", 1), ("T16", min(16, ncores)), ("Tall", ncores))
     legs = {}
     mism = 0
-    for name, nt in (("T1", 1), ("T16", min(16, ncores)), ("Tall", ncores)):
+    for name, nt in thread_legs:
         if name == "Tall" and nt == min(16, ncores):
             legs[name] = dict(legs["T16"], threads=nt)
             continue
@@ -425,10 +478,45 @@ def cpu_baseline(a, ds, batches, hcov, dcov):
                       "label_mismatches_vs_hip": bad}
         mism += bad
     t16 = legs["T16"]
-    return {"value": t16["mbases_per_s"], "unit": "Mbases/s", "cores": t16["threads"], "kind": "port",
-            "sample": "first %d bases of the same resident read set (%.1f s of CPU work), oracle/classpro_oracle.c with %d pthreads; "
-                      "the reference itself cannot be linked here (wall.c needs GSL)" % (t16["bases"], t16["seconds"], t16["threads"]),
+    port = {"value": t16["mbases_per_s"], "unit": "Mbases/s", "cores": t16["threads"], "kind": "port",
+            "sample": "first %d bases of the same resident read set (%.1f s of CPU work), oracle/classpro_oracle.c with %d pthreads"
+                      % (t16["bases"], t16["seconds"], t16["threads"]),
             "seconds": t16["seconds"], "label_mismatches_vs_hip": mism, "legs": legs, "host_cores": ncores}
+    if a.no_cpu_ref or not ref_wall_available():
+        port["sample"] += "; oracle/_ref (the reference's own functions) is not present on this box"
+        return port
+
+    # ---- the reference's own functions.  (No read of the resident set makes the reference exit(1): the HIP path raises
+    #      CP_EOVERFLOW at exactly its five abort sites -- tests/test_gpu_reference.py -- and cp_workspace_check above
+    #      reported none.)  One sample from the first sub-batch per leg: every call pays the allocation phase again. ----
+    R = Ref(a.read_len, hcov, dcov).wall_setup_from(O)
+    rlegs, rmism = {}, 0
+    for name, nt in (("T1", 1), ("T16", min(16, ncores)), ("Tall", min(ncores, a.cpu_ref_max_threads))):
+        if name == "Tall" and nt == min(16, ncores):
+            rlegs[name] = dict(rlegs["T16"], threads=nt)
+            continue
+        want_bases = r1 * 1e6 * a.cpu_seconds * min(nt, 16) * 0.8
+        n = int(np.searchsorted(rd0["seq_off_h"], min(want_bases, rd0["seq_off_h"][-1]), side="left"))
+        n = min(max(n, nt), b0.nreads)
+        seq, so, prof, po, lab = host_sample(rd0, b0, n)
+        want, (t_alloc, t_run) = R.classify_batch(seq, so, prof, po, K, nthreads=nt, rlen_max=0, defined=True)
+        bad = int((lab != want).sum())
+        rlegs[name] = {"mbases_per_s": round(int(so[-1]) / t_run / 1e6, 2), "threads": nt, "seconds": round(t_run, 2),
+                       "startup_seconds": round(t_alloc, 2), "bases": int(so[-1]), "label_mismatches_vs_hip": bad}
+        rmism += bad
+        del seq, prof, lab, want
+    r16 = rlegs["T16"]
+    return {"value": r16["mbases_per_s"], "unit": "Mbases/s", "cores": r16["threads"], "kind": "reference",
+            "detail": "the reference's own functions (context.c, wall.c:245-1051 = its GSL-free part, class_rel.c, class_unrel.c, the paint "
+                      "loop of ClassPro.c:263-269) in its thread loop without file I/O: per thread one set of scratch sized for "
+                      "MAX_READ_LEN (ClassPro.c:110-143), contiguous read ranges (ClassPro.c:530); the three stale-scratch cells "
+                      "(DESIGN 3.3, hazards 1, 2, 8) are reset per read inside the timed region so that labels are a function of the read",
+            "sample": "first %d bases of the same resident read set (%.1f s at -T%d after %.1f s of per-thread allocation, reported apart)"
+                      % (r16["bases"], r16["seconds"], r16["threads"], r16["startup_seconds"]),
+            "seconds": r16["seconds"], "startup_seconds": r16["startup_seconds"], "label_mismatches_vs_hip": rmism + mism,
+            "legs": rlegs, "host_cores": ncores,
+            "port": port,
+            "port_over_reference": {k: round(legs[k]["mbases_per_s"] / rlegs[k]["mbases_per_s"], 3) for k in ("T1", "T16")}}
 
 
 def gpu_numa(dev):
@@ -726,6 +814,133 @@ def pcie_pipeline(a, ds, clf, batches, dev):
     return res
 
 
+def numa_nodes():
+    """[(node id, cpu set)] from sysfs, restricted to the cpus this process may use; [( -1, all )] when sysfs says nothing."""
+    aff = os.sched_getaffinity(0)
+    out = []
+    try:
+        for d in sorted(os.listdir("/sys/devices/system/node")):
+            if not d.startswith("node") or not d[4:].isdigit():
+                continue
+            cpus = set()
+            for part in open("/sys/devices/system/node/%s/cpulist" % d).read().strip().split(","):
+                if part:
+                    lo, _, hi = part.partition("-")
+                    cpus.update(range(int(lo), int(hi or lo) + 1))
+            if cpus & aff:
+                out.append((int(d[4:]), cpus & aff))
+    except Exception:
+        out = []
+    return out or [(-1, aff)]
+
+
+def cpu_quota():
+    """CPUs' worth of time the cgroup grants this process (cpu.max), or None when unlimited / unknown."""
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            t = open(f).read().split()
+            if f.endswith("cpu.max"):
+                return None if t[0] == "max" else round(int(t[0]) / int(t[1]), 2)
+            q = int(t[0])
+            return None if q <= 0 else round(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()), 2)
+        except Exception:
+            continue
+    return None
+
+
+def host_feed(a, batches, groups=(1, 2, 4, 8)):
+    """The HOST half of the PCIe pipeline alone, no device: what one box sustains when it feeds 1, 2, 4, 8 GPUs at once.
+    A feeder group stands for one GPU's feeders (pcie_pipeline: --pcie-slots slot threads, each packing its batch's bases
+    to 2 bits on --pcie-pack-threads threads -- cp_pack_bases_batch -- into one of two staging buffers and copying the
+    batch's FASTK code bytes into a staging buffer, the host-DRAM traffic of the DMA read); group g lives on NUMA node
+    g mod nodes (threads pinned there, its source reads and staging buffers first touched there).  Each group has its own
+    copy of the source reads (bases as characters + 0.274 B/base of code bytes), far larger than the last-level cache.
+    Reports Gbases/s per group count, host-DRAM GB/s (1 B/base read + 0.25 written by the packing, 2 x 0.274 by the code
+    copy) and the threads in use.  README.md:71 / io.c:353-354 of the reference name I/O as ITS bottleneck; this is ours."""
+    import ctypes as C
+    import threading
+    from classpro_amd._lib import lib
+    L = lib()
+    nodes = numa_nodes()
+    rd0, b0 = batches[0]
+    per_group = int(min(a.host_feed_gbases * 1e9, b0.total_bases))
+    tgt = int(a.pcie_batch_mbases * 1e6)
+    so_all = rd0["seq_off_h"]
+    nreads = int(np.searchsorted(so_all, per_group, side="right") - 1)
+    nreads = max(nreads, 1)
+    so = so_all[:nreads + 1].astype(np.int64)
+    src = rd0["seq"][:so[-1]].cpu().numpy()
+    code_bpb = 0.274                                        # FASTK code bytes per base of this workload (extras.code_bytes_per_base)
+    # batches of ~tgt bases: (first read, last read)
+    cuts = [0]
+    while cuts[-1] < nreads:
+        r1 = int(np.searchsorted(so, so[cuts[-1]] + tgt, side="left"))
+        cuts.append(min(max(r1, cuts[-1] + 1), nreads))
+    bt = list(zip(cuts[:-1], cuts[1:]))
+    pko = np.zeros(nreads + 1, np.int64)
+    np.cumsum((np.diff(so) + 3) // 4, out=pko[1:])
+    NS, P = max(1, a.pcie_slots), max(1, a.pcie_pack_threads)
+    aff0 = os.sched_getaffinity(0)
+    res = {"numa_nodes": [[n, len(c)] for n, c in nodes], "cpus_allowed": len(aff0), "cgroup_cpu_quota": cpu_quota(),
+           "slots_per_group": NS, "pack_threads_per_slot": P, "batch_mbases": round(tgt / 1e6, 1),
+           "source_gbases_per_group": round(int(so[-1]) / 1e9, 2), "dram_bytes_per_base": round(1.25 + 2 * code_bpb, 3), "legs": {}}
+    maxb = max(int(so[r1] - so[r0]) for r0, r1 in bt)
+    state = {}
+
+    def setup(g):                                           # runs on a thread pinned to the group's node: first touch there
+        node, cpus = nodes[g % len(nodes)]
+        os.sched_setaffinity(0, cpus)
+        st = dict(seq=src.copy(), code=np.ones(int(code_bpb * int(so[-1])) + 64, np.uint8),
+                  pk=[[np.zeros(maxb // 4 + nreads + 64, np.uint8) for _ in range(2)] for _ in range(NS)],
+                  cst=[np.zeros(int(code_bpb * maxb) + 64, np.uint8) for _ in range(NS)])
+        state[g] = st
+
+    def slot(g, k, t_end, out):
+        node, cpus = nodes[g % len(nodes)]
+        os.sched_setaffinity(0, cpus)
+        st = state[g]
+        done, flip, j = 0, 0, k
+        while time.perf_counter() < t_end:
+            r0, r1 = bt[j % len(bt)]
+            j += NS
+            n = r1 - r0
+            nb = int(so[r1] - so[r0])
+            loc_so = np.ascontiguousarray(so[r0:r1 + 1])
+            loc_pk = np.ascontiguousarray(pko[r0:r1 + 1] - pko[r0])
+            ok = L.cp_pack_bases_batch(st["seq"].ctypes.data, loc_so.ctypes.data, n, st["pk"][k][flip].ctypes.data, loc_pk.ctypes.data, P)
+            flip ^= 1
+            if ok != 1:
+                raise RuntimeError("the synthetic reads should be pure ACGT")
+            nc = int(code_bpb * nb)
+            C.memmove(st["cst"][k].ctypes.data, st["code"].ctypes.data + int(code_bpb * int(so[r0])), nc)
+            done += nb
+        out.append(done)
+
+    try:
+        for G in groups:
+            for g in range(G):
+                if g not in state:
+                    t = threading.Thread(target=setup, args=(g,))
+                    t.start(); t.join()
+            outs = []
+            t_end = time.perf_counter() + a.host_feed_seconds
+            t0 = time.perf_counter()
+            th = [threading.Thread(target=slot, args=(g, k, t_end, outs)) for g in range(G) for k in range(NS)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            dt = time.perf_counter() - t0
+            tot = sum(outs)
+            res["legs"]["%d" % G] = {"feeder_groups": G, "gbases_per_s": round(tot / dt / 1e9, 1), "per_group_gbases_per_s": round(tot / dt / 1e9 / G, 1),
+                                     "host_dram_gb_per_s": round(tot * (1.25 + 2 * code_bpb) / dt / 1e9, 1),
+                                     "threads": G * NS * (P + 1), "seconds": round(dt, 2)}
+    finally:
+        os.sched_setaffinity(0, aff0)
+        state.clear()
+    return res
+
+
 def extra_rates(a, ds, clf, batches, hcov, dcov, dev, stream):
     """Reported beside `value`, never as `value`: the MHC-like configs[1] batch, the PCIe-inclusive rate of the
     drop-in's own transfer pattern, and the drop-in binary end to end on files in tmpfs."""
@@ -741,6 +956,13 @@ def extra_rates(a, ds, clf, batches, hcov, dcov, dev, stream):
         ex["pcie"] = pcie_pipeline(a, ds, clf, batches, dev)
     except Exception as e:                                  # the extras never take the bench line down
         ex["pcie_error"] = repr(e)[:300]
+    try:
+        ex["host_feed"] = host_feed(a, batches)
+        one = ex.get("pcie", {}).get("mbases_per_s")
+        if one:                                             # what 8 GPUs at the measured single-GPU PCIe-inclusive rate would ask of the host
+            ex["host_feed"]["asked_by_8_gpus_gbases_per_s"] = round(8 * one / 1e3, 1)
+    except Exception as e:
+        ex["host_feed_error"] = repr(e)[:300]
     if a.only_pcie:
         return ex
     # MHC-like set (BASELINE configs[1] stand-in): 5 Mbp x 40x = 10 000 reads, 200 Mbases, ONE batch per step

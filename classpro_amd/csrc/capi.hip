@@ -206,7 +206,7 @@ extern "C" void cp_params_destroy(cp_params *p)
 
 extern "C" int cp_params_tables(const cp_params *p, size_t *skel_bytes, size_t *uerr_bytes, size_t *petab_bytes)
 { if (!p) return set_err(CP_EINVAL,"cp_params_tables: null params");
-  if (skel_bytes) *skel_bytes = p->skel_bytes;
+  if (skel_bytes) *skel_bytes = p->skel_bytes+(p->eskel ? p->skel_bytes : 0);   // logp_trans and, same shape, exp() of it
   if (uerr_bytes) *uerr_bytes = p->uerr_bytes;
   if (petab_bytes) *petab_bytes = p->petab_bytes;
   return CP_OK;
@@ -937,8 +937,16 @@ extern "C" int cp_pack_bases_batch(const char *seq, const int64_t *seq_off, int 
     };
   if (nthreads == 1) work(0);
   else
-    { std::vector<std::thread> th;
-      for (int t = 0; t < nthreads; t++) th.emplace_back(work,t);
+    { // A thread that cannot be started (std::system_error under a process / thread limit) must not unwind through the
+      // C ABI: the ranges that got no thread are done by the caller, the threads that did start are joined either way.
+      std::vector<std::thread> th;
+      int started = 0;
+      try
+        { th.reserve((size_t)nthreads);
+          for (; started < nthreads-1; started++) th.emplace_back(work,started);
+        }
+      catch (...) { }
+      for (int t = started; t < nthreads; t++) work(t);
       for (auto &x : th) x.join();
     }
   for (int v : ok) if (!v) return 0;
@@ -977,7 +985,7 @@ extern "C" int cp_expand_label_runs(const int32_t *ends, const uint8_t *cls, int
       memset(labels+pos,(int)cls[j],(size_t)(e-pos));
       pos = e;
     }
-  if (nruns > 0 && pos != rlen) return set_err(CP_EINVAL,"cp_expand_label_runs: the runs do not cover the read");
+  if (pos != rlen) return set_err(CP_EINVAL,"cp_expand_label_runs: the runs do not cover the read");   // (rlen < K: pos == rlen already)
   return CP_OK;
 }
 

@@ -181,7 +181,16 @@ struct Window
     { if (hi <= lo) return;
       const int64_t base = lo & ~(int64_t)4095;
       if (ftruncate(fd,(off_t)hi) != 0) die("%s: cannot size the output\n",PROG);
-      void *m = mmap(nullptr,(size_t)(hi-base),PROT_READ|PROT_WRITE,MAP_SHARED,fd,(off_t)base);
+      int mfd = fd; off_t moff = (off_t)base;
+      // diagnostic knob (tests): the k-th output mapping of the run is backed by an EMPTY anonymous file, so the first
+      // store into it faults with SIGBUS exactly as a page that the file system cannot allocate does
+      static std::atomic<int> n_maps{0};
+      if (const char *e = getenv("CLASSPRO_DEBUG_ENOSPC_MAPPING"))
+        if (!track && atoi(e) == n_maps.fetch_add(1))
+          { mfd = memfd_create("classpro_enospc",0); moff = 0;
+            if (mfd < 0) die("%s: memfd_create failed\n",PROG);
+          }
+      void *m = mmap(nullptr,(size_t)(hi-base),PROT_READ|PROT_WRITE,MAP_SHARED,mfd,moff);
       if (m == MAP_FAILED) die("%s: cannot map the output file\n",PROG);
       remember_mapping(m,(size_t)(hi-base));
       if (track) { tmap = (char *)m; tmap_len = (size_t)(hi-base); tmap_base = base; trk_lo = lo; trk_hi = hi; }
@@ -267,18 +276,19 @@ static void remember_output(const std::string &p)
 // The mapped ranges of the outputs (map_out registers them): a SIGBUS is "no space" only when it comes from a store into
 // one of them.  From anywhere else -- a truncated or changed mapped INPUT, a hardware error -- the default action is
 // restored and the signal raised again, so the diagnosis and the core are the real ones and no output is deleted on a guess.
-static struct { volatile uintptr_t lo, hi; } g_out_maps[64];
-static volatile int g_n_out_maps = 0;
-static std::mutex g_out_maps_m;
+// The registry is a push-only linked list behind an atomic head: any number of mappings (a window adds one or two and a
+// human-scale input has hundreds of windows), appended by the indexing thread, walked by the handler without a lock
+// (a lock-free atomic pointer load is async-signal-safe; nodes are never freed or changed once published).
+struct OutMap { uintptr_t lo, hi; OutMap *next; };
+static std::atomic<OutMap *> g_out_maps{nullptr};
 static void remember_mapping(const void *m, size_t len)
-{ std::lock_guard<std::mutex> g(g_out_maps_m);
-  const int k = g_n_out_maps;
-  if (k < 64) { g_out_maps[k].lo = (uintptr_t)m; g_out_maps[k].hi = (uintptr_t)m+len; g_n_out_maps = k+1; }
+{ OutMap *n = new OutMap{(uintptr_t)m,(uintptr_t)m+len,g_out_maps.load(std::memory_order_relaxed)};
+  while (!g_out_maps.compare_exchange_weak(n->next,n,std::memory_order_release,std::memory_order_relaxed)) { }
 }
 static void on_sigbus(int sig, siginfo_t *si, void *)
 { const uintptr_t a = (uintptr_t)si->si_addr;
   bool ours = false;
-  for (int k = 0; k < g_n_out_maps; k++) if (a >= g_out_maps[k].lo && a < g_out_maps[k].hi) ours = true;
+  for (const OutMap *m = g_out_maps.load(std::memory_order_acquire); m; m = m->next) if (a >= m->lo && a < m->hi) ours = true;
   if (!ours)
     { signal(sig,SIG_DFL);
       raise(sig);

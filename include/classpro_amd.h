@@ -90,8 +90,9 @@ int  cp_params_create(int K, int read_len, int hcov, int dcov, cp_params **out);
 int  cp_params_create_model(int K, int read_len, int hcov, int dcov, const char *model_path, cp_params **out);
 int  cp_load_error_model(const char *model_path, double *pe63);
 void cp_params_destroy(cp_params *p);
-/* Device bytes of the three look-up tables this cp_params uses (0 = that table is not in use: its values are
- * computed on the spot). */
+/* Device bytes of the look-up tables this cp_params uses (0 = that table is not in use: its values are
+ * computed on the spot).  skel_bytes counts the logp_trans table AND, when present, the table of its exponentials
+ * (same shape: CLASSPRO_SKELLAM_TABLE_MB costs twice its value unless CLASSPRO_EXP_TABLE=0). */
 int  cp_params_tables(const cp_params *p, size_t *skel_bytes, size_t *uerr_bytes, size_t *petab_bytes);
 /* The device's scalar numerics, for inspection/tests: y[i] = f(x[i]) computed ON THE DEVICE by the functions the kernels
  * call -- fn 0: exp, 1: log (csrc/cp_libm.h: glibc 2.35's routines, the libm the reference's prob.c / class_rel.c /

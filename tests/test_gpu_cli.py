@@ -147,3 +147,23 @@ def test_output_larger_than_the_upfront_estimate(torch_dev, tmp_path):
     assert got == exp
     got, _ = _run(cli, d, "wide.fa", 4, "0,0", 600, None, {"CLASSPRO_OUT_ALLOC": "window"})
     assert got == exp
+
+
+@pytest.mark.parametrize("mapping", [3, 70])
+def test_full_output_device_in_any_window(cli_set, mapping):
+    """A page of the mapped output that cannot be allocated shows up as SIGBUS at the first store into it.  The handler
+    must recognise a fault in ANY output window as its own -- also the 71st mapping of a run (the registry of mapped
+    ranges was a 64-entry table until round 5: ADVICE r4) -- say "no space", remove the partial output, exit 1.
+    CLASSPRO_DEBUG_ENOSPC_MAPPING backs the chosen mapping with an empty anonymous file, the same fault as a full tmpfs."""
+    d, cli, exp = cli_set
+    env = dict(os.environ, CLASSPRO_DEVICES="0", CLASSPRO_WINDOW_KB="100", CLASSPRO_OUT_ALLOC="window",
+               CLASSPRO_DEBUG_ENOSPC_MAPPING=str(mapping))
+    assert os.path.getsize(os.path.join(d, "reads.fasta")) > 75 * 100 * 1024      # more than 70 windows
+    out = os.path.join(d, "reads.class")
+    r = subprocess.run([cli, "-T4", os.path.join(d, "reads.fasta")], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 1, (r.returncode, r.stderr)
+    assert "no space left on the output device" in r.stderr
+    assert not os.path.exists(out)
+    env.pop("CLASSPRO_DEBUG_ENOSPC_MAPPING")
+    r = subprocess.run([cli, "-T4", os.path.join(d, "reads.fasta")], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and open(out, "rb").read() == exp

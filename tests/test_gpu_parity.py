@@ -637,7 +637,7 @@ def test_skellam_table_is_what_the_kernels_compute(torch_dev, ds_b, monkeypatch)
         tb = clf.tables()
         assert (tb["skel"] == 0) == (mb == 0) and (tb["uerr"] == 0) == (mb == 0) and (tb["petab"] == 0) == (mb == 0), tb
         if mb == 1:
-            assert tb["skel"] == 1 << 20
+            assert tb["skel"] == 2 << 20                    # the logp_trans table and the table of its exponentials
         b = batch_fn()
         lab = clf.classify(b).copy()
         nc, ni, nr, off = clf.counts(b)
