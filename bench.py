@@ -82,8 +82,9 @@ def parse():
     ap.add_argument("--only-pcie", action="store_true", help="skip the other extras (profiling the PCIe pipeline)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-cpu-ref", action="store_true", help="cpu_baseline from the port only (skip the reference-function legs)")
-    ap.add_argument("--cpu-ref-max-threads", type=int, default=64,
-                    help="thread count of the reference's -T<all> leg: every thread allocates ~1 GB of DP scratch (alloc_rel_arg for MAX_READ_LEN)")
+    ap.add_argument("--cpu-ref-max-threads", type=int, default=32,
+                    help="cap on the thread count of the reference's -T<all> leg: every thread does 240 000 mallocs of 60 KB (alloc_rel_arg for "
+                         "MAX_READ_LEN, ~1 GB touched) and the threads serialise on the address-space lock: 0.3 s at -T1, 9.6 s at -T16, 85 s at -T64 (measured)")
     ap.add_argument("--no-extras", action="store_true", help="skip the MHC-like / PCIe / CLI extras (profiling runs)")
     return ap.parse_args()
 
@@ -434,7 +435,9 @@ def cpu_baseline(a, ds, batches, hcov, dcov):
     `value` is the reference's -T16 when that library is present, else the port's."""
     from oracle.oracle import Oracle, Ref, ref_wall_available
     O = Oracle(K, a.read_len, hcov, dcov)
-    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ncores_seen = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = cpu_quota()                                     # a box may show 256 cores and grant 16 cores' worth of time (cgroup cpu.max):
+    ncores = ncores_seen if not quota else max(1, min(ncores_seen, int(np.ceil(quota))))     # -T<all> means all it can run at once
     rd0, b0 = batches[0]
 
     def host_sample(rd, b, nreads):
@@ -481,7 +484,8 @@ def cpu_baseline(a, ds, batches, hcov, dcov):
     port = {"value": t16["mbases_per_s"], "unit": "Mbases/s", "cores": t16["threads"], "kind": "port",
             "sample": "first %d bases of the same resident read set (%.1f s of CPU work), oracle/classpro_oracle.c with %d pthreads"
                       % (t16["bases"], t16["seconds"], t16["threads"]),
-            "seconds": t16["seconds"], "label_mismatches_vs_hip": mism, "legs": legs, "host_cores": ncores}
+            "seconds": t16["seconds"], "label_mismatches_vs_hip": mism, "legs": legs, "host_cores": ncores,
+            "host_cores_visible": ncores_seen, "cgroup_cpu_quota": quota}
     if a.no_cpu_ref or not ref_wall_available():
         port["sample"] += "; oracle/_ref (the reference's own functions) is not present on this box"
         return port
@@ -514,7 +518,7 @@ def cpu_baseline(a, ds, batches, hcov, dcov):
             "sample": "first %d bases of the same resident read set (%.1f s at -T%d after %.1f s of per-thread allocation, reported apart)"
                       % (r16["bases"], r16["seconds"], r16["threads"], r16["startup_seconds"]),
             "seconds": r16["seconds"], "startup_seconds": r16["startup_seconds"], "label_mismatches_vs_hip": rmism + mism,
-            "legs": rlegs, "host_cores": ncores,
+            "legs": rlegs, "host_cores": ncores, "host_cores_visible": ncores_seen, "cgroup_cpu_quota": quota,
             "port": port,
             "port_over_reference": {k: round(legs[k]["mbases_per_s"] / rlegs[k]["mbases_per_s"], 3) for k in ("T1", "T16")}}
 
@@ -562,6 +566,8 @@ def pcie_pipeline(a, ds, clf, batches, dev):
     res["feeder_cpus_on_gpu_node"] = pinned_to
     # a box that gives this process few cores: the slots' packing threads share them instead of oversubscribing them sixfold
     ncpu = pinned_to or len(aff0)
+    res["cgroup_cpu_quota"] = cpu_quota()                   # (packing is short bursts -- 9 cores' worth on average at 88 Gbases/s -- so the
+                                                            #  slots keep their threads under a quota; extras.host_feed sizes by it)
     if a.pcie_slots * (a.pcie_pack_threads + 1) > ncpu:
         a.pcie_pack_threads = max(1, ncpu // max(1, a.pcie_slots) - 1)
     try:
@@ -879,23 +885,31 @@ def host_feed(a, batches, groups=(1, 2, 4, 8)):
     bt = list(zip(cuts[:-1], cuts[1:]))
     pko = np.zeros(nreads + 1, np.int64)
     np.cumsum((np.diff(so) + 3) // 4, out=pko[1:])
-    NS, P = max(1, a.pcie_slots), max(1, a.pcie_pack_threads)
     aff0 = os.sched_getaffinity(0)
-    res = {"numa_nodes": [[n, len(c)] for n, c in nodes], "cpus_allowed": len(aff0), "cgroup_cpu_quota": cpu_quota(),
-           "slots_per_group": NS, "pack_threads_per_slot": P, "batch_mbases": round(tgt / 1e6, 1),
-           "source_gbases_per_group": round(int(so[-1]) / 1e9, 2), "dram_bytes_per_base": round(1.25 + 2 * code_bpb, 3), "legs": {}}
+    quota = cpu_quota()
+    cores = len(aff0) if not quota else max(1, min(len(aff0), int(quota)))       # what can run at once
+    res = {"numa_nodes": [[n, len(c)] for n, c in nodes], "cpus_allowed": len(aff0), "cgroup_cpu_quota": quota, "cores_usable": cores,
+           "batch_mbases": round(tgt / 1e6, 1), "source_gbases_per_group": round(int(so[-1]) / 1e9, 2),
+           "dram_bytes_per_base": round(1.25 + 2 * code_bpb, 3), "legs": {}}
     maxb = max(int(so[r1] - so[r0]) for r0, r1 in bt)
     state = {}
+
+    def plan(G):
+        """slots per group and pack threads per slot: the pipeline's own (--pcie-slots x --pcie-pack-threads) when the box has the
+        cores for G such groups, else as many busy threads as it can run at once, split evenly"""
+        ns = max(1, min(a.pcie_slots, cores // G))
+        return ns, max(1, min(a.pcie_pack_threads, cores // (G * ns)))
 
     def setup(g):                                           # runs on a thread pinned to the group's node: first touch there
         node, cpus = nodes[g % len(nodes)]
         os.sched_setaffinity(0, cpus)
+        NSm = max(1, a.pcie_slots)
         st = dict(seq=src.copy(), code=np.ones(int(code_bpb * int(so[-1])) + 64, np.uint8),
-                  pk=[[np.zeros(maxb // 4 + nreads + 64, np.uint8) for _ in range(2)] for _ in range(NS)],
-                  cst=[np.zeros(int(code_bpb * maxb) + 64, np.uint8) for _ in range(NS)])
+                  pk=[[np.zeros(maxb // 4 + nreads + 64, np.uint8) for _ in range(2)] for _ in range(NSm)],
+                  cst=[np.zeros(int(code_bpb * maxb) + 64, np.uint8) for _ in range(NSm)])
         state[g] = st
 
-    def slot(g, k, t_end, out):
+    def slot(g, k, NS, P, t_end, out):
         node, cpus = nodes[g % len(nodes)]
         os.sched_setaffinity(0, cpus)
         st = state[g]
@@ -916,25 +930,49 @@ def host_feed(a, batches, groups=(1, 2, 4, 8)):
             done += nb
         out.append(done)
 
+    def copier(g, t_end, out):                              # the yardstick: plain memmove of the group's bases, thread pinned like a feeder
+        node, cpus = nodes[g % len(nodes)]
+        os.sched_setaffinity(0, cpus)
+        a_, n, done = state[g % len(state)]["seq"], int(so[-1]) // 2, 0
+        while time.perf_counter() < t_end:
+            C.memmove(a_.ctypes.data + n, a_.ctypes.data, n)
+            done += 2 * n                                   # bytes read + written
+        out.append(done)
+
     try:
         for G in groups:
             for g in range(G):
                 if g not in state:
                     t = threading.Thread(target=setup, args=(g,))
                     t.start(); t.join()
+            NS, P = plan(G)
             outs = []
             t_end = time.perf_counter() + a.host_feed_seconds
             t0 = time.perf_counter()
-            th = [threading.Thread(target=slot, args=(g, k, t_end, outs)) for g in range(G) for k in range(NS)]
+            th = [threading.Thread(target=slot, args=(g, k, NS, P, t_end, outs)) for g in range(G) for k in range(NS)]
             for t in th:
                 t.start()
             for t in th:
                 t.join()
             dt = time.perf_counter() - t0
             tot = sum(outs)
-            res["legs"]["%d" % G] = {"feeder_groups": G, "gbases_per_s": round(tot / dt / 1e9, 1), "per_group_gbases_per_s": round(tot / dt / 1e9 / G, 1),
-                                     "host_dram_gb_per_s": round(tot * (1.25 + 2 * code_bpb) / dt / 1e9, 1),
-                                     "threads": G * NS * (P + 1), "seconds": round(dt, 2)}
+            res["legs"]["%d" % G] = {"feeder_groups": G, "slots_per_group": NS, "pack_threads_per_slot": P, "busy_threads": G * NS * P,
+                                     "gbases_per_s": round(tot / dt / 1e9, 1), "per_group_gbases_per_s": round(tot / dt / 1e9 / G, 1),
+                                     "per_busy_thread_gbases_per_s": round(tot / dt / 1e9 / (G * NS * P), 2),
+                                     "host_dram_gb_per_s": round(tot * (1.25 + 2 * code_bpb) / dt / 1e9, 1), "seconds": round(dt, 2)}
+        # plain copies on as many threads as the box runs at once, spread over the nodes: the DRAM rate the figures above sit beside
+        outs = []
+        t_end = time.perf_counter() + 1.0
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=copier, args=(g, t_end, outs)) for g in range(cores)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        res["memmove_gb_per_s_read_plus_write"] = round(sum(outs) / (time.perf_counter() - t0) / 1e9, 1)
+        res["memmove_threads"] = cores
+        best = max(v["per_busy_thread_gbases_per_s"] for v in res["legs"].values())
+        res["per_core_gbases_per_s"] = best
     finally:
         os.sched_setaffinity(0, aff0)
         state.clear()
@@ -960,7 +998,10 @@ def extra_rates(a, ds, clf, batches, hcov, dcov, dev, stream):
         ex["host_feed"] = host_feed(a, batches)
         one = ex.get("pcie", {}).get("mbases_per_s")
         if one:                                             # what 8 GPUs at the measured single-GPU PCIe-inclusive rate would ask of the host
-            ex["host_feed"]["asked_by_8_gpus_gbases_per_s"] = round(8 * one / 1e3, 1)
+            hf_ = ex["host_feed"]
+            hf_["asked_by_8_gpus_gbases_per_s"] = round(8 * one / 1e3, 1)
+            hf_["asked_by_8_gpus_host_dram_gb_per_s"] = round(8 * one / 1e3 * hf_["dram_bytes_per_base"], 1)
+            hf_["asked_by_8_gpus_packing_cores"] = int(np.ceil(8 * one / 1e3 / max(hf_["per_core_gbases_per_s"], 1e-9)))
     except Exception as e:
         ex["host_feed_error"] = repr(e)[:300]
     if a.only_pcie:
