@@ -19,7 +19,7 @@
  * #includes it as <wall_gslfree.inc> when REF_HAVE_WALL is defined: the reference's own text for find_wall,
  * find_gain/find_drop, correct_wall_cnt, find_rel_intvl and their helpers, no line edited, no stub.
  * `find_wall` takes the Error_Model as a PARAMETER; `ref_wall_setup` fills one from a table the caller hands in
- * (calc_init_thres itself, wall.c:167-243, stays unbuildable: its table is pinned by exact integer arithmetic,
+ * (calc_init_thres itself, wall.c:167-243, calls load_emodel -> GSL and has no reference build: its table is pinned by exact integer arithmetic,
  * tests/test_first_principles.py).
  *
  * The globals below are the ones ClassPro.c:27-32 defines for the unity build.

@@ -1,5 +1,6 @@
-"""Checks of the wall.c restatements (parity-unpinned in this image: wall.c needs GSL to compile) that do not rest on
-anyone's reading of the code: mathematics.
+"""Checks of the restatement of calc_init_thres (wall.c:167-243: parity-unpinned in this image -- it calls load_emodel ->
+load_himodel -> GSL, wall.c:9-165, and GSL is absent; find_wall / find_rel_intvl, wall.c:245-1051, ARE pinned against the
+compiled reference: tests/test_oracle_wall.py) that do not rest on anyone's reading of the code: mathematics.
 
 calc_init_thres (wall.c:167-244) defines, for an error rate pe and an outer count cout,
     cthres[..][cout][s][SELF]   = the smallest cin with P(X > cin) < PE_THRES[s][e],  X ~ Binomial(cout, pe)
