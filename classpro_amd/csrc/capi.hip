@@ -413,14 +413,15 @@ static int launch_prefix_caps(cp_workspace *ws, int64_t *a, int64_t *b, int64_t 
 }
 
 // perm[] = read ids by decreasing key >> shift (kernels.hip: k_order_hist / k_order_scatter)
-static int launch_order_by_work(cp_workspace *ws, const int32_t *key, int n, int shift, int32_t *perm, hipStream_t st)
+static int launch_order_by_work(cp_workspace *ws, const int32_t *key, int n, int shift, int32_t *perm, hipStream_t st,
+                                const int64_t *long_off = nullptr)
 { const size_t c0 = ws->order_tmp.cap;
   ENSURE(ws->order_tmp,(size_t)(2*ORDER_BINS+1)*4);
   if (ws->order_tmp.cap != c0) HIPCHK(hipMemsetAsync(ws->order_tmp.p,0,ws->order_tmp.cap,st));   // zero once: the scatter kernel's last block leaves it zero
   const int blocks = (n+ORDER_TILE-1)/ORDER_TILE;
   int32_t *ghist = (int32_t *)ws->order_tmp.p, *gcur = ghist+ORDER_BINS;
-  hipLaunchKernelGGL(k_order_hist,dim3(blocks),dim3(WAVE),0,st,key,n,shift,ghist);
-  hipLaunchKernelGGL(k_order_scatter,dim3(blocks),dim3(WAVE),0,st,key,n,shift,ghist,gcur,perm);
+  hipLaunchKernelGGL(k_order_hist,dim3(blocks),dim3(WAVE),0,st,key,n,shift,ghist,long_off);
+  hipLaunchKernelGGL(k_order_scatter,dim3(blocks),dim3(WAVE),0,st,key,n,shift,ghist,gcur,perm,long_off);
   HIPCHK(hipGetLastError());
   return CP_OK;
 }
@@ -582,7 +583,7 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   if (last_stage < CP_STAGE_LABELS) HIPCHK(hipMemsetAsync(ws->asgn.p,0xff,(size_t)totalI*2,st));
   // size classes (kernels.hip: REL_SMALL_*): M <= 128 four reads per wave, up to 1024 one read per wave, larger (or a
   // read beyond 65535 k-mers): the sequential kernel
-  rc = launch_order_by_work(ws,(const int32_t *)ws->nrel.p,nreads,0,(int32_t *)ws->perm.p,st);
+  rc = launch_order_by_work(ws,(const int32_t *)ws->nrel.p,nreads,0,(int32_t *)ws->perm.p,st,d_prof_off);
   if (rc != CP_OK) return rc;
   // (the classes touch disjoint reads; the rare classes are a handful of latency-bound waves -- on most batches none at
   //  all, and the sequential kernel's 1024 scratch-using waves still cost 0.9 ms to start -- so they run beside the main
@@ -592,7 +593,7 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   hipLaunchKernelGGL(k_classify_rel,dim3(nreads < 1024 ? nreads : 1024),dim3(WAVE),0,ws->aux,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->parent.p,(int32_t *)ws->eff.p,
-                     (uint8_t *)ws->rpos.p,(int8_t *)ws->asgn.p,totalI);
+                     (uint8_t *)ws->rpos.p,(int8_t *)ws->asgn.p,totalI,(const int32_t *)ws->perm.p);
   hipLaunchKernelGGL((k_classify_rel_grp<REL_SMALL_MAXM,1024,1,1>),dim3(nreads < 2048 ? nreads : 2048),dim3(WAVE),0,ws->aux,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI,(const int32_t *)ws->perm.p);
@@ -610,20 +611,20 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   ENSURE(ws->ord,(size_t)totalI*4);
   // size classes (kernels.hip: UNREL_SMALL_*): N <= 256 and up to 1024, two reads per wave each (four speculative update
   // slots per read), larger: the sequential kernel; the rare classes on the auxiliary stream again
-  rc = launch_order_by_work(ws,(const int32_t *)ws->nintvl.p,nreads,0,(int32_t *)ws->perm.p,st);
+  rc = launch_order_by_work(ws,(const int32_t *)ws->nintvl.p,nreads,0,(int32_t *)ws->perm.p,st,d_prof_off);
   if (rc != CP_OK) return rc;
   HIPCHK(hipEventRecord(ws->ev_fork,st));
   HIPCHK(hipStreamWaitEvent(ws->aux,ws->ev_fork,0));
   hipLaunchKernelGGL(k_classify_unrel,dim3(nreads < 1024 ? nreads : 1024),dim3(WAVE),0,ws->aux,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
-                     (int32_t *)ws->ord.p);
+                     (int32_t *)ws->ord.p,(const int32_t *)ws->perm.p,d_prof_off);
   hipLaunchKernelGGL((k_classify_unrel_grp<UNREL_SMALL_MAXN,1024,UNREL_BIG_G>),dim3((nreads+UNREL_BIG_G-1)/UNREL_BIG_G < 2048 ? (nreads+UNREL_BIG_G-1)/UNREL_BIG_G : 2048),dim3(WAVE),0,ws->aux,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
-                     (const int32_t *)ws->perm.p);
+                     (const int32_t *)ws->perm.p,d_prof_off);
   HIPCHK(hipEventRecord(ws->ev_join,ws->aux));
   hipLaunchKernelGGL((k_classify_unrel_grp<0,UNREL_SMALL_MAXN,UNREL_SMALL_G>),dim3((nreads+UNREL_SMALL_G-1)/UNREL_SMALL_G),dim3(WAVE),0,st,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
-                     (const int32_t *)ws->perm.p);
+                     (const int32_t *)ws->perm.p,d_prof_off);
   HIPCHK(hipStreamWaitEvent(st,ws->ev_join,0));
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_CLASS_ALL)

@@ -335,16 +335,25 @@ k_prefix_caps_mb(int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t *__re
 // histogram into bin starts (every block for itself: 1024 values), reserves, per block and non-empty bin, a range of
 // the bin with ONE global atomic, and places its reads there.  `ghist` and `gcur` (ORDER_BINS ints each, adjacent, a
 // counter of finished blocks behind them) are zero on entry: the last block of the previous sort cleared them.
+// `long_off` (the reads' profile offsets, or NULL): a read of more than GRP_MAX_PLEN k-mers goes to the top bin whatever
+// its key -- the sequential classify kernels, which take such reads and the reads with key > 1024, then find their whole
+// class at the front of `perm` (order_top_bin) and stop at the first read of a lower bin.
+__device__ __forceinline__ int order_bin(const int32_t *__restrict__ key, int i, int shift, const int64_t *__restrict__ long_off)
+{ int b = key[i] >> shift;
+  if (b >= ORDER_BINS) b = ORDER_BINS-1;
+  if (long_off && long_off[i+1]-long_off[i] > GRP_MAX_PLEN && key[i] > 0) b = ORDER_BINS-1;
+  return b;
+}
+
 __global__ void __launch_bounds__(WAVE)
-k_order_hist(const int32_t *__restrict__ key, int n, int shift, int32_t *__restrict__ ghist)
+k_order_hist(const int32_t *__restrict__ key, int n, int shift, int32_t *__restrict__ ghist, const int64_t *__restrict__ long_off)
 { __shared__ int hist[ORDER_BINS];
   const int t = threadIdx.x, i0 = blockIdx.x*ORDER_TILE;
   for (int k = t; k < ORDER_BINS; k += WAVE) hist[k] = 0;
   __syncthreads();
   for (int i = i0+t; i < i0+ORDER_TILE && i < n; i += WAVE)
-    { const int b = key[i] >> shift;
-      atomicAdd(&hist[b < ORDER_BINS ? b : ORDER_BINS-1],1);
-    }
+    atomicAdd(&hist[order_bin(key,i,shift,long_off)],1);
+
   __syncthreads();
   for (int k = t; k < ORDER_BINS; k += WAVE)
     if (hist[k]) atomicAdd(&ghist[k],hist[k]);
@@ -352,7 +361,7 @@ k_order_hist(const int32_t *__restrict__ key, int n, int shift, int32_t *__restr
 
 __global__ void __launch_bounds__(WAVE)
 k_order_scatter(const int32_t *__restrict__ key, int n, int shift, int32_t *__restrict__ ghist, int32_t *__restrict__ gcur,
-                int32_t *__restrict__ perm)
+                int32_t *__restrict__ perm, const int64_t *__restrict__ long_off)
 { __shared__ int hist[ORDER_BINS];                        // this block's count per bin, then its cursor inside the bin
   __shared__ int start[ORDER_BINS];
   const int t = threadIdx.x, i0 = blockIdx.x*ORDER_TILE;
@@ -374,8 +383,7 @@ k_order_scatter(const int32_t *__restrict__ key, int n, int shift, int32_t *__re
     { const int i = i0+t+WAVE*k;
       b[k] = -1; r[k] = 0;
       if (i < n)
-        { int q = key[i] >> shift;
-          if (q >= ORDER_BINS) q = ORDER_BINS-1;
+        { const int q = order_bin(key,i,shift,long_off);
           b[k] = q;
           r[k] = atomicAdd(&hist[q],1);                   // rank inside this block's share of the bin
         }
@@ -1604,12 +1612,19 @@ k_classify_rel(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ 
                cp_intvl *__restrict__ intvl_all, cp_intvl *__restrict__ rintvl_all, const int32_t *__restrict__ relmap_all,
                const int64_t *__restrict__ ioff, const int32_t *__restrict__ nrel,
                int8_t *__restrict__ parent_all, int32_t *__restrict__ eff_all, uint8_t *__restrict__ rpos_all,
-               int8_t *__restrict__ asgn_all, int64_t totalI)
+               int8_t *__restrict__ asgn_all, int64_t totalI, const int32_t *__restrict__ perm)
 { const int lane = lane_id();
-  for (int r = blockIdx.x; r < nreads; r += gridDim.x)     // few reads need this kernel: a small grid strides over the batch
+  // Few reads need this kernel, on most batches none.  `perm` lists the reads by decreasing M with the reads beyond
+  // GRP_MAX_PLEN k-mers in the top bin as well (order_bin): the class is inside the top bin, at the front of the list,
+  // and a wave leaves at its first read of a lower bin -- after two loads when the class is empty.  (Until round 5
+  // every wave strode over the whole batch, three dependent cold loads per read: 0.3-0.5 ms of 1024 waves holding half
+  // of every SIMD's registers beside the main class.)
+  for (int i = blockIdx.x; i < nreads; i += gridDim.x)
   {
+  const int r = perm[i];
   const int M = nrel[r];
   const int plen = (int)(prof_off[r+1]-prof_off[r]);
+  if (M < ORDER_BINS-1 && plen <= GRP_MAX_PLEN) break;               // below the top bin: nothing of this class from here on
   if (M == 0 || (M <= REL_MAXM && plen <= GRP_MAX_PLEN)) continue;   // other reads: k_classify_rel_grp
   const int64_t o = ioff[r];
   cp_intvl *rintvl = rintvl_all+o;
@@ -1667,13 +1682,16 @@ k_classify_rel(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ 
 __global__ void __launch_bounds__(WAVE)
 k_classify_unrel(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__restrict__ intvl_all,
                  const int64_t *__restrict__ ioff, const int32_t *__restrict__ nintvl,
-                 int32_t *__restrict__ ord_all)
+                 int32_t *__restrict__ ord_all, const int32_t *__restrict__ perm, const int64_t *__restrict__ prof_off)
 { const int lane = lane_id();
-  for (int r = blockIdx.x; r < nreads; r += gridDim.x)     // few reads need this kernel: a small grid strides over the batch
+  for (int i = blockIdx.x; i < nreads; i += gridDim.x)     // the class is at the front of `perm`: see k_classify_rel
   {
+  const int r = perm[i];
   const int N = nintvl[r];
+  const int plen = (int)(prof_off[r+1]-prof_off[r]);
+  if (N < ORDER_BINS-1 && plen <= GRP_MAX_PLEN) break;
   cp_intvl *intvl = intvl_all+ioff[r];
-  if (N == 0 || (N <= UNREL_MAXN && intvl[N-1].e <= GRP_MAX_PLEN)) continue;   // other reads: k_classify_unrel_grp (the last interval ends at plen)
+  if (N == 0 || (N <= UNREL_MAXN && plen <= GRP_MAX_PLEN)) continue;   // other reads: k_classify_unrel_grp (the last interval ends at plen)
   int32_t *ord = ord_all+ioff[r];
   for (int k = lane; k < N; k += WAVE)                   // ord[rank] = index | fixed<<31
     { const cp_intvl I = intvl[k];
@@ -2089,9 +2107,10 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
   const int slot = blk*G+g;
   const int r = (slot < nreads) ? perm[slot] : nreads;
   int M = (r < nreads) ? nrel[r] : 0;
-  if (MINM > 0 && __ballot(M > MINM) == 0) break;
   const int rr = (r < nreads) ? r : 0;
   const int plen = (int)(prof_off[rr+1]-prof_off[rr]);
+  // (the reads beyond GRP_MAX_PLEN k-mers sit in the top bin whatever their M -- order_bin -- and are no reason to stop)
+  if (MINM > 0 && __ballot(M > MINM || (r < nreads && plen > GRP_MAX_PLEN)) == 0) break;
   if (M <= MINM || M > MAXM || plen > GRP_MAX_PLEN) M = 0; // other size classes / sequential kernel
   if (__ballot(M > 0) == 0) continue;
   const int64_t o = ioff[rr];
@@ -2214,7 +2233,7 @@ template <int MINN, int MAXN, int G>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(UNREL_WAVES_PER_EU)))
 k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__restrict__ intvl_all,
                      const int64_t *__restrict__ ioff, const int32_t *__restrict__ nintvl,
-                     const int32_t *__restrict__ perm)
+                     const int32_t *__restrict__ perm, const int64_t *__restrict__ prof_off)
 { __shared__ unrel_grp_lds<MAXN,G> S;
   constexpr int L = WAVE/G;
   static_assert(L >= 8 && (L % 8) == 0, "8 role lanes per read");
@@ -2225,10 +2244,12 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
   const int slot = blk*G+g;
   const int r = (slot < nreads) ? perm[slot] : nreads;
   int N = (r < nreads) ? nintvl[r] : 0;
-  if (MINN > 0 && __ballot(N > MINN) == 0) break;
-  const int64_t io = ioff[(r < nreads) ? r : 0];
+  const int rr = (r < nreads) ? r : 0;
+  const bool too_long = prof_off[rr+1]-prof_off[rr] > GRP_MAX_PLEN;  // (the last interval ends at plen)
+  if (MINN > 0 && __ballot(N > MINN || (r < nreads && too_long)) == 0) break;     // (long reads: in the top bin whatever their N)
+  const int64_t io = ioff[rr];
   cp_intvl *intvl = intvl_all+io;
-  if (N <= MINN || N > MAXN || intvl[N-1].e > GRP_MAX_PLEN) N = 0;   // other size classes / sequential kernel
+  if (N <= MINN || N > MAXN || too_long) N = 0;            // other size classes / sequential kernel
   if (__ballot(N > 0) == 0) continue;
   const int nwords = (N+63) >> 6;
   const int REP = P->cov[CP_REPEAT];

@@ -30,6 +30,30 @@ __global__ void __launch_bounds__(256) k_copy(const float4 *__restrict__ a, floa
     b[i] = a[i];
 }
 
+// the same with non-temporal loads (what k_scan_candidates issues: SCAN_LOAD)
+template <int UNROLL>
+__global__ void __launch_bounds__(256) k_read_nt(const uint4 *__restrict__ p, int64_t n, unsigned *__restrict__ out)
+{ const int lane = threadIdx.x & 63;
+  const int64_t nthreads = (int64_t)gridDim.x*blockDim.x, nwaves = nthreads/64;
+  const int64_t wid = ((int64_t)blockIdx.x*blockDim.x+threadIdx.x)/64, wavesz = 64*UNROLL;
+  unsigned acc = 0;
+  for (int64_t base = wid*wavesz; base < n; base += nwaves*wavesz)
+    { unsigned x[UNROLL][4];
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++)
+        { const int64_t g = base+(int64_t)u*64+lane;
+          const unsigned *q = reinterpret_cast<const unsigned *>(&p[g < n ? g : 0]);
+          typedef unsigned u4v __attribute__((ext_vector_type(4)));
+          const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(q));
+          x[u][0] = v.x; x[u][1] = v.y; x[u][2] = v.z; x[u][3] = v.w;
+        }
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++)
+        acc ^= x[u][0] ^ x[u][1] ^ x[u][2] ^ x[u][3];
+    }
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
 template <class F> float time_ms(F f, int iters)
 { hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   f(); (void)hipDeviceSynchronize();
@@ -54,6 +78,19 @@ int main()
   for (int blocks : { 2048, 8192 })
     { float a = time_ms([&] { hipLaunchKernelGGL(k_copy,dim3(blocks),dim3(256),0,0,(const float4 *)p,q,n); },20);
       printf("float4 copy, %5d blocks: %.1f GB/s read + the same written (%.1f GB/s total)\n",blocks,bytes/a/1e6,2*bytes/a/1e6);
+    }
+  // round 5: the ceiling the scan kernel's roofline fraction should be read against -- a 4-GB buffer (one bench launch
+  // streams 4.0 GB; 16x the 256-MiB Infinity Cache), read-only, 16 B per lane, plain and non-temporal loads
+  (void)hipFree(p); (void)hipFree(q);
+  const int64_t big = (int64_t)4 << 30, nb = big/16;
+  (void)hipMalloc(&p,big);
+  (void)hipMemset(p,1,big);
+  for (int blocks : { 1024, 2048, 4096, 8192, 16384 })
+    { float a = time_ms([&] { hipLaunchKernelGGL(k_read<4>,dim3(blocks),dim3(256),0,0,p,nb,out); },10);
+      float b = time_ms([&] { hipLaunchKernelGGL(k_read_nt<4>,dim3(blocks),dim3(256),0,0,p,nb,out); },10);
+      float c = time_ms([&] { hipLaunchKernelGGL(k_read_nt<8>,dim3(blocks),dim3(256),0,0,p,nb,out); },10);
+      printf("4 GB read-only, %5d blocks: plain unroll 4 %.1f GB/s, non-temporal unroll 4 %.1f GB/s, non-temporal unroll 8 %.1f GB/s\n",
+             blocks,big/a/1e6,big/b/1e6,big/c/1e6);
     }
   return 0;
 }
