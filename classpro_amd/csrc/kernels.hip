@@ -58,6 +58,14 @@ __device__ __forceinline__ int wave_of_last(int v) { return __builtin_amdgcn_rea
 //  first position of a read compare across a read boundary; consumers skip position 0.
 //  Algorithmic traffic: 2 B read + 1/8 B written per position.  The bitmap buffer has `nbytes` bytes (whole
 //  64-bit words plus one spare word); the bytes after the last group are cleared here.
+//  Round 5, what separates this kernel (5.0-5.4 TB/s) from a read-only kernel of the same access pattern (6.7-7.0 TB/s on
+//  4 GB: scripts/microbench/read_bw.hip, scan_variants.hip; profiles/r05_scan_variants.txt): the flag arithmetic costs
+//  8 % (6.1-6.2 TB/s without the stores) and the bitmap stores -- 1/16 of the bytes -- 16 %: writes interleaved with the
+//  read stream cost HBM efficiency out of proportion to their size, whatever their width (a byte per lane, dwords gathered
+//  by DPP, dwordx4 through LDS) or cache policy; storing one row in 4 / 16 / 64 takes back 50 / 70 / 90 % of the loss.  The
+//  full-width form gained 4 % in the micro-benchmark and nothing on the bench's profiles (779-791 us against 784-788 per
+//  4.0-GB launch, A/B in one call), so the simple form stays.  The bitmap IS the output: a sparser one (candidate lists,
+//  1/8 of the bytes) would buy back about half of the 16 % of a kernel that is 8 % of a step.
 // ---------------------------------------------------------------------------------------------
 typedef unsigned cp_u4v __attribute__((ext_vector_type(4)));
 // The profile is read once and the bitmap written once per batch: both go past the caches as streaming accesses
