@@ -235,10 +235,21 @@ def seeds():
     np.savez_compressed(os.path.join(OUT, "seeds.npz"), **out)
 
 
+MODEL_GROWTH = (0.0004, 0.0005, 0.0006)      # tests/test_error_model.py: flatter than the default model, changes wall decisions
+
+
+def model_path(d):
+    """The synthetic HIsim model of the -M parameter set (classpro_amd.synth.write_himodel is deterministic), written to d."""
+    p = os.path.join(d, "golden_hifi.model")
+    synth.write_himodel(p, growth=MODEL_GROWTH)
+    return p
+
+
 def _param_sets():
-    """(K, -r, H, D) of the wall / label vectors."""
-    return [(40, 20000, 20, 40), (40, 20000, 30, 60), (40, 2000, 20, 40), (21, 20000, 20, 40), (25, 25000, 30, 60),
-            (63, 20000, 12, 25)]
+    """(K, -r, H, D, model) of the wall / label vectors; model = 1: the error model of -M<model_path(...)> instead of the
+    default one (the reference's find_wall takes the model as a parameter; its tables come from the oracle's load + fit)."""
+    return [(40, 20000, 20, 40, 0), (40, 20000, 30, 60, 0), (40, 2000, 20, 40, 0), (21, 20000, 20, 40, 0), (25, 25000, 30, 60, 0),
+            (63, 20000, 12, 25, 0), (40, 20000, 20, 40, 1)]
 
 
 def _edge_cases(K, rng):
@@ -270,7 +281,7 @@ def wall_label_cases(which):
     from adversarial import adversarial_reads, tail_run_reads
     w = which == "wall"
     out = []
-    for si, (K, rl, h, d) in enumerate(_param_sets()):
+    for si, (K, rl, h, d, _m) in enumerate(_param_sets()):
         rng = np.random.default_rng(500 + si + (0 if w else 50))
         ds = synth.make_dataset(genome_len=60000, cov=d, read_len=min(rl, 9000) if w else min(rl, 14000), K=K,
                                 seed=(60 if w else 160) + si, het=0.004 if si % 2 else 0.001, n_repeats=6)
@@ -280,10 +291,10 @@ def wall_label_cases(which):
         out += [(si, s_, p_) for s_, p_ in zip(S, P)]
         S, P = tail_run_reads((21 if w else 31) + si, n=(24 if w else 24), K=K)
         out += [(si, s_, p_) for s_, p_ in zip(S, P)]
-        if si in (0, 3, 5):
+        if si in (0, 3, 5, 6):
             out += [(si, s_, p_) for s_, p_ in _edge_cases(K, rng)]
         AL = np.frombuffer(b"ACGT", np.uint8)                 # tiny reads with jumping counts: about a fifth of them
-        for it in range(30 if si in (0, 3, 5) else 9):         # end in the reference's exit(1) ("# E-intvls >= plen")
+        for it in range(30 if si in (0, 3, 5, 6) else 9):         # end in the reference's exit(1) ("# E-intvls >= plen")
             plen = int(rng.integers(1, 12)); rlen = plen + K - 1
             seq = [bytes(AL[rng.integers(0, 4, rlen)]), b"A" * rlen, (b"AC" * rlen)[:rlen]][it % 3]
             out.append((si, seq, rng.choice([1, 2, 5, 20, 40, 80, 300], plen).astype(np.uint16)))
@@ -293,7 +304,8 @@ def wall_label_cases(which):
 def _tables(psets):
     """Per parameter set the threshold tables find_wall gets (from the oracle; checked entry by entry with exact integer
     arithmetic in tests/test_first_principles.py) -- stored so the tests can see that the product uses the same ones."""
-    O = [Oracle(K, rl, h, d) for K, rl, h, d in psets]
+    td = tempfile.mkdtemp()
+    O = [Oracle(K, rl, h, d, model=(model_path(td) if m else None)) for K, rl, h, d, m in psets]
     return O, dict(psets=np.array(psets, np.int32),
                    cthres=np.stack([o.cthres() for o in O]), pe=np.stack([o.pe() for o in O]),
                    lmax=np.stack([o.lmax() for o in O]),
@@ -301,7 +313,7 @@ def _tables(psets):
 
 
 def _refs(psets, O):
-    return [Ref(rl, h, d).wall_setup_from(o) for (K, rl, h, d), o in zip(psets, O)]
+    return [Ref(rl, h, d).wall_setup_from(o) for (K, rl, h, d, m), o in zip(psets, O)]
 
 
 def wall():

@@ -29,6 +29,15 @@ void *hh_params_new(int K, int read_len, int hcov, int dcov)
   if (cp_host_fill_params(P,K,read_len,hcov,dcov) != CP_OK) { free(P); return NULL; }
   return P;
 }
+// -M<model_path>: the product's own loader + fit (cp_host_load_himodel), then the same table builder
+void *hh_params_new_model(int K, int read_len, int hcov, int dcov, const char *model_path)
+{ double pe[3][21];
+  char msg[256];
+  if (cp_host_load_himodel(model_path,pe,msg,sizeof(msg)) != CP_OK) return NULL;
+  cp_dev_params *P = (cp_dev_params *)malloc(sizeof(cp_dev_params));
+  if (cp_host_fill_params(P,K,read_len,hcov,dcov,pe) != CP_OK) { free(P); return NULL; }
+  return P;
+}
 void hh_params_free(void *P) { free(P); }
 const unsigned char *hh_params_cthres(void *P) { return &((cp_dev_params *)P)->cthres[0][0][0][0][0]; }
 const double *hh_params_logfact(void *P) { return ((cp_dev_params *)P)->logfact; }

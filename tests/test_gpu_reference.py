@@ -3,7 +3,7 @@
 tests/golden/wall.npz: per read the reference's find_wall + find_rel_intvl output (wall.c:570-958, 960-1051, the GSL-free
 part of wall.c compiled as it stands; oracle/gen_golden.py).  tests/golden/labels.npz: label strings and interval classes
 of whole reads through context.c -> wall.c -> class_rel.c -> class_unrel.c -> paint (ClassPro.c:229-271).  K = 21 / 25 /
-40 / 63, -r 2 000 - 25 000, coverages (12,25) - (30,60); generated, adversarial, tail-run, edge and tiny reads; the reads
+40 / 63, -r 2 000 - 25 000, coverages (12,25) - (30,60), one set under a -M error model; generated, adversarial, tail-run, edge and tiny reads; the reads
 on which the reference exit(1)s ("# E-intvls >= plen") must raise CP_EOVERFLOW, each on its own.
 Bar: bit-exact, the three doubles of a record included.
 """
@@ -33,9 +33,16 @@ def reads_of_set(g, si):
 
 def classifier_for(g, si):
     """A Classifier for parameter set si whose tables are the ones the reference's find_wall was handed."""
+    import os
+    import tempfile
+    from classpro_amd import synth
     from classpro_amd.api import Classifier
-    K, rl, h, d = (int(x) for x in g["psets"][si])
-    clf = Classifier(K, rl, h, d)
+    K, rl, h, d, m = (int(x) for x in g["psets"][si])
+    model = None
+    if m:                                                   # the -M set: the same synthetic HIsim model file, made here again
+        model = os.path.join(tempfile.mkdtemp(), "golden_hifi.model")
+        synth.write_himodel(model, growth=(0.0004, 0.0005, 0.0006))
+    clf = Classifier(K, rl, h, d, model=model)
     ex = clf.export()
     assert np.array_equal(ex["cthres"], g["cthres"][si]) and np.array_equal(ex["pe"], g["pe"][si])
     assert ex["cmax"] == g["cmax"][si] and ex["hc_erate"] == g["hc_erate"][si]
@@ -51,7 +58,7 @@ def assert_aborts(clf, seqs, profs):
         assert ei.value.code == -5                          # CP_EOVERFLOW = the reference's exit(1)
 
 
-@pytest.mark.parametrize("si", range(6))
+@pytest.mark.parametrize("si", range(7))
 def test_wall_and_rel_stage_against_reference_records(torch_dev, si):
     from classpro_amd.api import Batch, STAGE_WALL, STAGE_REL
     from oracle.oracle import INTVL_DTYPE
@@ -96,7 +103,7 @@ def test_wall_and_rel_stage_against_reference_records(torch_dev, si):
     clf.close()
 
 
-@pytest.mark.parametrize("si", range(6))
+@pytest.mark.parametrize("si", range(7))
 def test_labels_against_reference_text_only(torch_dev, si):
     from classpro_amd.api import Batch, STAGE_CLASS_ALL
     g = load_golden("labels.npz")

@@ -10,6 +10,8 @@ which the reference's `#define DEBUG` abort fires ("# E-intvls >= plen").  Check
 The -m gpu twin is tests/test_gpu_reference.py.
 """
 import ctypes as C
+import os
+import tempfile
 
 import numpy as np
 import pytest
@@ -21,6 +23,14 @@ from classpro_amd import synth
 
 INT_FIELDS = ("b", "e", "cb", "ce", "ccb", "cce", "is_rel")
 DBL_FIELDS = ("pe", "peo_b", "peo_e")
+MODEL_GROWTH = (0.0004, 0.0005, 0.0006)      # oracle/gen_golden.py: the -M parameter set's synthetic HIsim model
+
+
+def golden_model(d):
+    p = os.path.join(d, "golden_hifi.model")
+    if not os.path.exists(p):
+        synth.write_himodel(p, growth=MODEL_GROWTH)
+    return p
 
 
 def same_records(a, b, fields=INT_FIELDS):
@@ -39,8 +49,9 @@ def golden_reads(g):
 
 def oracles_for(g):
     out = []
-    for k, (K, rl, h, d) in enumerate(g["psets"]):
-        O = Oracle(int(K), int(rl), int(h), int(d))
+    td = tempfile.mkdtemp()
+    for k, (K, rl, h, d, m) in enumerate(g["psets"]):
+        O = Oracle(int(K), int(rl), int(h), int(d), model=(golden_model(td) if m else None))
         # the tables the reference's find_wall was given are the oracle's (and, test_gpu_reference.py, the product's)
         assert np.array_equal(O.cthres(), g["cthres"][k]) and np.array_equal(O.pe(), g["pe"][k])
         assert np.array_equal(O.lmax(), g["lmax"][k]) and O.scalars()[2] == g["cmax"][k] and O.scalars()[3] == g["hc_erate"][k]
@@ -98,10 +109,13 @@ def test_product_host_functions_against_reference_labels(harness):
     g = load_golden("labels.npz")
     lo, ao = g["labels_off"], g["asgn_off"]
     P = {}
+    td = tempfile.mkdtemp()
     for i, si, status, s, p in golden_reads(g):
         if si not in P:
-            K, rl, h, d = (int(x) for x in g["psets"][si])
-            P[si] = harness.hh_params_new(K, rl, h, d)
+            K, rl, h, d, m = (int(x) for x in g["psets"][si])
+            harness.hh_params_new_model.restype = C.c_void_p
+            P[si] = (harness.hh_params_new_model(K, rl, h, d, golden_model(td).encode()) if m else harness.hh_params_new(K, rl, h, d))
+            assert P[si]
         N, lab, iv, *_ = run_harness_read(harness, P[si], s, p)
         if status == 1:
             assert N < 0, i                                 # the product reports the reference's abort
