@@ -57,9 +57,9 @@ def parse():
                     help="a rank's share is resident in HBM in windows of at most this many Gbases (4 B of HBM per base + workspace)")
     ap.add_argument("--cov", type=int, default=40)
     ap.add_argument("--read-len", type=int, default=20000)
-    ap.add_argument("--batch-mbases", type=float, default=2100.0,
-                    help="sub-batch size of one cp_classify_batch call (2-Gbase sub-batches: 194 against 191 Gbases/s with 1-Gbase ones, for 44 GB "
-                         "of workspace instead of 22 -- of 288)")
+    ap.add_argument("--batch-mbases", type=float, default=4100.0,
+                    help="sub-batch size of one cp_classify_batch call: 4-Gbase sub-batches (one per stream and step on the 8-Gbase set) 204.0-204.3 "
+                         "Gbases/s, 2-Gbase ones 201.8-202.5, 1.4-Gbase ones 199.8-200.4 (A/B in one call, round 5), for 89 / 44 / 30 GB of workspace -- of 288")
     ap.add_argument("--streams", type=int, default=2, help="sub-batches alternate over this many streams / workspaces")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--seed", type=int, default=1)
