@@ -14,7 +14,7 @@ SYMBOLS = [
     "cp_params_export", "cp_decode_profile", "cp_workspace_create", "cp_workspace_destroy",
     "cp_workspace_bytes", "cp_classify_batch", "cp_workspace_check", "cp_run_stages", "cp_get_counts",
     "cp_get_intervals", "cp_get_rel_asgn", "cp_get_bitmap", "cp_seq_context", "cp_scan_candidates",
-    "cp_encode_profile", "cp_decode_profiles", "cp_params_create_model", "cp_load_error_model", "cp_unpack_bases",
+    "cp_encode_profile", "cp_decode_profiles", "cp_params_create_model", "cp_params_create_pe", "cp_load_error_model", "cp_unpack_bases",
     "cp_find_seeds_batch", "cp_get_rep_masks", "cp_rep_masks_capacity", "cp_params_tables", "cp_pack_bases", "cp_pack_labels", "cp_unpack_labels", "cp_math_eval", "cp_pack_bases_batch",
     "cp_label_runs", "cp_label_runs_capacity", "cp_expand_label_runs",
 ]
@@ -51,6 +51,7 @@ def lib():
     L.cp_params_create.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
     L.cp_params_create_model.argtypes = [i32, i32, i32, i32, C.c_char_p, C.POINTER(vp)]
     L.cp_load_error_model.argtypes = [C.c_char_p, vp]
+    L.cp_params_create_pe.argtypes = [i32, i32, i32, i32, vp, C.POINTER(vp)]
     L.cp_params_destroy.argtypes = [vp]
     L.cp_params_destroy.restype = None
     L.cp_params_export.argtypes = [vp] + [vp] * 7

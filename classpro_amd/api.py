@@ -145,7 +145,7 @@ class Batch:
 class Classifier:
     """Global setup (ClassPro.c:536-554) + batched hot path."""
 
-    def __init__(self, K=40, read_len=20000, hcov=20, dcov=40, device="cuda:0", model=None):
+    def __init__(self, K=40, read_len=20000, hcov=20, dcov=40, device="cuda:0", model=None, pe=None):
         self.L = lib()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -153,7 +153,11 @@ class Classifier:
         torch.cuda.set_device(self.device)
         self.K, self.read_len = K, read_len
         p = C.c_void_p()
-        check(self.L.cp_params_create_model(K, read_len, hcov, dcov, model.encode() if model else None, C.byref(p)))
+        if pe is not None:                                  # the error model as a table (cp_params_create_pe)
+            pe = np.ascontiguousarray(pe, np.float64).reshape(3, 21)
+            check(self.L.cp_params_create_pe(K, read_len, hcov, dcov, pe.ctypes.data, C.byref(p)))
+        else:
+            check(self.L.cp_params_create_model(K, read_len, hcov, dcov, model.encode() if model else None, C.byref(p)))
         self.p = p
         w = C.c_void_p()
         check(self.L.cp_workspace_create(C.byref(w)))

@@ -110,6 +110,8 @@ extern "C" int cp_load_error_model(const char *model_path, double *pe63)
   return CP_OK;
 }
 
+static int params_create(int K, int read_len, int hcov, int dcov, const double (*pe)[21], cp_params **out);
+
 extern "C" int cp_params_create_model(int K, int read_len, int hcov, int dcov, const char *model_path, cp_params **out)
 { if (!out) return set_err(CP_EINVAL,"cp_params_create: null out");
   double pe[3][21];
@@ -119,9 +121,27 @@ extern "C" int cp_params_create_model(int K, int read_len, int hcov, int dcov, c
       int rc = cp_host_load_himodel(model_path,pe,msg,sizeof(msg));
       if (rc != CP_OK) return set_err(rc,msg);
     }
-  cp_params *p = (cp_params *)malloc(sizeof(cp_params));
+  return params_create(K,read_len,hcov,dcov,model_path ? pe : nullptr,out);
+}
+
+// The error model as a table: pe63 = double[3][21], rows HP / DS / TS, pe[t][l] for l = 1 .. MAX_N_LC/(t+1) (entry 0 and
+// the entries beyond are ignored).  For a caller that has the rates already -- the reference's own load_himodel with its GSL
+// fit, or cp_load_error_model -- and for tests that hand the reference's find_wall and this library the same table.
+extern "C" int cp_params_create_pe(int K, int read_len, int hcov, int dcov, const double *pe63, cp_params **out)
+{ if (!out || !pe63) return set_err(CP_EINVAL,"cp_params_create_pe: null argument");
+  double pe[3][21];
+  memcpy(pe,pe63,sizeof(pe));
+  for (int t = 0; t < 3; t++)
+    for (int l = 1; l <= 20/(t+1); l++)
+      if (!(pe[t][l] > 0.) || !(pe[t][l] < 1.))
+        return set_err(CP_EINVAL,"cp_params_create_pe: error rates must lie in (0,1)");
+  return params_create(K,read_len,hcov,dcov,pe,out);
+}
+
+static int params_create(int K, int read_len, int hcov, int dcov, const double (*pe)[21], cp_params **out)
+{ cp_params *p = (cp_params *)malloc(sizeof(cp_params));
   if (!p) return set_err(CP_ENOMEM,"cp_params_create: out of memory");
-  int rc = cp_host_fill_params(&p->host,K,read_len,hcov,dcov,model_path ? pe : nullptr);
+  int rc = cp_host_fill_params(&p->host,K,read_len,hcov,dcov,pe);
   if (rc != CP_OK)
     { char buf[128];
       if (rc == CP_ERCOV) snprintf(buf,sizeof(buf),"Too high REPEAT coverage (%d) > 255",p->host.cov[CP_REPEAT]);

@@ -89,6 +89,11 @@ int  cp_params_create(int K, int read_len, int hcov, int dcov, cp_params **out);
  * (pe63 = double[3][21], rows HP/DS/TS). */
 int  cp_params_create_model(int K, int read_len, int hcov, int dcov, const char *model_path, cp_params **out);
 int  cp_load_error_model(const char *model_path, double *pe63);
+/* The error model handed in as a table (pe63 = double[3][21], rows HP / DS / TS; entries l = 1 .. 20/(t+1) are used and
+ * must lie in (0,1)): for a caller that has the rates already -- e.g. the reference's own load_himodel (wall.c:55-115) with
+ * its GSL fit, when bit-identity with THAT fit is wanted -- or from cp_load_error_model.  find_wall (wall.c:570) takes the
+ * Error_Model as a parameter in the reference too. */
+int  cp_params_create_pe(int K, int read_len, int hcov, int dcov, const double *pe63, cp_params **out);
 void cp_params_destroy(cp_params *p);
 /* Device bytes of the look-up tables this cp_params uses (0 = that table is not in use: its values are
  * computed on the spot).  skel_bytes counts the logp_trans table AND, when present, the table of its exponentials
