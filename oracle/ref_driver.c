@@ -468,7 +468,7 @@ int ref_classify_batch(const char *seq, const long long *seq_off, const unsigned
 { if (!g_emodel_set) return -1;
   if (rlen_max <= 0) rlen_max = MAX_READ_LEN;
   for (int i = 0; i < nreads; i++)
-    if (seq_off[i+1]-seq_off[i] > rlen_max-1) return -2;
+    if (seq_off[i+1]-seq_off[i] > rlen_max) return -2;               /* ClassPro.c:184: rlen > MAX_READ_LEN is the reference's error */
   if (nthreads < 1) nthreads = 1;
   if (nthreads > nreads && nreads > 0) nthreads = nreads;
   pthread_t *th = Malloc(sizeof(pthread_t)*nthreads,"th");
