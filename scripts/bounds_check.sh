@@ -5,5 +5,5 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/bounds; rm -rf $O; mkdir -p $O
 export CLASSPRO_AMD_LIB=$GRAFT_REPO_ROOT/build_diag/lib_bounds.so CP_BOUNDS_REPORT=$GRAFT_REPO_ROOT/$O/report.txt
-timeout -k 10 1000 python -m pytest tests/test_gpu_parity.py tests/test_gpu_neighbours.py tests/test_gpu_seeds.py tests/test_gpu_pack.py -x -q -k "not cli and not config2_full" > $O/pytest.log 2>&1
+timeout -k 10 1000 python -m pytest tests/test_gpu_parity.py tests/test_gpu_neighbours.py tests/test_gpu_seeds.py tests/test_gpu_pack.py tests/test_gpu_reference.py -x -q -k "not cli and not config2_full" > $O/pytest.log 2>&1
 echo "pytest rc=$?"; tail -3 $O/pytest.log; cat $O/report.txt
