@@ -325,12 +325,21 @@ def main():
         # ---- roofline of the profile-scan kernel: HIP events on the launch stream; every launch streams one
         #      sub-batch's profile (1.6 GB at the default size), the whole resident set (16 GB >> the 256 MiB
         #      Infinity Cache) in rotation ----------------------------------------------------------------------
-        bms = [torch.zeros(b.total_kmers // 64 + 2, dtype=torch.int64, device=dev) for _, b in batches]
-        reps = max(1, 200 // len(batches))
+        # (the library scans a batch in kernel launches of at most 2^31 positions -- capi.hip: launch_scan -- and so does this
+        #  loop: one cp_scan_candidates call per such piece, i.e. per kernel launch)
+        chunk = 1 << 31
+        if os.environ.get("CLASSPRO_SCAN_CHUNK_KMERS"):
+            chunk = max(4096, int(os.environ["CLASSPRO_SCAN_CHUNK_KMERS"]) & ~4095)
+        pieces = []
+        for _, b in batches:
+            for p0 in range(0, max(b.total_kmers, 1), chunk):
+                n = min(chunk, b.total_kmers - p0)
+                pieces.append((b.prof.data_ptr() + 2 * p0, n, torch.zeros(n // 64 + 2, dtype=torch.int64, device=dev)))
+        reps = max(1, 200 // len(pieces))
 
         def scan_all():
-            for (_, b), bm in zip(batches, bms):
-                check(L.cp_scan_candidates(clf.p, b.prof.data_ptr(), b.total_kmers, bm.data_ptr(), stream))
+            for ptr, n, bm in pieces:
+                check(L.cp_scan_candidates(clf.p, ptr, n, bm.data_ptr(), stream))
         scan_all()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(dev))
@@ -338,11 +347,11 @@ def main():
             scan_all()
         e1.record(torch.cuda.current_stream(dev))
         torch.cuda.synchronize()
-        nlaunch = reps * len(batches)
+        nlaunch = reps * len(pieces)
         scan_ms = e0.elapsed_time(e1) / nlaunch
-        alg_bytes = 2.0 * win_kmers / len(batches)      # 2 B (uint16 count) per position; average launch
+        alg_bytes = 2.0 * win_kmers / len(pieces)       # 2 B (uint16 count) per position; average launch
         achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
-        del bms
+        del pieces
         traffic, traffic_src = None, None
         pmc = os.path.join(_ROOT, "profiles", "scan_pmc.json")
         if os.path.exists(pmc):

@@ -99,8 +99,10 @@ __device__ __forceinline__ unsigned scan_pair_flags(unsigned prevcur, unsigned c
 }
 
 __global__ void __launch_bounds__(256)
-k_scan_candidates(const uint16_t *__restrict__ prof, int64_t total, int rep, uint8_t *__restrict__ bitmap, int64_t nbytes)
-{ const int64_t ngroups = total >> 3;                   // full groups of 8 positions
+k_scan_candidates(const uint16_t *__restrict__ prof, int64_t total, int rep, uint8_t *__restrict__ bitmap, int64_t nbytes, int has_prev)
+{ // has_prev: this launch continues a profile (capi.hip: launch_scan cuts a batch into launches of at most 2^31
+  // positions): the count before its first position is prof[-1], as it would be inside a single launch
+  const int64_t ngroups = total >> 3;                   // full groups of 8 positions
   const int64_t nthreads = (int64_t)gridDim.x*blockDim.x;
   const int lane = lane_id();
   const uint4 *vp = reinterpret_cast<const uint4 *>(prof);
@@ -121,7 +123,7 @@ k_scan_candidates(const uint16_t *__restrict__ prof, int64_t total, int rep, uin
         }
       unsigned carry = 0;
       if (lane == 0)
-        carry = (base > 0) ? prof[base*8-1] : (v[0].x & 0xffff);
+        carry = (base > 0 || has_prev) ? prof[base*8-1] : (v[0].x & 0xffff);
 #pragma unroll
       for (int u = 0; u < SCAN_UNROLL; u++)
         { const bool live = g[u] < ngroups;
@@ -158,7 +160,7 @@ k_scan_candidates(const uint16_t *__restrict__ prof, int64_t total, int rep, uin
           unsigned last = v[u].w >> 16;                 // count at 8g+7
           unsigned prev = __shfl_up(last,1);            // all lanes take part
           if (lane == 0 && live)
-            prev = (g[u] > 0) ? prof[g[u]*8-1] : (v[u].x & 0xffff);
+            prev = (g[u] > 0 || has_prev) ? prof[g[u]*8-1] : (v[u].x & 0xffff);
           unsigned c[8] = { v[u].x & 0xffff, v[u].x >> 16, v[u].y & 0xffff, v[u].y >> 16,
                             v[u].z & 0xffff, v[u].z >> 16, v[u].w & 0xffff, v[u].w >> 16 };
           unsigned bits = 0;
@@ -181,7 +183,7 @@ k_scan_candidates(const uint16_t *__restrict__ prof, int64_t total, int rep, uin
       if (p0 < total)
         { unsigned bits = 0;
           for (int64_t p = p0; p < total; p++)
-            if (p > 0)
+            if (p > 0 || has_prev)
               { unsigned a = prof[p-1], b = prof[p];
                 unsigned mn = a < b ? a : b, df = a < b ? b-a : a-b;
                 if (mn < (unsigned)rep && df >= CP_MIN_CNT_CHANGE) bits |= 1u << (p-p0);

@@ -49,6 +49,34 @@ def close(a, b):
     return np.array_equal(np.isfinite(a), fin) and np.array_equal(a[~fin], b[~fin]) and np.allclose(a[fin], b[fin], rtol=FLOAT_RTOL, atol=0)
 
 
+def test_scan_in_several_launches(torch_dev, ds_a, monkeypatch):
+    """cp_run_stages scans a batch in launches of at most 2^31 positions (capi.hip: launch_scan); a launch that continues a
+    profile takes the count before its first position from the launch before it.  With the launch size set to 4096 and 12288
+    positions (CLASSPRO_SCAN_CHUNK_KMERS) the bitmap of a batch of a few hundred thousand positions -- cut inside reads, at
+    counts that are candidates or not -- equals the single launch's, and so do the labels."""
+    from classpro_amd.api import Classifier, Batch, STAGE_SCAN
+    from classpro_amd import synth
+    ds, h, d = ds_a
+    seq, so, prof, po = synth.pack_batch(ds["seqs"][:60], ds["profiles"][:60])
+    clf = Classifier(K, 20000, h, d)
+    b = Batch(seq, so, prof, po)
+    clf.run(b, STAGE_SCAN)
+    want = clf.bitmap(b).copy()
+    lab = clf.classify(b).copy()
+    assert b.total_kmers > 5 * 12288
+    for chunk in (4096, 12288):
+        monkeypatch.setenv("CLASSPRO_SCAN_CHUNK_KMERS", str(chunk))
+        clf.run(b, STAGE_SCAN)
+        got = clf.bitmap(b)
+        nw = b.total_kmers // 64
+        assert np.array_equal(got[:nw], want[:nw]), chunk
+        assert np.array_equal(np.unpackbits(got.view(np.uint8), bitorder="little")[:b.total_kmers],
+                              np.unpackbits(want.view(np.uint8), bitorder="little")[:b.total_kmers])
+        assert np.array_equal(clf.classify(b), lab)
+    monkeypatch.delenv("CLASSPRO_SCAN_CHUNK_KMERS")
+    clf.close()
+
+
 @pytest.mark.parametrize("which", ["a", "b"])
 def test_stage_parity(torch_dev, ds_a, ds_b, which):
     from classpro_amd.api import (Classifier, Batch, STAGE_SCAN, STAGE_WALL, STAGE_REL, STAGE_CLASS_REL, STAGE_CLASS_ALL)
