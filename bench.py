@@ -61,6 +61,10 @@ def parse():
                     help="sub-batch size of one cp_classify_batch call: 4-Gbase sub-batches (one per stream and step on the 8-Gbase set) 204.0-204.3 "
                          "Gbases/s, 2-Gbase ones 201.8-202.5, 1.4-Gbase ones 199.8-200.4 (A/B in one call, round 5), for 89 / 44 / 30 GB of workspace -- of 288")
     ap.add_argument("--streams", type=int, default=2, help="sub-batches alternate over this many streams / workspaces")
+    ap.add_argument("--issue-threads", type=int, default=1, help="host threads that issue the sub-batches: 1 = one thread alternating over the streams "
+                                                                  "(the default: 204.5-205.6 Gbases/s); 2 = one thread per stream, free-running or staggered by "
+                                                                  "half a sub-batch (199.3-200.2: measured and dropped, round 5)")
+    ap.add_argument("--no-stagger", dest="stagger", action="store_false", help="with a thread per stream: do not start stream k half a sub-batch late")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="target CPU time of each cpu_baseline leg (-T1, -T16, -T<all>)")
@@ -251,12 +255,47 @@ def main():
         ds.check()
         return out
 
+    def call(k, b):
+        check(L.cp_classify_batch(clf.p, wss[k], b.seq.data_ptr(), b.seq_off.data_ptr(), b.prof.data_ptr(),
+                                  b.prof_off.data_ptr(), b.nreads, b.total_bases, b.total_kmers,
+                                  b.labels.data_ptr(), C.c_void_p(streams[k].cuda_stream)))
+
     def step(batches):
         for i, (_, b) in enumerate(batches):
-            k = i % nst
-            check(L.cp_classify_batch(clf.p, wss[k], b.seq.data_ptr(), b.seq_off.data_ptr(), b.prof.data_ptr(),
-                                      b.prof_off.data_ptr(), b.nreads, b.total_bases, b.total_kmers,
-                                      b.labels.data_ptr(), C.c_void_p(streams[k].cuda_stream)))
+            call(i % nst, b)
+
+    def run_steps(batches, nsteps, stagger=0.0):
+        """nsteps passes over the window's sub-batches.  --issue-threads 1 (default): one host thread alternates over the streams;
+        every cp_classify_batch call waits for its sub-batch's head, so the streams end up starting their sub-batches within a
+        head's time of each other and run the same kinds of kernel side by side.  --issue-threads 2: a host thread per stream
+        issues that stream's sub-batches back to back, stream k starting k * `stagger` seconds late (half a sub-batch: one
+        stream's bandwidth-bound scan and paint beside the other's latency-bound kernels).  That was the idea; measured, it
+        loses 2.5 % with or without the stagger (A/B in one call), so it is an option, not the default."""
+        if a.issue_threads <= 1 or nst == 1:
+            for _ in range(nsteps):
+                step(batches)
+            return
+        import threading
+        errs = []
+
+        def worker(k):
+            try:
+                torch.cuda.set_device(dev)
+                if k and stagger:
+                    time.sleep(k * stagger)
+                for _ in range(nsteps):
+                    for i, (_, b) in enumerate(batches):
+                        if i % nst == k:
+                            call(k, b)
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(nst)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
 
     def barrier():
         if use_dist:
@@ -274,12 +313,16 @@ def main():
         my_bases += sum(b.total_bases for _, b in batches)
         my_kmers += sum(b.total_kmers for _, b in batches)
         nsub += len(batches)
-        for _ in range(a.warmup):
-            step(batches)
+        run_steps(batches, a.warmup)
         barrier()
+        stagger = 0.0
+        if a.stagger and a.issue_threads > 1 and nst > 1 and a.warmup > 0:
+            tw = time.perf_counter()                        # one more untimed step (the first ones grow the workspaces): half the time
+            run_steps(batches, 1)                           # a stream takes for one of its sub-batches
+            barrier()
+            stagger = 0.5 * (time.perf_counter() - tw) / max(1, len(batches) // nst)
         t0 = time.perf_counter()
-        for _ in range(a.steps):
-            step(batches)
+        run_steps(batches, a.steps, stagger)
         barrier()
         dt += time.perf_counter() - t0
         for w in wss:                                       # the error words are sticky: every launch since the last check is covered
