@@ -283,7 +283,7 @@ struct dbuf { void *p; size_t cap; };
 
 struct cp_workspace
   { dbuf bitmap, ncand, nintvl, nrel, ioff, eoff, hoff, wall, wall_s, hkeys, hvals, eintvl, ointvl, intvl, rintvl,
-         relmap, parent, eff, rpos, asgn, ord, err, perm, wlist, err2, tres, fwc, dtot,
+         rrec, pcls, relmap, parent, eff, rpos, asgn, ord, err, perm, wlist, err2, tres, fwc, dtot,
          s_cap, s_rcap, s_dummy, s_key, s_seg, s_aux, s_mi, s_rep, s_repcnt, scan_state, order_tmp;
     int      scan_epoch;      // tag of the next k_prefix_caps_mb launch (its state array is never cleared)
     int64_t *h_totals;        // pinned: [totalI, totalE, totalH]
@@ -293,6 +293,7 @@ struct cp_workspace
     int      nreads;
     int64_t  total_kmers, total_bases, totalI, totalE, totalH, nwords;
     int      last_stage;
+    int      last_compact;    // the last run was a whole-path call with compact records: classes in `pcls`, no `rintvl` (cp_run_stages)
     int      decode_pending;  // a cp_decode_profiles result has not been checked yet
     int      seed_nreads; int64_t seed_totalR;   // shape of the last cp_find_seeds_batch
     std::vector<void *> *retired;   // buffers that were outgrown while a stream could still be using them (ensure())
@@ -359,7 +360,7 @@ extern "C" int cp_workspace_create(cp_workspace **out)
 extern "C" void cp_workspace_destroy(cp_workspace *ws)
 { if (!ws) return;
   dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
-                  &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
+                  &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->rrec,&ws->pcls,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
                   &ws->asgn,&ws->ord,&ws->err,&ws->perm,&ws->wlist,&ws->err2,&ws->tres,&ws->fwc,&ws->dtot,
                   &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_rep,&ws->s_repcnt,&ws->scan_state,&ws->order_tmp };
   for (dbuf *b : all) if (b->p) (void)hipFree(b->p);
@@ -377,7 +378,7 @@ extern "C" void cp_workspace_destroy(cp_workspace *ws)
 extern "C" size_t cp_workspace_bytes(const cp_workspace *ws)
 { if (!ws) return 0;
   const dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
-                        &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
+                        &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->rrec,&ws->pcls,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
                         &ws->asgn,&ws->ord,&ws->err,&ws->perm,&ws->wlist,&ws->err2,&ws->tres,&ws->fwc,&ws->dtot,
                   &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_rep,&ws->s_repcnt,&ws->scan_state,&ws->order_tmp };
   size_t s = 0;
@@ -475,7 +476,7 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
     return set_err(CP_EINVAL,"cp_run_stages: more than CP_MAX_BATCH_KMERS k-mer positions in one batch: split it");
   hipStream_t st = (hipStream_t)stream;
   ws->nreads = nreads; ws->total_kmers = total_kmers; ws->total_bases = total_bases;
-  ws->totalI = ws->totalE = 0; ws->last_stage = last_stage; ws->stream = st;
+  ws->totalI = ws->totalE = 0; ws->last_stage = last_stage; ws->stream = st; ws->last_compact = 0;
   ws->nwords = total_kmers/64+2;
   if (nreads == 0)
     return CP_OK;
@@ -581,6 +582,12 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   const bool fuse_rel = (!fuse_e || atol(fuse_e) != 0) && last_stage >= CP_STAGE_REL;
   ENSURE(ws->rintvl,(size_t)totalI*sizeof(cp_intvl));
   ENSURE(ws->relmap,(size_t)totalI*4);
+  // whole-path calls: the reliable intervals go to classify_rel as 24-byte records (kernels.hip: cp_rrec) instead of
+  // 48-byte copies + an index, and only intvl[].asgn comes back (CLASSPRO_COMPACT_REL=0: the copies, as the stage API has them)
+  const char *crel_e = getenv("CLASSPRO_COMPACT_REL");
+  const bool compact_rel = fuse_rel && last_stage == CP_STAGE_LABELS && (!crel_e || atol(crel_e) != 0);
+  if (compact_rel) { ENSURE(ws->rrec,(size_t)totalI*sizeof(cp_rrec)); ENSURE(ws->pcls,(size_t)totalI*4); }
+  ws->last_compact = compact_rel ? 1 : 0;
   hipLaunchKernelGGL(k_find_wall,dim3(nreads),dim3(WAVE),0,st,
                      p->dev,d_seq,d_seq_off,d_prof,d_prof_off,nreads,
                      (uint8_t *)ws->wall.p,(uint8_t *)ws->wall_s.p,(int32_t *)ws->hkeys.p,(double *)ws->hvals.p,(const int64_t *)ws->hoff.p,
@@ -588,7 +595,8 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
                      (const int64_t *)ws->eoff.p,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,
                      (int32_t *)ws->nintvl.p,(int32_t *)ws->err.p,(const int32_t *)ws->perm.p,(int32_t *)ws->wlist.p,
                      (const task_res *)ws->tres.p,(const int32_t *)ws->fwc.p,
-                     (cp_intvl *)ws->rintvl.p,(int32_t *)ws->relmap.p,(int32_t *)ws->nrel.p,fuse_rel ? 1 : 0);
+                     (cp_intvl *)ws->rintvl.p,(int32_t *)ws->relmap.p,(int32_t *)ws->nrel.p,compact_rel ? 2 : fuse_rel ? 1 : 0,
+                     (cp_rrec *)ws->rrec.p);
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_WALL)
     return CP_OK;
@@ -624,14 +632,23 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->parent.p,(int32_t *)ws->eff.p,
                      (uint8_t *)ws->rpos.p,(int8_t *)ws->asgn.p,totalI,(const int32_t *)ws->perm.p);
-  hipLaunchKernelGGL((k_classify_rel_grp<REL_SMALL_MAXM,1024,1,1>),dim3(nreads < 2048 ? nreads : 2048),dim3(WAVE),0,ws->aux,
+  hipLaunchKernelGGL((k_classify_rel_grp<REL_SMALL_MAXM,1024,1,1,0>),dim3(nreads < 2048 ? nreads : 2048),dim3(WAVE),0,ws->aux,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
-                     (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI,(const int32_t *)ws->perm.p);
+                     (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI,(const int32_t *)ws->perm.p,
+                     (const cp_rrec *)nullptr);
   HIPCHK(hipEventRecord(ws->ev_join,ws->aux));
-  hipLaunchKernelGGL((k_classify_rel_grp<0,REL_SMALL_MAXM,REL_SMALL_G,REL_SMALL_WPB>),
-                     dim3((nreads+REL_SMALL_G*REL_SMALL_WPB-1)/(REL_SMALL_G*REL_SMALL_WPB)),dim3(WAVE*REL_SMALL_WPB),0,st,
-                     p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
-                     (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI,(const int32_t *)ws->perm.p);
+  if (compact_rel)
+    hipLaunchKernelGGL((k_classify_rel_grp<0,REL_SMALL_MAXM,REL_SMALL_G,REL_SMALL_WPB,1>),
+                       dim3((nreads+REL_SMALL_G*REL_SMALL_WPB-1)/(REL_SMALL_G*REL_SMALL_WPB)),dim3(WAVE*REL_SMALL_WPB),0,st,
+                       p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
+                       (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI,(const int32_t *)ws->perm.p,
+                       (const cp_rrec *)ws->rrec.p);
+  else
+    hipLaunchKernelGGL((k_classify_rel_grp<0,REL_SMALL_MAXM,REL_SMALL_G,REL_SMALL_WPB,0>),
+                       dim3((nreads+REL_SMALL_G*REL_SMALL_WPB-1)/(REL_SMALL_G*REL_SMALL_WPB)),dim3(WAVE*REL_SMALL_WPB),0,st,
+                       p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
+                       (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI,(const int32_t *)ws->perm.p,
+                       (const cp_rrec *)nullptr);
   HIPCHK(hipStreamWaitEvent(st,ws->ev_join,0));
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_CLASS_REL)
@@ -647,14 +664,14 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   HIPCHK(hipStreamWaitEvent(ws->aux,ws->ev_fork,0));
   hipLaunchKernelGGL(k_classify_unrel,dim3(nreads < 1024 ? nreads : 1024),dim3(WAVE),0,ws->aux,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
-                     (int32_t *)ws->ord.p,(const int32_t *)ws->perm.p,d_prof_off);
+                     (int32_t *)ws->ord.p,(const int32_t *)ws->perm.p,d_prof_off,compact_rel ? (uint32_t *)ws->pcls.p : (uint32_t *)nullptr);
   hipLaunchKernelGGL((k_classify_unrel_grp<UNREL_SMALL_MAXN,1024,UNREL_BIG_G>),dim3((nreads+UNREL_BIG_G-1)/UNREL_BIG_G < 2048 ? (nreads+UNREL_BIG_G-1)/UNREL_BIG_G : 2048),dim3(WAVE),0,ws->aux,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
-                     (const int32_t *)ws->perm.p,d_prof_off);
+                     (const int32_t *)ws->perm.p,d_prof_off,compact_rel ? (uint32_t *)ws->pcls.p : (uint32_t *)nullptr);
   HIPCHK(hipEventRecord(ws->ev_join,ws->aux));
   hipLaunchKernelGGL((k_classify_unrel_grp<0,UNREL_SMALL_MAXN,UNREL_SMALL_G>),dim3((nreads+UNREL_SMALL_G-1)/UNREL_SMALL_G),dim3(WAVE),0,st,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
-                     (const int32_t *)ws->perm.p,d_prof_off);
+                     (const int32_t *)ws->perm.p,d_prof_off,compact_rel ? (uint32_t *)ws->pcls.p : (uint32_t *)nullptr);
   HIPCHK(hipStreamWaitEvent(st,ws->ev_join,0));
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_CLASS_ALL)
@@ -663,7 +680,7 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   // ---- stage 6: labels ---------------------------------------------------------------------------
   hipLaunchKernelGGL(k_paint_labels,dim3(nreads),dim3(WAVE),0,st,
                      p->dev,d_seq_off,nreads,(const cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,
-                     (const int32_t *)ws->nintvl.p,d_labels);
+                     (const int32_t *)ws->nintvl.p,d_labels,compact_rel ? (const uint32_t *)ws->pcls.p : (const uint32_t *)nullptr);
   HIPCHK(hipGetLastError());
   return CP_OK;
 }
@@ -727,6 +744,24 @@ extern "C" int cp_get_intervals(cp_workspace *ws, cp_intvl *intvl, cp_intvl *rin
   size_t bytes = (size_t)ws->totalI*sizeof(cp_intvl);
   if (bytes == 0) return CP_OK;
   if (intvl && ws->last_stage >= CP_STAGE_WALL) HIPCHK(hipMemcpy(intvl,ws->intvl.p,bytes,hipMemcpyDeviceToHost));
+  if (ws->last_compact)
+    { // after a whole-path call (cp_classify_batch) the final classes live in the (end, class) words the label paint reads,
+      // not in the records, and the reliable-interval copies were never made: the classes are put into the records here,
+      // `rintvl` comes back zeroed (run the stages up to CP_STAGE_CLASS_ALL for it)
+      if (rintvl) memset(rintvl,0,bytes);
+      if (intvl)
+        { std::vector<uint32_t> pc((size_t)ws->totalI);
+          std::vector<int64_t> off((size_t)ws->nreads+1);
+          std::vector<int32_t> ni((size_t)ws->nreads);
+          HIPCHK(hipMemcpy(pc.data(),ws->pcls.p,(size_t)ws->totalI*4,hipMemcpyDeviceToHost));
+          HIPCHK(hipMemcpy(off.data(),ws->ioff.p,((size_t)ws->nreads+1)*8,hipMemcpyDeviceToHost));
+          HIPCHK(hipMemcpy(ni.data(),ws->nintvl.p,(size_t)ws->nreads*4,hipMemcpyDeviceToHost));
+          for (int r = 0; r < ws->nreads; r++)
+            for (int k = 0; k < ni[(size_t)r]; k++)
+              intvl[off[(size_t)r]+k].asgn = (int8_t)CP_PCLS_CLS(pc[(size_t)(off[(size_t)r]+k)]);
+        }
+      return CP_OK;
+    }
   if (rintvl && ws->last_stage >= CP_STAGE_REL) HIPCHK(hipMemcpy(rintvl,ws->rintvl.p,bytes,hipMemcpyDeviceToHost));
   return CP_OK;
 }
@@ -998,7 +1033,7 @@ extern "C" int cp_label_runs(const cp_params *p, cp_workspace *ws, int32_t *d_en
     return set_err(CP_EINVAL,"cp_label_runs: the batch on this workspace was not classified (run at least CP_STAGE_CLASS_ALL)");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_label_runs,dim3(ws->nreads),dim3(WAVE),0,st,p->dev,ws->nreads,(const cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,
-                     (const int32_t *)ws->nintvl.p,d_ends,d_cls,d_nruns);
+                     (const int32_t *)ws->nintvl.p,d_ends,d_cls,d_nruns,ws->last_compact ? (const uint32_t *)ws->pcls.p : (const uint32_t *)nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(d_cap_off,ws->ioff.p,((size_t)ws->nreads+1)*8,hipMemcpyDeviceToDevice,st));
   return CP_OK;

@@ -39,6 +39,9 @@ __device__ unsigned long long g_bounds[4];               // cp_bounds.h
 #define WAVE 64
 #define REL_MAXM 1024           // reads with more reliable intervals use the sequential kernel
 #define UNREL_MAXN 1024         // reads with more intervals use the sequential kernel
+#ifndef REL_SMALL_MAXM
+#define REL_SMALL_MAXM 112      // the main size class of k_classify_rel_grp (four reads per wave): M <= this
+#endif
 #define GRP_MAX_PLEN 65535      // the lane-parallel classify kernels keep interval ends as 16-bit LDS fields; a longer read
                                 // (a Dazzler database may hold them: ClassPro.c:87,110 sizes by db->maxlen) takes the sequential kernels
 
@@ -734,6 +737,18 @@ __device__ __forceinline__ void cf_wall_mult(RD *R, const fw_cflags &F, int q, i
     }
 }
 
+// Whole-path calls: the end and the final class of an interval as one word, written by the classify_unrel kernels and read
+// by k_paint_labels / k_label_runs instead of the 48-byte records (an end is below 2^28; a class is 0..3, 7 = none).
+#define CP_PCLS(e,a)   (((uint32_t)(e) << 3) | ((uint32_t)(a) & 7u))
+#define CP_PCLS_END(x) ((int)((x) >> 3))
+#define CP_PCLS_CLS(x) (((x) & 7u) == 7u ? -1 : (int)((x) & 7u))
+
+// What classify_rel needs of a reliable interval, 24 bytes instead of a 48-byte copy of the record plus a 4-byte index:
+// written by k_find_wall on whole-path calls (do_rel == 2) and read by the main size class of k_classify_rel_grp; the
+// stage API and the rare size classes keep the `rintvl` copies (round 5: 0.9 GB less HBM traffic per 2 Gbases).
+struct cp_rrec { int32_t b, e; uint16_t ccb, cce; int32_t idx; double pe; };
+static_assert(sizeof(cp_rrec) == 24,"compact reliable-interval record");
+
 // ---------------------------------------------------------------------------------------------
 //  k_find_wall: wall.c:570-958, one wave per read.
 // ---------------------------------------------------------------------------------------------
@@ -948,7 +963,8 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
             cp_intvl *__restrict__ intvl_all, const int64_t *__restrict__ ioff,
             int32_t *__restrict__ nintvl, int32_t *__restrict__ err, const int32_t *__restrict__ perm,
             int32_t *__restrict__ wlist, const task_res *__restrict__ tres_all, const int32_t *__restrict__ fwc,
-            cp_intvl *__restrict__ rintvl_all, int32_t *__restrict__ relmap_all, int32_t *__restrict__ nrel, int do_rel)
+            cp_intvl *__restrict__ rintvl_all, int32_t *__restrict__ relmap_all, int32_t *__restrict__ nrel, int do_rel,
+            cp_rrec *__restrict__ rrec_all)
 { if ((int)blockIdx.x >= nreads) return;
   const int r = perm[blockIdx.x];
   const int lane = lane_id();
@@ -1528,13 +1544,30 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
           { const uint64_t mask = __ballot(ok);
             if (ok)
               { const int rank = __popcll(mask & ((1ull << lane)-1));
-                rintvl[M+rank] = I;
-                relmap[M+rank] = k;
+                if (do_rel == 2)                             // whole-path call: the compact record only
+                  { cp_rrec q; q.b = I.b; q.e = I.e; q.ccb = I.ccb; q.cce = I.cce; q.idx = k; q.pe = I.pe;
+                    rrec_all[ioff[r]+M+rank] = q;
+                  }
+                else
+                  { rintvl[M+rank] = I;
+                    relmap[M+rank] = k;
+                  }
               }
             M += __popcll(mask);
           }
       }
     if (do_rel && lane == 0) nrel[r] = M;
+    // the rare size classes (M beyond the main class, or a read beyond GRP_MAX_PLEN k-mers: the one-read-per-wave and the
+    // sequential kernels) work on full records: a read of theirs gets its copies here, from the records just written
+    if (do_rel == 2 && (M > REL_SMALL_MAXM || plen > GRP_MAX_PLEN))
+      { wave_sync();
+        const cp_rrec *rr = rrec_all+ioff[r];
+        for (int i = lane; i < M; i += WAVE)
+          { const int k = rr[i].idx;
+            rintvl[i] = intvl[k];
+            relmap[i] = k;
+          }
+      }
   }
   PH_STAMP(5);
   // Leave the flag arrays all zero (capi.hip fills them only when they are allocated): every cell the walk and the
@@ -1692,7 +1725,8 @@ k_classify_rel(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ 
 __global__ void __launch_bounds__(WAVE)
 k_classify_unrel(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__restrict__ intvl_all,
                  const int64_t *__restrict__ ioff, const int32_t *__restrict__ nintvl,
-                 int32_t *__restrict__ ord_all, const int32_t *__restrict__ perm, const int64_t *__restrict__ prof_off)
+                 int32_t *__restrict__ ord_all, const int32_t *__restrict__ perm, const int64_t *__restrict__ prof_off,
+                 uint32_t *__restrict__ pcls_all)
 { const int lane = lane_id();
   for (int i = blockIdx.x; i < nreads; i += gridDim.x)     // the class is at the front of `perm`: see k_classify_rel
   {
@@ -1724,6 +1758,10 @@ k_classify_unrel(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__re
           cp_update_state(P,ord[i] & 0x3fffffff,intvl,N);
     }
   wave_sync();
+  if (pcls_all)                                            // whole-path calls: (end, class) per interval for k_paint_labels (CP_PCLS)
+    { for (int k = lane; k < N; k += WAVE) pcls_all[ioff[r]+k] = CP_PCLS(intvl[k].e,intvl[k].asgn);
+      wave_sync();
+    }
   }
 }
 
@@ -1817,8 +1855,10 @@ __device__ __forceinline__ void grp_sync()
   else { __builtin_amdgcn_fence(__ATOMIC_RELEASE,"wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE,"wavefront"); }
 }
 
+// pe of reliable interval i: a field of the 48-byte record copies (stage API, rare classes) or of the compact records
+#define REL_PE(i) (*reinterpret_cast<const double *>(pe0+(size_t)(i)*pe_stride))
 template <int MAXM, int G, int WPB>
-__device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, const rel_libm_lds &T, const cp_intvl *rintvl, int M, int plen,
+__device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, const rel_libm_lds &T, const char *pe0, int pe_stride, int M, int plen,
                              bool active, const int *COV)
 { CP_LDS_PTR(const uint64_t) xt = (CP_LDS_PTR(const uint64_t))T.exp_tab;
   CP_LDS_PTR(const double)   lt = (CP_LDS_PTR(const double))T.log_tab; // Lanes of a read: LD per direction (forward first).  With LD = 16 (G <= 2) lane (s,t) owns transition
@@ -1843,7 +1883,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
   int i = F ? 0 : M-1;
   if (in_grp && ld < 4)                                    // init, class_rel.c:544-580
     { cp_riv I = rv(i);
-      I.pe = rintvl[i].pe;
+      I.pe = REL_PE(i);
       cp_cell c;
       cp_rel_init_cell(P,ld,I,i,plen,F,COV,&c);
       S.cell[g][d][0][ld].set(c);
@@ -1865,7 +1905,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
   int cur = 0;
   double pe_next = 0.;                                     // pe of the next interval (E lanes), one step ahead
   if (in_grp && t_tab == CP_ERROR && M > 1)
-    pe_next = rintvl[F ? 1 : M-2].pe;
+    pe_next = REL_PE(F ? 1 : M-2);
   for (int k = 1; k < maxM; k++)                           // _update, class_rel.c:279-513
     { const bool on = in_grp && k < M;
       const int i_pred = i;
@@ -1884,7 +1924,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
       if (on)
         { I = rv(i);
           if (t_tab == CP_ERROR && k+1 < M)
-            pe_next = rintvl[F ? k+1 : M-2-k].pe;
+            pe_next = REL_PE(F ? k+1 : M-2-k);
           const auto &pr = S.cell[g][d][cur][s];
           live = pr.dp != -INFINITY;
           if (live)
@@ -2062,9 +2102,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
 #ifndef REL_SMALL_G
 #define REL_SMALL_G 4
 #endif
-#ifndef REL_SMALL_MAXM
-#define REL_SMALL_MAXM 112
-#endif
+// (REL_SMALL_MAXM: defined at the top of the file, k_find_wall needs it)
 // (unrel, later, with K = 64/G/8 speculative update slots per read: G = 4 4.28 ms per step, G = 2 4.07, G = 1 4.04)
 #ifndef UNREL_SMALL_G
 #define UNREL_SMALL_G 2
@@ -2092,13 +2130,16 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
 #define REL_WAVES_PER_EU 4
 #endif
 
-template <int MINM, int MAXM, int G, int WPB>
+template <int MINM, int MAXM, int G, int WPB, int COMPACT = 0>
 __global__ void __launch_bounds__(WAVE*WPB) __attribute__((amdgpu_waves_per_eu(REL_WAVES_PER_EU))) REL_EXTRA_ATTR
 k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ prof_off, int nreads,
                    cp_intvl *__restrict__ intvl_all, cp_intvl *__restrict__ rintvl_all, const int32_t *__restrict__ relmap_all,
                    const int64_t *__restrict__ ioff, const int32_t *__restrict__ nrel,
-                   int8_t *__restrict__ asgn_all, int64_t totalI, const int32_t *__restrict__ perm)
-{ __shared__ rel_grp_lds<MAXM,G> Sw[WPB];
+                   int8_t *__restrict__ asgn_all, int64_t totalI, const int32_t *__restrict__ perm,
+                   const cp_rrec *__restrict__ rrec_all)
+{ // COMPACT (whole-path calls, main size class only): the reliable intervals come as compact records (rrec_all) and only
+  // intvl[].asgn is written (the fw / bw assignments and rintvl[].asgn are what the stage API reads back)
+  __shared__ rel_grp_lds<MAXM,G> Sw[WPB];
   __shared__ rel_libm_lds T;
   for (int k = threadIdx.x; k < 256; k += WAVE*WPB)
     { T.exp_tab[k] = cp_libm::exp_tab[k]; T.log_tab[k] = cp_libm::log_tab[k]; }
@@ -2125,10 +2166,19 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
   if (__ballot(M > 0) == 0) continue;
   const int64_t o = ioff[rr];
   cp_intvl *rintvl = rintvl_all+o;
-  for (int k = ql; k < M; k += L)
-    { S.b[g][k] = (uint16_t)rintvl[k].b; S.e[g][k] = (uint16_t)rintvl[k].e;
-      S.ccb[g][k] = rintvl[k].ccb; S.cce[g][k] = rintvl[k].cce;
-    }
+  const cp_rrec *rrec = COMPACT ? rrec_all+o : nullptr;
+  const char *pe0 = COMPACT ? reinterpret_cast<const char *>(&rrec[0].pe) : reinterpret_cast<const char *>(&rintvl[0].pe);
+  constexpr int pe_stride = COMPACT ? (int)sizeof(cp_rrec) : (int)sizeof(cp_intvl);
+  if (COMPACT)
+    for (int k = ql; k < M; k += L)
+      { const cp_rrec q = rrec[k];
+        S.b[g][k] = (uint16_t)q.b; S.e[g][k] = (uint16_t)q.e; S.ccb[g][k] = q.ccb; S.cce[g][k] = q.cce;
+      }
+  else
+    for (int k = ql; k < M; k += L)
+      { S.b[g][k] = (uint16_t)rintvl[k].b; S.e[g][k] = (uint16_t)rintvl[k].e;
+        S.ccb[g][k] = rintvl[k].ccb; S.cce[g][k] = rintvl[k].cce;
+      }
   grp_sync<WPB>();
 
   constexpr int LD = (L >= 32) ? 16 : 8;                   // lanes per direction, see rel_grp_pass
@@ -2137,7 +2187,7 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
   const bool lead = (M > 0) && (ql < 2*LD) && ((ql % LD) == 0);
   int COV[4] = { P->cov[0], P->cov[1], P->cov[2], P->cov[3] };
   rel_grp_rv<MAXM,G> rv; rv.S = &S; rv.g = g;
-  rel_grp_pass<MAXM,G,WPB>(P,S,T,rintvl,M,plen,M > 0,COV);
+  rel_grp_pass<MAXM,G,WPB>(P,S,T,pe0,pe_stride,M,plen,M > 0,COV);
 
   int rerun = 0;                                           // class_rel.c:629-650
   if (lead)
@@ -2147,7 +2197,7 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
   COV[CP_DIPLO] = __shfl(COV[CP_DIPLO],leadlane);
   if (M == 0 || ql >= 2*LD) rerun = 0;
   if (__ballot(rerun != 0))
-    rel_grp_pass<MAXM,G,WPB>(P,S,T,rintvl,M,plen,rerun != 0,COV);
+    rel_grp_pass<MAXM,G,WPB>(P,S,T,pe0,pe_stride,M,plen,rerun != 0,COV);
   double hdrr = 1.;
   if (lead)
     hdrr = cp_rel_post2(P,rv,M,F,S.asgn(g,d),rerun != 0);
@@ -2183,6 +2233,10 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
   cp_intvl *intvl = intvl_all+o;
   const int32_t *relmap = relmap_all+o;
   int8_t *gfw = asgn_all+o, *gbw = asgn_all+totalI+o;
+  if (COMPACT)
+    for (int i = ql; i < M; i += L)                        // class_rel.c:949-960, the interval array only
+      intvl[rrec[i].idx].asgn = take_bw ? S.asgn(g,1)[i] : S.asgn(g,0)[i];
+  else
   for (int i = ql; i < M; i += L)                          // class_rel.c:949-960
     { int8_t f = S.asgn(g,0)[i], w = S.asgn(g,1)[i];
       int8_t a = take_bw ? w : f;
@@ -2243,7 +2297,7 @@ template <int MINN, int MAXN, int G>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(UNREL_WAVES_PER_EU)))
 k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__restrict__ intvl_all,
                      const int64_t *__restrict__ ioff, const int32_t *__restrict__ nintvl,
-                     const int32_t *__restrict__ perm, const int64_t *__restrict__ prof_off)
+                     const int32_t *__restrict__ perm, const int64_t *__restrict__ prof_off, uint32_t *__restrict__ pcls_all)
 { __shared__ unrel_grp_lds<MAXN,G> S;
   constexpr int L = WAVE/G;
   static_assert(L >= 8 && (L % 8) == 0, "8 role lanes per read");
@@ -2484,8 +2538,12 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
           }
         wave_sync();
       }
-  for (int k = ql; k < N; k += L)
-    intvl[k].asgn = S.asgn[g][k];
+  if (pcls_all)                                            // whole-path calls: 4 bytes per interval for k_paint_labels instead of a
+    for (int k = ql; k < N; k += L)                        // one-byte store into every 48-byte record (CP_PCLS)
+      pcls_all[io+k] = CP_PCLS((int)S.e[g][k],S.asgn[g][k]);
+  else
+    for (int k = ql; k < N; k += L)
+      intvl[k].asgn = S.asgn[g][k];
   wave_sync();                                             // the LDS record is reused by the block's next group
   }
 }
@@ -2506,11 +2564,12 @@ __device__ __forceinline__ unsigned cp_label_char(int a)
 __global__ void __launch_bounds__(WAVE)
 k_paint_labels(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ seq_off, int nreads,
                const cp_intvl *__restrict__ intvl_all, const int64_t *__restrict__ ioff,
-               const int32_t *__restrict__ nintvl, char *__restrict__ labels)
+               const int32_t *__restrict__ nintvl, char *__restrict__ labels, const uint32_t *__restrict__ pcls_all)
 { const int r = blockIdx.x;
   if (r >= nreads) return;
   const int lane = lane_id();
   const int K = P->K;
+  const uint32_t *pcls = pcls_all ? pcls_all+ioff[r] : nullptr;      // whole-path calls: (end, class) words (CP_PCLS)
   char *lab = labels+seq_off[r];
   const int rlen = (int)(seq_off[r+1]-seq_off[r]);
   const cp_intvl *intvl = intvl_all+ioff[r];
@@ -2519,6 +2578,10 @@ k_paint_labels(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ 
   __shared__ uint8_t s_chr[PAINT_MAX];
   if (N+1 <= PAINT_MAX)
     { if (lane == 0) { s_end[0] = K-1 < rlen ? K-1 : rlen; s_chr[0] = 'N'; }
+      if (pcls)
+        for (int k = lane; k < N; k += WAVE)
+          { const uint32_t x = pcls[k]; s_end[k+1] = CP_PCLS_END(x)+(K-1); s_chr[k+1] = (uint8_t)cp_label_char(CP_PCLS_CLS(x)); }
+      else
       for (int k = lane; k < N; k += WAVE)
         { s_end[k+1] = intvl[k].e+(K-1); s_chr[k+1] = (uint8_t)cp_label_char(intvl[k].asgn); }
       wave_sync();
@@ -2564,7 +2627,12 @@ k_paint_labels(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ 
   for (int base = 0; base < N; base += WAVE)             // 64 interval records per round of loads
     { int b_l = 0, e_l = 0, a_l = -1;
       if (base+lane < N)
-        { b_l = intvl[base+lane].b; e_l = intvl[base+lane].e; a_l = intvl[base+lane].asgn; }
+        { if (pcls)
+            { const uint32_t x = pcls[base+lane];
+              b_l = base+lane ? CP_PCLS_END(pcls[base+lane-1]) : 0; e_l = CP_PCLS_END(x); a_l = CP_PCLS_CLS(x);
+            }
+          else { b_l = intvl[base+lane].b; e_l = intvl[base+lane].e; a_l = intvl[base+lane].asgn; }
+        }
       const int nb = (N-base < WAVE) ? N-base : WAVE;
       for (int k = 0; k < nb; k++)
         { const int b = __builtin_amdgcn_readlane(b_l,k), e = __builtin_amdgcn_readlane(e_l,k);
@@ -2735,7 +2803,8 @@ k_unpack_bases(const uint8_t *__restrict__ packed, const int64_t *__restrict__ p
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WAVE)
 k_label_runs(const cp_dev_params *__restrict__ P, int nreads, const cp_intvl *__restrict__ intvl_all, const int64_t *__restrict__ ioff,
-             const int32_t *__restrict__ nintvl, int32_t *__restrict__ ends, uint8_t *__restrict__ cls, int32_t *__restrict__ nruns)
+             const int32_t *__restrict__ nintvl, int32_t *__restrict__ ends, uint8_t *__restrict__ cls, int32_t *__restrict__ nruns,
+             const uint32_t *__restrict__ pcls_all)
 { const int r = blockIdx.x;
   if (r >= nreads) return;
   const int lane = lane_id();
@@ -2747,7 +2816,12 @@ k_label_runs(const cp_dev_params *__restrict__ P, int nreads, const cp_intvl *__
   for (int base = 0; base < N; base += WAVE)
     { const int k = base+lane;
       int e = 0; unsigned c = 0; bool last = false;
-      if (k < N)
+      if (k < N && pcls_all)                               // after a whole-path call the classes are in the (end, class) words
+        { const uint32_t x = pcls_all[o+k];
+          e = CP_PCLS_END(x)+Km1; c = cp_label_char(CP_PCLS_CLS(x));
+          last = (k == N-1) || cp_label_char(CP_PCLS_CLS(pcls_all[o+k+1])) != c;
+        }
+      else if (k < N)
         { e = intvl[k].e+Km1; c = cp_label_char(intvl[k].asgn);
           last = (k == N-1) || cp_label_char(intvl[k+1].asgn) != c;
         }

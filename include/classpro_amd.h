@@ -229,7 +229,12 @@ int cp_run_stages(const cp_params *p, cp_workspace *ws,
 
 /* Read-back of stage results of the last cp_run_stages/cp_classify_batch on `ws` (host buffers;
  * synchronises the stream).  counts: n_intvl[nreads], n_rel[nreads]; offsets into the flat arrays
- * are the exclusive prefix sums of the per-read capacities returned in cap_off[nreads+1]. */
+ * are the exclusive prefix sums of the per-read capacities returned in cap_off[nreads+1].
+ * After a whole-path call (cp_classify_batch = CP_STAGE_LABELS) the interval records come back complete (the final classes
+ * included), but the copies of the reliable intervals and the forward / backward assignments do not exist -- that path
+ * hands classify_rel 24-byte records and the label paint 4-byte (end, class) words instead: `rintvl`
+ * is returned zeroed.  Stop at CP_STAGE_REL .. CP_STAGE_CLASS_ALL for them.  (CLASSPRO_COMPACT_REL=0: the full records
+ * on every call.) */
 int cp_get_counts(cp_workspace *ws, int32_t *n_cand, int32_t *n_intvl, int32_t *n_rel, int64_t *cap_off);
 int cp_get_intervals(cp_workspace *ws, cp_intvl *intvl, cp_intvl *rintvl, int64_t capacity);
 int cp_get_rel_asgn(cp_workspace *ws, int8_t *fw, int8_t *bw, int64_t capacity);   /* after a run that stopped at CP_STAGE_CLASS_REL or CP_STAGE_CLASS_ALL */
