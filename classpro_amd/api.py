@@ -216,10 +216,12 @@ class Classifier:
     def check(self):
         check(self.L.cp_workspace_check(self.ws))
 
-    def label_runs(self, b):
+    def label_runs(self, b, rerun=True):
         """The batch's labels as runs (cp_label_runs): classification without painting the label string, then per read
-        (ends int32[n], cls uint8[n]); `expand_label_runs` rebuilds the strings on the host."""
-        self.run(b, STAGE_CLASS_ALL)
+        (ends int32[n], cls uint8[n]); `expand_label_runs` rebuilds the strings on the host.  rerun=False: the runs of the
+        batch last classified on this workspace (after classify() / run())."""
+        if rerun:
+            self.run(b, STAGE_CLASS_ALL)
         cap = int(self.L.cp_label_runs_capacity(self.ws))
         dev = self.device
         d_end = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)

@@ -626,6 +626,68 @@ def test_find_rel_fused_and_as_a_kernel(torch_dev, ds_a, monkeypatch):
     assert out[0] == out[1]
 
 
+def test_whole_path_compact_records_equal_full_records(torch_dev, ds_a, monkeypatch):
+    """cp_classify_batch hands classify_rel 24-byte records and the label paint 4-byte (end, class) words instead of the
+    48-byte records (capi.hip: compact_rel; CLASSPRO_COMPACT_REL=0 keeps the records): labels, the interval records that
+    cp_get_intervals returns (final classes patched in on read-back) and the label runs are the same bytes either way --
+    on generated reads, adversarial and tail-run ones and reads of the rare size classes (M > 112, N > 256, M / N > 1024)."""
+    from classpro_amd.api import Classifier, Batch, expand_label_runs
+    from classpro_amd._lib import check
+    from classpro_amd import synth
+    from oracle.oracle import Oracle, INTVL_DTYPE
+    from adversarial import adversarial_reads, tail_run_reads
+    ds, h, d = ds_a
+    O = Oracle(K, 20000, h, d)
+    AL = np.frombuffer(b"ACGT", np.uint8)
+    rng = np.random.default_rng(15)
+    seqs, profs = list(ds["seqs"][:40]), list(ds["profiles"][:40])
+    a_s, a_p = adversarial_reads(31, n=80)
+    t_s, t_p = tail_run_reads(32, n=40)
+    big = synth.make_dataset(genome_len=300000, cov=40, read_len=50000, seed=9, het=0.004, err_sub=0.002, err_indel=0.002, min_len=30000)
+    b_s, b_p = list(big["seqs"][:12]), list(big["profiles"][:12])
+    for blk, lo, hi in ((60, 15, 45), (45, 5, 60)):           # N and M beyond 1024: the sequential kernels
+        plen = 58000
+        b_p.append(np.repeat(rng.integers(lo, hi, plen // blk + 1), blk)[:plen].astype(np.uint16))
+        b_s.append(bytes(AL[rng.integers(0, 4, plen + K - 1)]))
+    for s_, p_ in zip(a_s + t_s + b_s, a_p + t_p + b_p):
+        try:
+            O.classify_read(s_, p_)
+        except OverflowError:
+            continue
+        seqs.append(s_); profs.append(p_)
+    out = []
+    for env in (None, "0"):
+        if env is None:
+            monkeypatch.delenv("CLASSPRO_COMPACT_REL", raising=False)
+        else:
+            monkeypatch.setenv("CLASSPRO_COMPACT_REL", env)
+        clf = Classifier(K, 20000, h, d)
+        b = Batch.from_reads(seqs, profs)
+        lab = clf.classify(b).tobytes()
+        nc, ni, nr, off = clf.counts(b)
+        tot = int(off[-1])
+        iv = np.zeros((tot, INTVL_DTYPE.itemsize), np.uint8)
+        rv = np.zeros((tot, INTVL_DTYPE.itemsize), np.uint8)
+        check(clf.L.cp_get_intervals(clf.ws, iv.ctypes.data, rv.ctypes.data, tot))
+        idx = np.arange(tot) - off[np.searchsorted(off, np.arange(tot), side="right") - 1]
+        live = idx < np.repeat(ni, np.diff(off))
+        so = b.seq_off_h
+        clf.classify(b)
+        runs = clf.label_runs(b, rerun=False)               # straight after the whole-path call: from the (end, class) words
+        strings = b"".join(expand_label_runs(e_, c_, int(so[r + 1] - so[r]), K) for r, (e_, c_) in enumerate(runs))
+        runs2 = clf.label_runs(b)                           # and after a run that stops at CP_STAGE_CLASS_ALL: from the records
+        assert strings == b"".join(expand_label_runs(e_, c_, int(so[r + 1] - so[r]), K) for r, (e_, c_) in enumerate(runs2))
+        out.append((lab, iv[live].tobytes(), ni.tobytes(), nr.tobytes(), strings))
+        if env is None:
+            assert not rv.any()                             # no copies of the reliable intervals on the compact path
+        assert strings == lab
+        clf.close()
+    monkeypatch.delenv("CLASSPRO_COMPACT_REL", raising=False)
+    assert max(np.frombuffer(out[0][3], np.int32)) > 1024 and max(np.frombuffer(out[0][2], np.int32)) > 1024
+    assert out[0] == out[1]
+    assert out[0][0] == b"".join(O.classify_read(s_, p_) for s_, p_ in zip(seqs, profs))
+
+
 def test_fuzz_regressions(torch_dev):
     """Reads that the fuzz soak (scripts/fuzz_parity.py) once found different.  fuzz305_34: classify_unrel's argmax meets
     log(px*py) against log(px)+log(py); with ocml's log the device said E where the oracle (glibc) says D."""
