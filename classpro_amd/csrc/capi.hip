@@ -283,7 +283,7 @@ struct dbuf { void *p; size_t cap; };
 
 struct cp_workspace
   { dbuf bitmap, ncand, nintvl, nrel, ioff, eoff, hoff, wall, wall_s, hkeys, hvals, eintvl, ointvl, intvl, rintvl,
-         rrec, pcls, relmap, parent, eff, rpos, asgn, ord, err, perm, wlist, err2, tres, fwc, dtot,
+         rrec, pcls, ivA, ivB, ivC, relmap, parent, eff, rpos, asgn, ord, err, perm, wlist, err2, tres, fwc, dtot,
          s_cap, s_rcap, s_dummy, s_key, s_seg, s_aux, s_mi, s_rep, s_repcnt, scan_state, order_tmp;
     int      scan_epoch;      // tag of the next k_prefix_caps_mb launch (its state array is never cleared)
     int64_t *h_totals;        // pinned: [totalI, totalE, totalH]
@@ -360,7 +360,7 @@ extern "C" int cp_workspace_create(cp_workspace **out)
 extern "C" void cp_workspace_destroy(cp_workspace *ws)
 { if (!ws) return;
   dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
-                  &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->rrec,&ws->pcls,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
+                  &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->rrec,&ws->pcls,&ws->ivA,&ws->ivB,&ws->ivC,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
                   &ws->asgn,&ws->ord,&ws->err,&ws->perm,&ws->wlist,&ws->err2,&ws->tres,&ws->fwc,&ws->dtot,
                   &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_rep,&ws->s_repcnt,&ws->scan_state,&ws->order_tmp };
   for (dbuf *b : all) if (b->p) (void)hipFree(b->p);
@@ -378,7 +378,7 @@ extern "C" void cp_workspace_destroy(cp_workspace *ws)
 extern "C" size_t cp_workspace_bytes(const cp_workspace *ws)
 { if (!ws) return 0;
   const dbuf *all[] = { &ws->bitmap,&ws->ncand,&ws->nintvl,&ws->nrel,&ws->ioff,&ws->eoff,&ws->hoff,&ws->wall,&ws->wall_s,&ws->hkeys,&ws->hvals,
-                        &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->rrec,&ws->pcls,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
+                        &ws->eintvl,&ws->ointvl,&ws->intvl,&ws->rintvl,&ws->rrec,&ws->pcls,&ws->ivA,&ws->ivB,&ws->ivC,&ws->relmap,&ws->parent,&ws->eff,&ws->rpos,
                         &ws->asgn,&ws->ord,&ws->err,&ws->perm,&ws->wlist,&ws->err2,&ws->tres,&ws->fwc,&ws->dtot,
                   &ws->s_cap,&ws->s_rcap,&ws->s_dummy,&ws->s_key,&ws->s_seg,&ws->s_aux,&ws->s_mi,&ws->s_rep,&ws->s_repcnt,&ws->scan_state,&ws->order_tmp };
   size_t s = 0;
@@ -586,8 +586,12 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   // 48-byte copies + an index, and only intvl[].asgn comes back (CLASSPRO_COMPACT_REL=0: the copies, as the stage API has them)
   const char *crel_e = getenv("CLASSPRO_COMPACT_REL");
   const bool compact_rel = fuse_rel && last_stage == CP_STAGE_LABELS && (!crel_e || atol(crel_e) != 0);
+  // ... and the interval records as three arrays (cp_soa; CLASSPRO_COMPACT_REL=1: the 24-byte and 4-byte records only)
+  const bool soa_on = compact_rel && (!crel_e || atol(crel_e) != 1);
   if (compact_rel) { ENSURE(ws->rrec,(size_t)totalI*sizeof(cp_rrec)); ENSURE(ws->pcls,(size_t)totalI*4); }
-  ws->last_compact = compact_rel ? 1 : 0;
+  if (soa_on) { ENSURE(ws->ivA,(size_t)totalI*sizeof(cp_ivA)); ENSURE(ws->ivB,(size_t)totalI*sizeof(cp_ivB)); ENSURE(ws->ivC,(size_t)totalI*sizeof(cp_ivC)); }
+  cp_soa soa; soa.a = soa_on ? (cp_ivA *)ws->ivA.p : nullptr; soa.b = soa_on ? (cp_ivB *)ws->ivB.p : nullptr; soa.c = soa_on ? (cp_ivC *)ws->ivC.p : nullptr;
+  ws->last_compact = compact_rel ? (soa_on ? 2 : 1) : 0;
   hipLaunchKernelGGL(k_find_wall,dim3(nreads),dim3(WAVE),0,st,
                      p->dev,d_seq,d_seq_off,d_prof,d_prof_off,nreads,
                      (uint8_t *)ws->wall.p,(uint8_t *)ws->wall_s.p,(int32_t *)ws->hkeys.p,(double *)ws->hvals.p,(const int64_t *)ws->hoff.p,
@@ -596,7 +600,7 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
                      (int32_t *)ws->nintvl.p,(int32_t *)ws->err.p,(const int32_t *)ws->perm.p,(int32_t *)ws->wlist.p,
                      (const task_res *)ws->tres.p,(const int32_t *)ws->fwc.p,
                      (cp_intvl *)ws->rintvl.p,(int32_t *)ws->relmap.p,(int32_t *)ws->nrel.p,compact_rel ? 2 : fuse_rel ? 1 : 0,
-                     (cp_rrec *)ws->rrec.p);
+                     (cp_rrec *)ws->rrec.p,soa);
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_WALL)
     return CP_OK;
@@ -631,24 +635,24 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   hipLaunchKernelGGL(k_classify_rel,dim3(nreads < 1024 ? nreads : 1024),dim3(WAVE),0,ws->aux,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->parent.p,(int32_t *)ws->eff.p,
-                     (uint8_t *)ws->rpos.p,(int8_t *)ws->asgn.p,totalI,(const int32_t *)ws->perm.p);
+                     (uint8_t *)ws->rpos.p,(int8_t *)ws->asgn.p,totalI,(const int32_t *)ws->perm.p,soa);
   hipLaunchKernelGGL((k_classify_rel_grp<REL_SMALL_MAXM,1024,1,1,0>),dim3(nreads < 2048 ? nreads : 2048),dim3(WAVE),0,ws->aux,
                      p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                      (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI,(const int32_t *)ws->perm.p,
-                     (const cp_rrec *)nullptr);
+                     (const cp_rrec *)nullptr,soa);
   HIPCHK(hipEventRecord(ws->ev_join,ws->aux));
   if (compact_rel)
     hipLaunchKernelGGL((k_classify_rel_grp<0,REL_SMALL_MAXM,REL_SMALL_G,REL_SMALL_WPB,1>),
                        dim3((nreads+REL_SMALL_G*REL_SMALL_WPB-1)/(REL_SMALL_G*REL_SMALL_WPB)),dim3(WAVE*REL_SMALL_WPB),0,st,
                        p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                        (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI,(const int32_t *)ws->perm.p,
-                       (const cp_rrec *)ws->rrec.p);
+                       (const cp_rrec *)ws->rrec.p,soa);
   else
     hipLaunchKernelGGL((k_classify_rel_grp<0,REL_SMALL_MAXM,REL_SMALL_G,REL_SMALL_WPB,0>),
                        dim3((nreads+REL_SMALL_G*REL_SMALL_WPB-1)/(REL_SMALL_G*REL_SMALL_WPB)),dim3(WAVE*REL_SMALL_WPB),0,st,
                        p->dev,d_prof_off,nreads,(cp_intvl *)ws->intvl.p,(cp_intvl *)ws->rintvl.p,(const int32_t *)ws->relmap.p,
                        (const int64_t *)ws->ioff.p,(const int32_t *)ws->nrel.p,(int8_t *)ws->asgn.p,totalI,(const int32_t *)ws->perm.p,
-                       (const cp_rrec *)nullptr);
+                       (const cp_rrec *)nullptr,soa);
   HIPCHK(hipStreamWaitEvent(st,ws->ev_join,0));
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_CLASS_REL)
@@ -664,14 +668,19 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   HIPCHK(hipStreamWaitEvent(ws->aux,ws->ev_fork,0));
   hipLaunchKernelGGL(k_classify_unrel,dim3(nreads < 1024 ? nreads : 1024),dim3(WAVE),0,ws->aux,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
-                     (int32_t *)ws->ord.p,(const int32_t *)ws->perm.p,d_prof_off,compact_rel ? (uint32_t *)ws->pcls.p : (uint32_t *)nullptr);
-  hipLaunchKernelGGL((k_classify_unrel_grp<UNREL_SMALL_MAXN,1024,UNREL_BIG_G>),dim3((nreads+UNREL_BIG_G-1)/UNREL_BIG_G < 2048 ? (nreads+UNREL_BIG_G-1)/UNREL_BIG_G : 2048),dim3(WAVE),0,ws->aux,
+                     (int32_t *)ws->ord.p,(const int32_t *)ws->perm.p,d_prof_off,compact_rel ? (uint32_t *)ws->pcls.p : (uint32_t *)nullptr,soa);
+  hipLaunchKernelGGL((k_classify_unrel_grp<UNREL_SMALL_MAXN,1024,UNREL_BIG_G,0>),dim3((nreads+UNREL_BIG_G-1)/UNREL_BIG_G < 2048 ? (nreads+UNREL_BIG_G-1)/UNREL_BIG_G : 2048),dim3(WAVE),0,ws->aux,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
-                     (const int32_t *)ws->perm.p,d_prof_off,compact_rel ? (uint32_t *)ws->pcls.p : (uint32_t *)nullptr);
+                     (const int32_t *)ws->perm.p,d_prof_off,compact_rel ? (uint32_t *)ws->pcls.p : (uint32_t *)nullptr,soa);
   HIPCHK(hipEventRecord(ws->ev_join,ws->aux));
-  hipLaunchKernelGGL((k_classify_unrel_grp<0,UNREL_SMALL_MAXN,UNREL_SMALL_G>),dim3((nreads+UNREL_SMALL_G-1)/UNREL_SMALL_G),dim3(WAVE),0,st,
-                     p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
-                     (const int32_t *)ws->perm.p,d_prof_off,compact_rel ? (uint32_t *)ws->pcls.p : (uint32_t *)nullptr);
+  if (soa_on)
+    hipLaunchKernelGGL((k_classify_unrel_grp<0,UNREL_SMALL_MAXN,UNREL_SMALL_G,1>),dim3((nreads+UNREL_SMALL_G-1)/UNREL_SMALL_G),dim3(WAVE),0,st,
+                       p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
+                       (const int32_t *)ws->perm.p,d_prof_off,(uint32_t *)ws->pcls.p,soa);
+  else
+    hipLaunchKernelGGL((k_classify_unrel_grp<0,UNREL_SMALL_MAXN,UNREL_SMALL_G,0>),dim3((nreads+UNREL_SMALL_G-1)/UNREL_SMALL_G),dim3(WAVE),0,st,
+                       p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
+                       (const int32_t *)ws->perm.p,d_prof_off,compact_rel ? (uint32_t *)ws->pcls.p : (uint32_t *)nullptr,soa);
   HIPCHK(hipStreamWaitEvent(st,ws->ev_join,0));
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_CLASS_ALL)
@@ -756,9 +765,24 @@ extern "C" int cp_get_intervals(cp_workspace *ws, cp_intvl *intvl, cp_intvl *rin
           HIPCHK(hipMemcpy(pc.data(),ws->pcls.p,(size_t)ws->totalI*4,hipMemcpyDeviceToHost));
           HIPCHK(hipMemcpy(off.data(),ws->ioff.p,((size_t)ws->nreads+1)*8,hipMemcpyDeviceToHost));
           HIPCHK(hipMemcpy(ni.data(),ws->nintvl.p,(size_t)ws->nreads*4,hipMemcpyDeviceToHost));
+          std::vector<cp_ivA> A; std::vector<cp_ivB> B; std::vector<cp_ivC> Cc;
+          if (ws->last_compact == 2)                      // the records went to the device as three arrays: put them together
+            { A.resize((size_t)ws->totalI); B.resize((size_t)ws->totalI); Cc.resize((size_t)ws->totalI);
+              HIPCHK(hipMemcpy(A.data(),ws->ivA.p,(size_t)ws->totalI*sizeof(cp_ivA),hipMemcpyDeviceToHost));
+              HIPCHK(hipMemcpy(B.data(),ws->ivB.p,(size_t)ws->totalI*sizeof(cp_ivB),hipMemcpyDeviceToHost));
+              HIPCHK(hipMemcpy(Cc.data(),ws->ivC.p,(size_t)ws->totalI*sizeof(cp_ivC),hipMemcpyDeviceToHost));
+            }
           for (int r = 0; r < ws->nreads; r++)
             for (int k = 0; k < ni[(size_t)r]; k++)
-              intvl[off[(size_t)r]+k].asgn = (int8_t)CP_PCLS_CLS(pc[(size_t)(off[(size_t)r]+k)]);
+              { const size_t at = (size_t)(off[(size_t)r]+k);
+                cp_intvl &I = intvl[at];
+                if (ws->last_compact == 2)
+                  { memset(&I,0,sizeof(I));
+                    I.b = A[at].b; I.e = A[at].e; I.cb = A[at].cb; I.ce = A[at].ce; I.ccb = A[at].ccb; I.cce = A[at].cce;
+                    I.is_rel = Cc[at].is_rel; I.pe = B[at].pe; I.peo_b = B[at].peo_b; I.peo_e = B[at].peo_e;
+                  }
+                I.asgn = (int8_t)CP_PCLS_CLS(pc[at]);
+              }
         }
       return CP_OK;
     }

@@ -42,6 +42,9 @@ __device__ unsigned long long g_bounds[4];               // cp_bounds.h
 #ifndef REL_SMALL_MAXM
 #define REL_SMALL_MAXM 112      // the main size class of k_classify_rel_grp (four reads per wave): M <= this
 #endif
+#ifndef UNREL_SMALL_MAXN
+#define UNREL_SMALL_MAXN 256    // the main size class of k_classify_unrel_grp (two reads per wave): N <= this
+#endif
 #define GRP_MAX_PLEN 65535      // the lane-parallel classify kernels keep interval ends as 16-bit LDS fields; a longer read
                                 // (a Dazzler database may hold them: ClassPro.c:87,110 sizes by db->maxlen) takes the sequential kernels
 
@@ -748,6 +751,31 @@ __device__ __forceinline__ void cf_wall_mult(RD *R, const fw_cflags &F, int q, i
 // stage API and the rare size classes keep the `rintvl` copies (round 5: 0.9 GB less HBM traffic per 2 Gbases).
 struct cp_rrec { int32_t b, e; uint16_t ccb, cce; int32_t idx; double pe; };
 static_assert(sizeof(cp_rrec) == 24,"compact reliable-interval record");
+// ... and the interval records themselves as three arrays (whole-path calls): what every classify_unrel update reads
+// (16 bytes, loaded coalesced), the three log-probabilities that only the updates of non-fixed intervals come back for (24
+// bytes), and the two bytes classify_rel and classify_unrel exchange -- instead of 48-byte records of which a wave's loads
+// use a third of every line they fetch.  The 48-byte records are still written for the reads of the rare classify_unrel
+// classes (N > UNREL_SMALL_MAXN, or beyond GRP_MAX_PLEN k-mers), whose kernels work on them, and cp_get_intervals puts them
+// together again on read-back.
+struct cp_ivA { int32_t b, e; uint16_t cb, ce, ccb, cce; };
+struct cp_ivB { double pe, peo_b, peo_e; };
+struct cp_ivC { uint8_t is_rel; int8_t asgn; };
+static_assert(sizeof(cp_ivA) == 16 && sizeof(cp_ivB) == 24 && sizeof(cp_ivC) == 2,"interval records as arrays");
+struct cp_soa { cp_ivA *a; cp_ivB *b; cp_ivC *c; };       // all NULL: the 48-byte records only
+__device__ __forceinline__ void cp_soa_put(const cp_soa &S, int64_t at, const cp_intvl &I)
+{ cp_ivA a; a.b = I.b; a.e = I.e; a.cb = I.cb; a.ce = I.ce; a.ccb = I.ccb; a.cce = I.cce;
+  cp_ivB b; b.pe = I.pe; b.peo_b = I.peo_b; b.peo_e = I.peo_e;
+  cp_ivC c; c.is_rel = I.is_rel; c.asgn = I.asgn;
+  S.a[at] = a; S.b[at] = b; S.c[at] = c;
+}
+__device__ __forceinline__ cp_intvl cp_soa_get(const cp_soa &S, int64_t at)
+{ const cp_ivA a = S.a[at]; const cp_ivB b = S.b[at]; const cp_ivC c = S.c[at];
+  cp_intvl I;
+  memset(&I,0,sizeof(I));
+  I.b = a.b; I.e = a.e; I.cb = a.cb; I.ce = a.ce; I.ccb = a.ccb; I.cce = a.cce;
+  I.is_rel = c.is_rel; I.asgn = c.asgn; I.pe = b.pe; I.peo_b = b.peo_b; I.peo_e = b.peo_e;
+  return I;
+}
 
 // ---------------------------------------------------------------------------------------------
 //  k_find_wall: wall.c:570-958, one wave per read.
@@ -964,7 +992,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
             int32_t *__restrict__ nintvl, int32_t *__restrict__ err, const int32_t *__restrict__ perm,
             int32_t *__restrict__ wlist, const task_res *__restrict__ tres_all, const int32_t *__restrict__ fwc,
             cp_intvl *__restrict__ rintvl_all, int32_t *__restrict__ relmap_all, int32_t *__restrict__ nrel, int do_rel,
-            cp_rrec *__restrict__ rrec_all)
+            cp_rrec *__restrict__ rrec_all, cp_soa soa)
 { if ((int)blockIdx.x >= nreads) return;
   const int r = perm[blockIdx.x];
   const int lane = lane_id();
@@ -1526,6 +1554,10 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   { const int Ncl = N < icap ? N : icap;
     cp_intvl *rintvl = rintvl_all+ioff[r];
     int32_t *relmap = relmap_all+ioff[r];
+    // whole-path calls (do_rel == 2): the records as arrays (cp_soa); the 48-byte form only for a read of a rare
+    // classify_unrel class, whose kernels work on it
+    const bool use_soa = do_rel == 2 && soa.a != nullptr;
+    const bool aos = !use_soa || Ncl > UNREL_SMALL_MAXN || plen > GRP_MAX_PLEN;
     int M = 0;
     for (int base = 0; base < Ncl; base += WAVE)
       { const int k = base+lane;
@@ -1538,7 +1570,8 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
               { ok = cp_rel_interval(P,R.prof,R.seq,R.seq,rlen,&I,k);
                 I.is_rel = ok ? 1 : 0;
               }
-            intvl[k] = I;
+            if (aos) intvl[k] = I;
+            if (use_soa) cp_soa_put(soa,ioff[r]+k,I);
           }
         if (do_rel)
           { const uint64_t mask = __ballot(ok);
@@ -1564,7 +1597,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
         const cp_rrec *rr = rrec_all+ioff[r];
         for (int i = lane; i < M; i += WAVE)
           { const int k = rr[i].idx;
-            rintvl[i] = intvl[k];
+            rintvl[i] = aos ? intvl[k] : cp_soa_get(soa,ioff[r]+k);
             relmap[i] = k;
           }
       }
@@ -1655,7 +1688,7 @@ k_classify_rel(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ 
                cp_intvl *__restrict__ intvl_all, cp_intvl *__restrict__ rintvl_all, const int32_t *__restrict__ relmap_all,
                const int64_t *__restrict__ ioff, const int32_t *__restrict__ nrel,
                int8_t *__restrict__ parent_all, int32_t *__restrict__ eff_all, uint8_t *__restrict__ rpos_all,
-               int8_t *__restrict__ asgn_all, int64_t totalI, const int32_t *__restrict__ perm)
+               int8_t *__restrict__ asgn_all, int64_t totalI, const int32_t *__restrict__ perm, cp_soa soa)
 { const int lane = lane_id();
   // Few reads need this kernel, on most batches none.  `perm` lists the reads by decreasing M with the reads beyond
   // GRP_MAX_PLEN k-mers in the top bin as well (order_bin): the class is inside the top bin, at the front of the list,
@@ -1713,6 +1746,7 @@ k_classify_rel(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ 
     { int8_t a = take_bw ? bw[i] : fw[i];
       rintvl[i].asgn = a;
       intvl[relmap[i]].asgn = a;
+      if (soa.c) soa.c[o+relmap[i]].asgn = a;              // whole-path calls: classify_unrel reads the class there
     }
   wave_sync();
   }
@@ -1726,7 +1760,7 @@ __global__ void __launch_bounds__(WAVE)
 k_classify_unrel(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__restrict__ intvl_all,
                  const int64_t *__restrict__ ioff, const int32_t *__restrict__ nintvl,
                  int32_t *__restrict__ ord_all, const int32_t *__restrict__ perm, const int64_t *__restrict__ prof_off,
-                 uint32_t *__restrict__ pcls_all)
+                 uint32_t *__restrict__ pcls_all, cp_soa soa)
 { const int lane = lane_id();
   for (int i = blockIdx.x; i < nreads; i += gridDim.x)     // the class is at the front of `perm`: see k_classify_rel
   {
@@ -1737,6 +1771,10 @@ k_classify_unrel(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__re
   cp_intvl *intvl = intvl_all+ioff[r];
   if (N == 0 || (N <= UNREL_MAXN && plen <= GRP_MAX_PLEN)) continue;   // other reads: k_classify_unrel_grp (the last interval ends at plen)
   int32_t *ord = ord_all+ioff[r];
+  if (soa.c)                                             // whole-path calls: classify_rel left its classes in the two-byte array
+    { for (int k = lane; k < N; k += WAVE) intvl[k].asgn = soa.c[ioff[r]+k].asgn;
+      wave_sync();
+    }
   for (int k = lane; k < N; k += WAVE)                   // ord[rank] = index | fixed<<31
     { const cp_intvl I = intvl[k];
       const int key = I.cb < I.ce ? I.cb : I.ce;
@@ -2107,9 +2145,7 @@ __device__ void rel_grp_pass(const cp_dev_params *P, rel_grp_lds<MAXM,G> &S, con
 #ifndef UNREL_SMALL_G
 #define UNREL_SMALL_G 2
 #endif
-#ifndef UNREL_SMALL_MAXN
-#define UNREL_SMALL_MAXN 256
-#endif
+// (UNREL_SMALL_MAXN: defined at the top of the file, k_find_wall needs it)
 // the class above it holds a handful of reads per sub-batch, each a chain of several hundred updates: one read per wave
 // (eight speculative slots) -- with two, the stage's main kernel waited 0.5 ms for this one at its end
 #ifndef UNREL_BIG_G
@@ -2136,7 +2172,7 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
                    cp_intvl *__restrict__ intvl_all, cp_intvl *__restrict__ rintvl_all, const int32_t *__restrict__ relmap_all,
                    const int64_t *__restrict__ ioff, const int32_t *__restrict__ nrel,
                    int8_t *__restrict__ asgn_all, int64_t totalI, const int32_t *__restrict__ perm,
-                   const cp_rrec *__restrict__ rrec_all)
+                   const cp_rrec *__restrict__ rrec_all, cp_soa soa)
 { // COMPACT (whole-path calls, main size class only): the reliable intervals come as compact records (rrec_all) and only
   // intvl[].asgn is written (the fw / bw assignments and rintvl[].asgn are what the stage API reads back)
   __shared__ rel_grp_lds<MAXM,G> Sw[WPB];
@@ -2234,8 +2270,10 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
   const int32_t *relmap = relmap_all+o;
   int8_t *gfw = asgn_all+o, *gbw = asgn_all+totalI+o;
   if (COMPACT)
-    for (int i = ql; i < M; i += L)                        // class_rel.c:949-960, the interval array only
-      intvl[rrec[i].idx].asgn = take_bw ? S.asgn(g,1)[i] : S.asgn(g,0)[i];
+    for (int i = ql; i < M; i += L)                        // class_rel.c:949-960, the class only: into the two-byte array
+      { const int8_t a = take_bw ? S.asgn(g,1)[i] : S.asgn(g,0)[i];            // (or the record, without the arrays)
+        if (soa.c) soa.c[o+rrec[i].idx].asgn = a; else intvl[rrec[i].idx].asgn = a;
+      }
   else
   for (int i = ql; i < M; i += L)                          // class_rel.c:949-960
     { int8_t f = S.asgn(g,0)[i], w = S.asgn(g,1)[i];
@@ -2243,6 +2281,7 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
       gfw[i] = f; gbw[i] = w;
       rintvl[i].asgn = a;
       intvl[relmap[i]].asgn = a;
+      if (soa.c) soa.c[o+relmap[i]].asgn = a;
     }
   grp_sync<WPB>();                                             // the LDS record is reused by the block's next group
   }
@@ -2293,12 +2332,16 @@ __device__ __forceinline__ int bits_right(const uint64_t *bits, int idx, int nwo
 #ifndef UNREL_WAVES_PER_EU
 #define UNREL_WAVES_PER_EU 4
 #endif
-template <int MINN, int MAXN, int G>
+template <int MINN, int MAXN, int G, int COMPACT = 0>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(UNREL_WAVES_PER_EU)))
 k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__restrict__ intvl_all,
                      const int64_t *__restrict__ ioff, const int32_t *__restrict__ nintvl,
-                     const int32_t *__restrict__ perm, const int64_t *__restrict__ prof_off, uint32_t *__restrict__ pcls_all)
-{ __shared__ unrel_grp_lds<MAXN,G> S;
+                     const int32_t *__restrict__ perm, const int64_t *__restrict__ prof_off, uint32_t *__restrict__ pcls_all,
+                     cp_soa soa)
+{ // COMPACT (whole-path calls, main size class): the intervals come as arrays (cp_soa) -- 16 bytes per interval in the load
+  // loop, the three log-probabilities from their own array when an update asks for them.  Without COMPACT but with soa.c
+  // (the rare class on whole-path calls): the 48-byte records, the classes of classify_rel from the two-byte array.
+  __shared__ unrel_grp_lds<MAXN,G> S;
   constexpr int L = WAVE/G;
   static_assert(L >= 8 && (L % 8) == 0, "8 role lanes per read");
   const int lane = lane_id();
@@ -2327,8 +2370,17 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
   for (int base = 0; base < maxN; base += L)               // load + bitsets, L intervals of every read per step
     { const int k = base+ql;
       bool h = false, dd = false;
-      if (k < N)
-        { const cp_intvl I = intvl[k];
+      if (k < N && COMPACT)
+        { const cp_ivA A = soa.a[io+k]; const cp_ivC Cc = soa.c[io+k];
+          S.b[g][k] = (uint16_t)A.b; S.e[g][k] = (uint16_t)A.e;
+          S.cb[g][k] = A.cb; S.ce[g][k] = A.ce; S.ccb[g][k] = A.ccb; S.cce[g][k] = A.cce;
+          S.asgn[g][k] = Cc.asgn; S.isrel[g][k] = Cc.is_rel;
+          h  = Cc.is_rel && Cc.asgn == CP_HAPLO;
+          dd = Cc.is_rel && Cc.asgn == CP_DIPLO;
+        }
+      else if (k < N)
+        { cp_intvl I = intvl[k];
+          if (soa.c) I.asgn = soa.c[io+k].asgn;
           S.b[g][k] = (uint16_t)I.b; S.e[g][k] = (uint16_t)I.e;
           S.cb[g][k] = I.cb; S.ce[g][k] = I.ce; S.ccb[g][k] = I.ccb; S.cce[g][k] = I.cce;
           S.asgn[g][k] = I.asgn; S.isrel[g][k] = I.is_rel;
@@ -2421,12 +2473,12 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
                 const int l_rel = s2 ? lD : lH, r_rel = s2 ? rD : rH;
                 { if (kind == 0)                           // class_unrel.c:123-163, arguments only
                       { if (side == 0)
-                          { if (idx-1 >= 0 && S.asgn[g][idx-1] == (int8_t)s) er = intvl[idx].peo_b;
+                          { if (idx-1 >= 0 && S.asgn[g][idx-1] == (int8_t)s) er = COMPACT ? soa.b[io+idx].peo_b : intvl[idx].peo_b;
                             if (l_rel != -1)
                               { do_sf = true; tb = S.e[g][l_rel]-1; te = Ib; tcb = S.cce[g][l_rel]; tce = Icb; tcov = tcb; }
                           }
                         else
-                          { if (idx+1 < N && S.asgn[g][idx+1] == (int8_t)s) er = intvl[idx].peo_e;
+                          { if (idx+1 < N && S.asgn[g][idx+1] == (int8_t)s) er = COMPACT ? soa.b[io+idx].peo_e : intvl[idx].peo_e;
                             if (r_rel != -1)
                               { do_sf = true; tb = Ie-1; te = S.b[g][r_rel]; tcb = Ice; tce = S.ccb[g][r_rel]; tcov = tce; }
                           }
@@ -2478,7 +2530,7 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
             const double logp_s = logp_l+logp_r;
             const double vH = __shfl(logp_s,sbase), vD = __shfl(logp_s,sbase+4);
             // E and R are table look-ups (class_unrel.c:53-113)
-            const double pe = intvl[idx].pe;
+            const double pe = COMPACT ? soa.b[io+idx].pe : intvl[idx].pe;
             const double po = cp_logp_poisson(P,Icb,P->cov[CP_ERROR])+cp_logp_poisson(P,Ice,P->cov[CP_ERROR])+CP_E_PO_BASE;
             const double vE = (pe > po) ? pe : po;
             double vR;

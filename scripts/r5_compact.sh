@@ -2,13 +2,13 @@
 # whole-path calls with compact reliable-interval records (default) against CLASSPRO_COMPACT_REL=0: parity tests, bench A/B, bytes
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python -m pytest tests/test_gpu_parity.py tests/test_gpu_reference.py tests/test_gpu_neighbours.py tests/test_gpu_pack.py -m gpu -x -q 2>&1 | tail -3
-for v in 1 0 1 0; do
+for v in 2 1 0 2 1 0; do
   CLASSPRO_COMPACT_REL=$v python bench.py --steps 10 --warmup 3 --no-cpu --no-extras 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('COMPACT_REL=$v: value %.1f Gb/s  step %.2f ms' % (d['value']/1e3, d['ms_per_step']))"
 done
-for v in 1 0; do
+for v in 2 1 0; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf gpurun_out/pmc_tmp
     CLASSPRO_COMPACT_REL=$v rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_tmp -- python bench.py --steps 1 --warmup 1 --no-cpu --no-extras > gpurun_out/pmc_tmp.log 2>&1
