@@ -50,13 +50,16 @@ with open(os.path.join(dst, name + "_pmc.txt"), "w") as f:
     f.write("%-36s %-11s %6s %14s %14s %14s\n" % ("kernel", "counter", "n", "avg_KiB", "min_KiB", "max_KiB"))
     tot = collections.Counter()
     nsub = max(1, len(agg[("k_find_wall", "FETCH_SIZE")]))      # sub-batches in the run (the scan also runs in the roofline loop)
+    # scan launches per sub-batch: a sub-batch is scanned in launches of at most 2^31 positions (capi.hip: launch_scan)
+    sub_kmers = bench["roofline"]["working_set_bytes"] / 2.0 / max(1, bench["extras"].get("sub_batches_per_rank", 1))
+    scan_per_sub = max(1, int(round(sub_kmers / kmers)))
     for (k, c), v in sorted(agg.items()):
         if k.startswith("k_") and "_table" not in k and not k.startswith("k_sg_"):
             f.write("%-36s %-11s %6d %14.1f %14.1f %14.1f\n" % (k, c, len(v), sum(v) / len(v), min(v), max(v)))
-            tot[c] += sum(v) / len(v) if k == "k_scan_candidates" else sum(v) / nsub
-    f.write("# sum over the product kernels per sub-batch (%d sub-batches in the run; only the scan's FETCH_SIZE is\n" % nsub)
+            tot[c] += scan_per_sub * sum(v) / len(v) if k == "k_scan_candidates" else sum(v) / nsub
+    f.write("# sum over the product kernels per sub-batch (%d sub-batches in the run, %d scan launches each; only the scan's FETCH_SIZE is\n" % (nsub, scan_per_sub))
     f.write("# doubled: the x2 is calibrated for 16-B-per-lane streaming reads, the other kernels' access widths are not):\n")
-    scan_f = sum(agg[("k_scan_candidates", "FETCH_SIZE")]) / len(agg[("k_scan_candidates", "FETCH_SIZE")])
+    scan_f = scan_per_sub * sum(agg[("k_scan_candidates", "FETCH_SIZE")]) / len(agg[("k_scan_candidates", "FETCH_SIZE")])
     f.write("#   FETCH_SIZE %.0f KiB raw, %.0f KiB with the scan doubled; WRITE_SIZE %.0f KiB\n" % (tot["FETCH_SIZE"], tot["FETCH_SIZE"] + scan_f, tot["WRITE_SIZE"]))
 fs = agg[("k_scan_candidates", "FETCH_SIZE")]
 wsz = agg[("k_scan_candidates", "WRITE_SIZE")]
