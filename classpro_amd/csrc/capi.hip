@@ -759,6 +759,7 @@ extern "C" int cp_get_intervals(cp_workspace *ws, cp_intvl *intvl, cp_intvl *rin
       // `rintvl` comes back zeroed (run the stages up to CP_STAGE_CLASS_ALL for it)
       if (rintvl) memset(rintvl,0,bytes);
       if (intvl)
+        try
         { std::vector<uint32_t> pc((size_t)ws->totalI);
           std::vector<int64_t> off((size_t)ws->nreads+1);
           std::vector<int32_t> ni((size_t)ws->nreads);
@@ -784,6 +785,7 @@ extern "C" int cp_get_intervals(cp_workspace *ws, cp_intvl *intvl, cp_intvl *rin
                 I.asgn = (int8_t)CP_PCLS_CLS(pc[at]);
               }
         }
+        catch (const std::bad_alloc &) { return set_err(CP_ENOMEM,"cp_get_intervals: out of host memory"); }   // (never through the C ABI)
       return CP_OK;
     }
   if (rintvl && ws->last_stage >= CP_STAGE_REL) HIPCHK(hipMemcpy(rintvl,ws->rintvl.p,bytes,hipMemcpyDeviceToHost));
