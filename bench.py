@@ -541,6 +541,12 @@ def cpu_baseline(a, ds, batches, hcov, dcov):
     if a.no_cpu_ref or not ref_wall_available():
         port["sample"] += "; oracle/_ref (the reference's own functions) is not present on this box"
         return port
+    if mism:
+        # The reference exit(1)s on a read whose E-interval list overflows, and that would take this process and its JSON line
+        # with it.  The port returns instead (the read's labels stay unwritten = a mismatch), and its samples contain the
+        # reference's: any mismatch above means the reference legs are not run.
+        port["sample"] += "; reference-function legs skipped: the port's labels differ from the HIP result on this sample"
+        return port
 
     # ---- the reference's own functions.  (No read of the resident set makes the reference exit(1): the HIP path raises
     #      CP_EOVERFLOW at exactly its five abort sites -- tests/test_gpu_reference.py -- and cp_workspace_check above
