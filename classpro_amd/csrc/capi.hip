@@ -664,6 +664,10 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
   // slots per read), larger: the sequential kernel; the rare classes on the auxiliary stream again
   rc = launch_order_by_work(ws,(const int32_t *)ws->nintvl.p,nreads,0,(int32_t *)ws->perm.p,st,d_prof_off);
   if (rc != CP_OK) return rc;
+  // the second sweep re-evaluates only the intervals whose inputs changed since the first (kernels.hip);
+  // CLASSPRO_UNREL_SWEEP2=full: every one of them, as the reference does (same classes: tests, A/B)
+  const char *sw2_e = getenv("CLASSPRO_UNREL_SWEEP2");
+  const int full_sweep2 = (sw2_e && !strcmp(sw2_e,"full")) ? 1 : 0;
   HIPCHK(hipEventRecord(ws->ev_fork,st));
   HIPCHK(hipStreamWaitEvent(ws->aux,ws->ev_fork,0));
   hipLaunchKernelGGL(k_classify_unrel,dim3(nreads < 1024 ? nreads : 1024),dim3(WAVE),0,ws->aux,
@@ -671,16 +675,16 @@ extern "C" int cp_run_stages(const cp_params *p, cp_workspace *ws,
                      (int32_t *)ws->ord.p,(const int32_t *)ws->perm.p,d_prof_off,compact_rel ? (uint32_t *)ws->pcls.p : (uint32_t *)nullptr,soa);
   hipLaunchKernelGGL((k_classify_unrel_grp<UNREL_SMALL_MAXN,1024,UNREL_BIG_G,0>),dim3((nreads+UNREL_BIG_G-1)/UNREL_BIG_G < 2048 ? (nreads+UNREL_BIG_G-1)/UNREL_BIG_G : 2048),dim3(WAVE),0,ws->aux,
                      p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
-                     (const int32_t *)ws->perm.p,d_prof_off,compact_rel ? (uint32_t *)ws->pcls.p : (uint32_t *)nullptr,soa);
+                     (const int32_t *)ws->perm.p,d_prof_off,compact_rel ? (uint32_t *)ws->pcls.p : (uint32_t *)nullptr,soa,full_sweep2);
   HIPCHK(hipEventRecord(ws->ev_join,ws->aux));
   if (soa_on)
     hipLaunchKernelGGL((k_classify_unrel_grp<0,UNREL_SMALL_MAXN,UNREL_SMALL_G,1>),dim3((nreads+UNREL_SMALL_G-1)/UNREL_SMALL_G),dim3(WAVE),0,st,
                        p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
-                       (const int32_t *)ws->perm.p,d_prof_off,(uint32_t *)ws->pcls.p,soa);
+                       (const int32_t *)ws->perm.p,d_prof_off,(uint32_t *)ws->pcls.p,soa,full_sweep2);
   else
     hipLaunchKernelGGL((k_classify_unrel_grp<0,UNREL_SMALL_MAXN,UNREL_SMALL_G,0>),dim3((nreads+UNREL_SMALL_G-1)/UNREL_SMALL_G),dim3(WAVE),0,st,
                        p->dev,nreads,(cp_intvl *)ws->intvl.p,(const int64_t *)ws->ioff.p,(const int32_t *)ws->nintvl.p,
-                       (const int32_t *)ws->perm.p,d_prof_off,compact_rel ? (uint32_t *)ws->pcls.p : (uint32_t *)nullptr,soa);
+                       (const int32_t *)ws->perm.p,d_prof_off,compact_rel ? (uint32_t *)ws->pcls.p : (uint32_t *)nullptr,soa,full_sweep2);
   HIPCHK(hipStreamWaitEvent(st,ws->ev_join,0));
   HIPCHK(hipGetLastError());
   if (last_stage == CP_STAGE_CLASS_ALL)

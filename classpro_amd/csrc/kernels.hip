@@ -2306,7 +2306,9 @@ struct unrel_grp_lds
     int16_t  ord[G][MAXN];               // sorted index, bit 14 = fixed
     uint16_t key[G][MAXN+4];             // min(cb,ce), padded with 0xffff to a multiple of four (the sort reads four per load)
     uint64_t rel[G][2][MAXN/64];         // [0] reliable & H, [1] reliable & D
-    int16_t  mail_idx[G][8];             // interval and new class of each speculative slot of a round
+    uint64_t need[G][MAXN/64];           // second sweep: intervals whose inputs changed since the first sweep evaluated them
+    int16_t  mail_idx[G][8];             // interval, new class and order position of each speculative slot of a round
+    int16_t  mail_pos[G][8];
     int8_t   mail_s[G][8];
   };
 
@@ -2337,7 +2339,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(UNREL
 k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *__restrict__ intvl_all,
                      const int64_t *__restrict__ ioff, const int32_t *__restrict__ nintvl,
                      const int32_t *__restrict__ perm, const int64_t *__restrict__ prof_off, uint32_t *__restrict__ pcls_all,
-                     cp_soa soa)
+                     cp_soa soa, int full_sweep2)
 { // COMPACT (whole-path calls, main size class): the intervals come as arrays (cp_soa) -- 16 bytes per interval in the load
   // loop, the three log-probabilities from their own array when an update asks for them.  Without COMPACT but with soa.c
   // (the rare class on whole-path calls): the 48-byte records, the classes of classify_rel from the two-byte array.
@@ -2365,7 +2367,7 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
     { int x = __shfl_xor(maxN,o); maxN = x > maxN ? x : maxN; }
 
   for (int k = ql; k < MAXN/64; k += L)
-    { S.rel[g][0][k] = 0; S.rel[g][1][k] = 0; }
+    { S.rel[g][0][k] = 0; S.rel[g][1][k] = 0; S.need[g][k] = ~0ull; }
   wave_sync();
   for (int base = 0; base < maxN; base += L)               // load + bitsets, L intervals of every read per step
     { const int k = base+ql;
@@ -2442,19 +2444,49 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
   // lanes of a read take K consecutive updates at once (slots), and one lane then commits them in order:
   // a slot is committed only if no earlier slot of the round changed the class of one of its neighbours
   // or either set; otherwise the round ends there and the next one starts from that update.
+  //
+  // THE SECOND SWEEP ONLY RE-EVALUATES WHAT CAN HAVE CHANGED (round 5).  update_state(idx) is a function of the constant fields
+  // of interval idx, of "asgn == H" / "asgn == D" of its two neighbours (class_unrel.c:126,145) and of the nearest
+  // reliable-H / reliable-D interval on either side (find_nn_u, class_unrel.c:11-25) -- never of the interval's own
+  // class.  S.need holds a bit per interval: set at the start, cleared when the interval is evaluated, set again by a
+  // class change of j (old -> new) for j-1 and j+1 if old or new is H or D, and, if j is reliable and joins or leaves
+  // the H or the D set, for every interval between the nearest members of that set on either side of j (both
+  // included: the intervals whose nearest member on one side is or was j).  An interval whose bit is clear in the second
+  // sweep would get the class it has: it is skipped -- on reads like the bench's 95 % of that sweep
+  // (tests/test_unrel_memo.py runs this rule against the two plain sweeps on the host).  A round of the second sweep
+  // looks at the next L order positions, gives its K slots the first K whose bit is set, and ends behind a slot that
+  // changes a class (what lies behind may have been skipped on the strength of a bit that slot has just set).
   constexpr int K = L/8;
   const int sub = ql >> 3, role = ql & 7, sbase = gbase+sub*8;
   const int s2 = (role >> 2) & 1, side = (role >> 1) & 1, kind = role & 1;
   const int s = s2 ? CP_DIPLO : CP_HAPLO;
+  const uint64_t glm = (L == 64) ? ~0ull : ((1ull << L)-1);
   int pass = 0, it = 0;                                    // class_unrel.c:260-274, position of this read
   bool done = (N == 0) || (nnf == 0);
   while (__ballot(!done) != 0)
-      { const int myit = it+sub;
-        const bool act = !done && myit < nnf;              // this slot has an update to do
+      { int mypos = it+sub;                                // order position of this slot's update
+        int cover = (it+K < nnf) ? it+K : nnf;             // the round settles the positions [it, cover) if every slot commits
+        if (pass == 1)
+          { const int p = it+ql;
+            bool dirty = false;
+            if (!done && p < nnf)
+              { const int k = S.ord[g][p];
+                dirty = full_sweep2 || ((S.need[g][k >> 6] >> (k & 63)) & 1);     // (full_sweep2: the A/B and test knob CLASSPRO_UNREL_SWEEP2=full)
+              }
+            const uint64_t m = (__ballot(dirty) >> gbase) & glm;
+            uint64_t t = m;
+            for (int j = 0; j < sub; j++) t &= t-1;
+            mypos = t ? it+__ffsll((long long)t)-1 : nnf;
+            uint64_t t2 = m;
+#pragma unroll
+            for (int j = 0; j < K; j++) t2 &= t2-1;
+            cover = t2 ? it+__ffsll((long long)t2)-1 : ((it+L < nnf) ? it+L : nnf);
+          }
+        const bool act = !done && mypos < nnf;             // this slot has an update to do
         bool on = act;
         int idx = 0;
         if (act)
-          idx = S.ord[g][pass == 0 ? nnf-1-myit : myit];
+          idx = S.ord[g][pass == 0 ? nnf-1-mypos : mypos];
         int snew = -1;
         bool do_sf = false, do_bin = false;
         int tb = 0, te = 0, tcb = 0, tce = 0, tcov = 0, est = 0, c = 0;
@@ -2554,38 +2586,55 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
           }
         if (role == 0)
           { S.mail_idx[g][sub] = (int16_t)idx;
+            S.mail_pos[g][sub] = (int16_t)mypos;
             S.mail_s[g][sub] = (int8_t)(act ? snew : -1);
           }
         wave_sync();                                           // every slot has read the old state
-        int napplied = 0;
+        int newit = cover;
         if (ql == 0 && !done)                                  // commit the round's slots in order
           { bool sets_changed = false;
             int changed[K], nch = 0;
             for (int j = 0; j < K; j++)
               { const int sj = S.mail_s[g][j], ij = S.mail_idx[g][j];
-                if (sj < 0) break;                             // no update in this slot (end of the sweep)
+                if (sj < 0) break;                             // no update in this slot
                 bool clash = sets_changed;
                 for (int m = 0; m < nch; m++)
                   clash = clash || changed[m] == ij-1 || changed[m] == ij+1;
-                if (clash) break;                              // computed from a state an earlier slot changed
+                if (clash) { newit = S.mail_pos[g][j]; break; }        // computed from a state an earlier slot changed
                 const int old = S.asgn[g][ij];
+                S.need[g][ij >> 6] &= ~(1ull << (ij & 63));    // evaluated on the state as it is now
                 if (old != sj)
-                  { if (S.isrel[g][ij])
+                  { const bool ohd = old == CP_HAPLO || old == CP_DIPLO, nhd = sj == CP_HAPLO || sj == CP_DIPLO;
+                    if (ohd || nhd)                            // the neighbours' "asgn == s" tests
+                      { if (ij > 0)   S.need[g][(ij-1) >> 6] |= 1ull << ((ij-1) & 63);
+                        if (ij+1 < N) S.need[g][(ij+1) >> 6] |= 1ull << ((ij+1) & 63);
+                      }
+                    if (S.isrel[g][ij] && (ohd || nhd))
                       { const uint64_t bit = 1ull << (ij & 63);
-                        if (old == CP_HAPLO) { S.rel[g][0][ij >> 6] &= ~bit; sets_changed = true; }
-                        if (old == CP_DIPLO) { S.rel[g][1][ij >> 6] &= ~bit; sets_changed = true; }
-                        if (sj == CP_HAPLO)  { S.rel[g][0][ij >> 6] |= bit;  sets_changed = true; }
-                        if (sj == CP_DIPLO)  { S.rel[g][1][ij >> 6] |= bit;  sets_changed = true; }
+                        for (int q = 0; q < 2; q++)            // ij leaves / joins the reliable-H (q = 0) or the reliable-D set
+                          { const int sq = q ? CP_DIPLO : CP_HAPLO;
+                            if (old != sq && sj != sq) continue;
+                            int lo = bits_left(S.rel[g][q],ij), hi = bits_right(S.rel[g][q],ij,nwords);   // (ij's own bit plays no part)
+                            if (lo < 0) lo = 0;
+                            if (hi < 0) hi = N-1;
+                            for (int w = lo >> 6; w <= (hi >> 6); w++)
+                              { const uint64_t ml = (w == (lo >> 6)) ? (~0ull << (lo & 63)) : ~0ull;
+                                const uint64_t mh = (w == (hi >> 6)) ? (~0ull >> (63-(hi & 63))) : ~0ull;
+                                S.need[g][w] |= ml & mh;
+                              }
+                            if (old == sq) S.rel[g][q][ij >> 6] &= ~bit; else S.rel[g][q][ij >> 6] |= bit;
+                            sets_changed = true;
+                          }
                       }
                     S.asgn[g][ij] = (int8_t)sj;
-                    changed[nch++] = ij;
+                    if (ohd || nhd) changed[nch++] = ij;       // (a change among E, R and "no class yet" is no input of anybody's update)
+                    if (pass == 1 && (ohd || nhd)) { newit = S.mail_pos[g][j]+1; break; }   // positions behind it were skipped on bits this change may have set
                   }
-                napplied++;
               }
           }
-        napplied = __shfl(napplied,gbase);
+        newit = __shfl(newit,gbase);
         if (!done)
-          { it += napplied;
+          { it = newit;
             if (it >= nnf) { it = 0; pass++; if (pass == 2) done = true; }
           }
         wave_sync();

@@ -51,6 +51,8 @@ static void sort_e(cp_eintvl *v, int n)
     { if (a.b != b.b) return a.b < b.b; return a.e < b.e; });
 }
 
+static thread_local std::vector<cp_intvl> g_pre_unrel;
+
 // Sequential orchestration of the scalar device functions for one read (mirrors what the kernels do
 // with lanes).  Returns N or -1 on list overflow.
 int hh_classify_read(void *Pv, const char *seq, int rlen, const uint16_t *prof, char *labels,
@@ -114,6 +116,7 @@ int hh_classify_read(void *Pv, const char *seq, int rlen, const uint16_t *prof, 
       cp_rel_reconcile(fw,bw,M,hf,hb,asg.data());
       for (int r = 0; r < M; r++) { rintvl[r].asgn = asg[r]; intvl[relmap[r]].asgn = asg[r]; }
     }
+  g_pre_unrel.assign(intvl,intvl+N);                      // (for hh_unrel_memo: the records classify_unrel starts from)
   { std::vector<int> ord(N);
     std::vector<uint8_t> fixed(N);
     for (int i = 0; i < N; i++)
@@ -134,6 +137,75 @@ int hh_classify_read(void *Pv, const char *seq, int rlen, const uint16_t *prof, 
   return N;
 }
 
+// The records the last hh_classify_read on this thread handed to classify_unrel (classes of classify_rel in place).
+int hh_last_pre_unrel(cp_intvl *out, int cap)
+{ const int N = (int)g_pre_unrel.size();
+  if (N > cap) return -1;
+  if (N) memcpy(out,g_pre_unrel.data(),(size_t)N*sizeof(cp_intvl));
+  return N;
+}
+
+// The second sweep of classify_unrel with the RE-EVALUATION RULE of k_classify_unrel_grp (kernels.hip), sequentially:
+// update_state(idx) (class_unrel.c:192-236) is a pure function of the constant fields of interval idx, of
+// "asgn == H" / "asgn == D" of its two neighbours (class_unrel.c:126,145) and of the nearest reliable-H / reliable-D
+// interval on either side (find_nn_u, class_unrel.c:11-25) -- never of its own class.  So an interval whose inputs did
+// not change since its evaluation in the first sweep keeps its class in the second, and the evaluation can be skipped:
+//   need[k] = 1 at the start; an evaluation of k clears need[k]; a class change of j from `old` to `new`
+//     * sets need[j-1], need[j+1] if old or new is H or D (the neighbours' "asgn == s" tests),
+//     * if j is reliable, for s in {H,D} with old == s or new == s (j leaves / joins the set of find_nn_u): sets need[k]
+//       for every k from the nearest member of the set below j to the nearest member above j, both included (the
+//       intervals whose nearest member on one side is, or was, j).
+// Runs the plain two sweeps and the two sweeps with the rule on copies; intvl gets the classes of the form with the
+// rule; returns the number of intervals whose class differs between the two (0 if the rule is exact);
+// stats[0] = evaluations of the second sweep, stats[1] = those the rule skips, stats[2] = class changes in sweep 1,
+// stats[3] = class changes in sweep 2.
+int hh_unrel_memo(void *Pv, cp_intvl *intvl, int N, int64_t *stats)
+{ const cp_dev_params *P = (const cp_dev_params *)Pv;
+  std::vector<cp_intvl> A(intvl,intvl+N), B(intvl,intvl+N);
+  std::vector<int> ord(N);
+  std::vector<uint8_t> fixed(N), need(N,1);
+  for (int i = 0; i < N; i++)
+    { ord[i] = i;
+      fixed[i] = intvl[i].is_rel && (intvl[i].asgn == CP_HAPLO || intvl[i].asgn == CP_DIPLO);
+    }
+  std::stable_sort(ord.begin(),ord.end(),[&](int x, int y)
+    { int kx = intvl[x].cb < intvl[x].ce ? intvl[x].cb : intvl[x].ce;
+      int ky = intvl[y].cb < intvl[y].ce ? intvl[y].cb : intvl[y].ce;
+      return kx < ky; });
+  for (int i = N-1; i >= 0; i--) if (!fixed[ord[i]]) cp_update_state(P,ord[i],A.data(),N);
+  for (int i = 0; i < N; i++)    if (!fixed[ord[i]]) cp_update_state(P,ord[i],A.data(),N);
+  stats[0] = stats[1] = stats[2] = stats[3] = 0;
+  auto changed = [&](int j, int old, int nw)
+    { if (old == CP_HAPLO || old == CP_DIPLO || nw == CP_HAPLO || nw == CP_DIPLO)
+        { if (j > 0) need[j-1] = 1;
+          if (j+1 < N) need[j+1] = 1;
+        }
+      if (B[j].is_rel)
+        for (int s = CP_HAPLO; s <= CP_DIPLO; s++)
+          if (old == s || nw == s)
+            { int lo = j-1, hi = j+1;
+              while (lo >= 0 && !(B[lo].is_rel && B[lo].asgn == s)) lo--;
+              while (hi < N && !(B[hi].is_rel && B[hi].asgn == s)) hi++;
+              for (int k = (lo < 0 ? 0 : lo); k <= (hi >= N ? N-1 : hi); k++) need[k] = 1;
+            }
+    };
+  for (int pass = 0; pass < 2; pass++)
+    for (int t = 0; t < N; t++)
+      { const int idx = ord[pass == 0 ? N-1-t : t];
+        if (fixed[idx]) continue;
+        if (pass == 1)
+          { stats[0]++;
+            if (!need[idx]) { stats[1]++; continue; }
+          }
+        const int old = B[idx].asgn;
+        cp_update_state(P,idx,B.data(),N);
+        need[idx] = 0;
+        if (B[idx].asgn != old) { stats[2+pass]++; changed(idx,old,B[idx].asgn); }
+      }
+  int bad = 0;
+  for (int i = 0; i < N; i++) { bad += A[i].asgn != B[i].asgn; intvl[i].asgn = B[i].asgn; }
+  return bad;
+}
 
 int hh_kmer_hash(const char *seq, int j, int K) { return cp_kmer_hash(seq,j,K); }
 }

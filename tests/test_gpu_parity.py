@@ -688,6 +688,51 @@ def test_whole_path_compact_records_equal_full_records(torch_dev, ds_a, monkeypa
     assert out[0][0] == b"".join(O.classify_read(s_, p_) for s_, p_ in zip(seqs, profs))
 
 
+def test_second_sweep_rule_on_device(torch_dev, ds_a, monkeypatch):
+    """classify_unrel's second sweep re-evaluates only intervals whose inputs changed since the first (kernels.hip,
+    k_classify_unrel_grp; the rule itself: tests/test_unrel_memo.py).  CLASSPRO_UNREL_SWEEP2=full evaluates every one, as
+    class_unrel.c:267-274 does: the same labels and interval classes, and the oracle's, on generated, adversarial and
+    tail-run reads and on reads of the one-read-per-wave class (256 < N <= 1024), with full and with compact records."""
+    from classpro_amd.api import Classifier, Batch, STAGE_CLASS_ALL
+    from classpro_amd import synth
+    from oracle.oracle import Oracle
+    from adversarial import adversarial_reads, tail_run_reads
+    ds, h, d = ds_a
+    O = Oracle(K, 20000, h, d)
+    seqs, profs = list(ds["seqs"][:60]), list(ds["profiles"][:60])
+    a_s, a_p = adversarial_reads(41, n=160)
+    t_s, t_p = tail_run_reads(42, n=60)
+    big = synth.make_dataset(genome_len=300000, cov=40, read_len=50000, seed=19, het=0.004, err_sub=0.002, err_indel=0.002, min_len=30000)
+    for s_, p_ in zip(a_s + t_s + list(big["seqs"][:10]), a_p + t_p + list(big["profiles"][:10])):
+        try:
+            O.classify_read(s_, p_)
+        except OverflowError:
+            continue
+        seqs.append(s_); profs.append(p_)
+    want = b"".join(O.classify_read(s_, p_) for s_, p_ in zip(seqs, profs))
+    out = []
+    for sweep2 in (None, "full"):
+        for compact in (None, "0"):
+            for name, v in (("CLASSPRO_UNREL_SWEEP2", sweep2), ("CLASSPRO_COMPACT_REL", compact)):
+                if v is None:
+                    monkeypatch.delenv(name, raising=False)
+                else:
+                    monkeypatch.setenv(name, v)
+            clf = Classifier(K, 20000, h, d)
+            b = Batch.from_reads(seqs, profs)
+            lab = clf.classify(b).tobytes()
+            clf.run(b, STAGE_CLASS_ALL)
+            clf.check()
+            ivs = clf.intervals(b)
+            out.append((lab, b"".join(iv["asgn"].tobytes() for iv, _ in ivs)))
+            clf.close()
+    monkeypatch.delenv("CLASSPRO_UNREL_SWEEP2", raising=False)
+    monkeypatch.delenv("CLASSPRO_COMPACT_REL", raising=False)
+    assert max(len(iv) for iv, _ in ivs) > 256
+    assert all(o == out[0] for o in out[1:])
+    assert out[0][0] == want
+
+
 def test_fuzz_regressions(torch_dev):
     """Reads that the fuzz soak (scripts/fuzz_parity.py) once found different.  fuzz305_34: classify_unrel's argmax meets
     log(px*py) against log(px)+log(py); with ocml's log the device said E where the oracle (glibc) says D."""
