@@ -1333,11 +1333,23 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   int32_t *olist = wl, *compB = wl+2*(int64_t)icap, *compE = compB+(icap >> 1), *bnd = wl+3*(int64_t)icap;
   const int ccap = icap >> 1;                           // components <= candidates+1 <= icap/2
   int midx = NS;
+  // Most O-only walls are haplotype boundaries, not errors: cp_wall_mult (wall.c:763-860) does nothing at all for a wall
+  // whose SELF-pass P(error) is below the threshold for both the DROP and the GAIN reading (wall.c:765, 808) -- and nothing
+  // writes the memo in this phase -- so the lanes look the two entries up for all walls at once and only the walls that
+  // pass are taken one by one (the whole wave went through every wall, two dependent memo probes and a barrier each).
+  auto mult_live = [&](int i) -> bool
+    {
+#ifdef CP_NO_MULT_PREFILTER                              // (A/B build: every O-only wall is taken, as before)
+      (void)i; return true;
+#else
+      return !(CP_PERR(&R,i,CP_SELF,CP_DROP) < CP_PE_THRES_FINAL) || !(CP_PERR(&R,i,CP_SELF,CP_GAIN) < CP_PE_THRES_FINAL);
+#endif
+    };
   if (cf)                                              // the O-only walls are met candidate by candidate, in order
     { PH_STAMP(2);
       for (int base = 0; base < n_c; base += WAVE)
         { const int q = base+lane;
-          const uint64_t m = __ballot(q < n_c && (F.fo[q] & CP_W_WALL_O) && !(F.fs[q] & CP_W_WALL_S));
+          const uint64_t m = __ballot(q < n_c && (F.fo[q] & CP_W_WALL_O) && !(F.fs[q] & CP_W_WALL_S) && mult_live(F.pos[q]));
           for (uint64_t t = m; t; t &= t-1)
             { const int qq = base+__ffsll((long long)t)-1;
               wave_sync();                             // lane 0's flag updates of the previous wall
@@ -1354,7 +1366,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
           int i = 0; bool keep = false;
           if (q < n_c)
             { i = clist[q];
-              keep = (wall[i] & CP_W_WALL_O) && !(wall_s[i] & CP_W_WALL_S);
+              keep = (wall[i] & CP_W_WALL_O) && !(wall_s[i] & CP_W_WALL_S) && mult_live(i);
             }
           const uint64_t m = __ballot(keep);
           if (keep)
