@@ -2315,8 +2315,9 @@ struct unrel_grp_lds
   { static_assert(MAXN % 64 == 0,"the reliable-interval bitsets are whole 64-bit words"); uint16_t b[G][MAXN], e[G][MAXN], cb[G][MAXN], ce[G][MAXN], ccb[G][MAXN], cce[G][MAXN];
     int8_t   asgn[G][MAXN];
     uint8_t  isrel[G][MAXN];
-    int16_t  ord[G][MAXN];               // sorted index, bit 14 = fixed
-    uint16_t key[G][MAXN+4];             // min(cb,ce), padded with 0xffff to a multiple of four (the sort reads four per load)
+    typedef typename std::conditional<(MAXN > 256),uint32_t,uint16_t>::type ord_t;
+    ord_t    ord[G][MAXN];               // the non-fixed intervals in index order, their rank in the high bits (scratch of the sort)
+    uint16_t key[G][MAXN+4];             // min(cb,ce) of those, padded with 0xffff to a multiple of four (the sort reads four per load); then: the order
     uint64_t rel[G][2][MAXN/64];         // [0] reliable & H, [1] reliable & D
     uint64_t need[G][MAXN/64];           // second sweep: intervals whose inputs changed since the first sweep evaluated them
     int16_t  mail_idx[G][8];             // interval, new class and order position of each speculative slot of a round
@@ -2409,40 +2410,48 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
         }
     }
   wave_sync();
-  // stable sort by min(cb,ce), class_unrel.c:252-258: rank = keys below mine + equal keys before me.  The keys go to LDS
-  // once, padded to a multiple of four with 0xffff (above every count), and a lane compares four per 8-byte load (the
-  // first form recomputed min(cb,ce) from two loads per comparison: a quarter of this kernel's instructions were this loop).
-  for (int k = ql; k < ((N+3) & ~3); k += L)
-    S.key[g][k] = (k < N) ? (S.cb[g][k] < S.ce[g][k] ? S.cb[g][k] : S.ce[g][k]) : (uint16_t)0xffff;
-  wave_sync();
-  for (int k = ql; k < N; k += L)
-    { const unsigned key = S.key[g][k];
-      int rank = 0;
-      for (int m = 0; m < N; m += 4)
-        { const uint2 q = *reinterpret_cast<const uint2 *>(&S.key[g][m]);
-          const unsigned k0 = q.x & 0xffffu, k1 = q.x >> 16, k2 = q.y & 0xffffu, k3 = q.y >> 16;
-          rank += (k0 < key || (k0 == key && m   < k)) ? 1 : 0;
-          rank += (k1 < key || (k1 == key && m+1 < k)) ? 1 : 0;
-          rank += (k2 < key || (k2 == key && m+2 < k)) ? 1 : 0;
-          rank += (k3 < key || (k3 == key && m+3 < k)) ? 1 : 0;
-        }
-      int fixed = (S.isrel[g][k] && (S.asgn[g][k] == CP_HAPLO || S.asgn[g][k] == CP_DIPLO)) ? 1 : 0;
-      S.ord[g][rank] = (int16_t)(k | (fixed << 14));
-    }
-  wave_sync();
-  int nnf = 0;                                             // keep only the non-fixed intervals, order preserved: L at a time,
-  for (int base = 0; base < maxN; base += L)               // every lane placing its own (a target never lies beyond its source)
+  // The order of the updates (class_unrel.c:246-258): a stable sort of ALL intervals by min(cb,ce), of which the loops then
+  // skip the fixed ones.  The same order from less work (round 5): the non-fixed intervals first, in index order (ballot +
+  // popcount, L at a time), then a stable rank sort of those alone -- rank = keys below mine + equal keys before me, the
+  // keys in LDS padded to a multiple of four with 0xffff (above every count), four per 8-byte load -- nnf^2 comparisons
+  // instead of N^2 with nnf about 0.4 N.  The rank goes into the high bits of the entry, then the entries go to their
+  // places in the key array's storage, which holds the order from here on (S_ORD).
+  constexpr int RSH = (MAXN > 256) ? 16 : 8;
+  int nnf = 0;
+  for (int base = 0; base < maxN; base += L)
     { const int i = base+ql;
-      int16_t oi = 0;
-      bool keep = false;
-      if (i < N) { oi = S.ord[g][i]; keep = !(oi & (1 << 14)); }
+      const bool keep = i < N && !(S.isrel[g][i] && (S.asgn[g][i] == CP_HAPLO || S.asgn[g][i] == CP_DIPLO));
       const uint64_t lm = (L == 64) ? ~0ull : ((1ull << L)-1);
       const uint64_t mk = (__ballot(keep) >> gbase) & lm;
-      wave_sync();
-      if (keep) S.ord[g][nnf+__popcll(mk & ((1ull << ql)-1))] = oi;
+      if (keep) S.ord[g][nnf+__popcll(mk & ((1ull << ql)-1))] = (typename unrel_grp_lds<MAXN,G>::ord_t)i;
       nnf += __popcll(mk);
-      wave_sync();
     }
+  wave_sync();
+  for (int j = ql; j < ((nnf+3) & ~3); j += L)
+    { uint16_t key = 0xffff;
+      if (j < nnf) { const int k = S.ord[g][j]; key = S.cb[g][k] < S.ce[g][k] ? S.cb[g][k] : S.ce[g][k]; }
+      S.key[g][j] = key;
+    }
+  wave_sync();
+  for (int j = ql; j < nnf; j += L)
+    { const unsigned key = S.key[g][j];
+      int rank = 0;
+      for (int m = 0; m < nnf; m += 4)
+        { const uint2 q = *reinterpret_cast<const uint2 *>(&S.key[g][m]);
+          const unsigned k0 = q.x & 0xffffu, k1 = q.x >> 16, k2 = q.y & 0xffffu, k3 = q.y >> 16;
+          rank += (k0 < key || (k0 == key && m   < j)) ? 1 : 0;
+          rank += (k1 < key || (k1 == key && m+1 < j)) ? 1 : 0;
+          rank += (k2 < key || (k2 == key && m+2 < j)) ? 1 : 0;
+          rank += (k3 < key || (k3 == key && m+3 < j)) ? 1 : 0;
+        }
+      S.ord[g][j] = (typename unrel_grp_lds<MAXN,G>::ord_t)((unsigned)S.ord[g][j] | ((unsigned)rank << RSH));
+    }
+  wave_sync();                                             // every rank is computed: the key array is free
+  for (int j = ql; j < nnf; j += L)
+    { const unsigned v = S.ord[g][j];
+      S.key[g][v >> RSH] = (uint16_t)(v & ((1u << RSH)-1));
+    }
+#define S_ORD(p) ((int)S.key[g][p])
   nnf = __shfl(nnf,gbase);
   int maxNF = nnf;
   for (int o = 32; o > 0; o >>= 1)
@@ -2482,7 +2491,7 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
           { const int p = it+ql;
             bool dirty = false;
             if (!done && p < nnf)
-              { const int k = S.ord[g][p];
+              { const int k = S_ORD(p);
                 dirty = full_sweep2 || ((S.need[g][k >> 6] >> (k & 63)) & 1);     // (full_sweep2: the A/B and test knob CLASSPRO_UNREL_SWEEP2=full)
               }
             const uint64_t m = (__ballot(dirty) >> gbase) & glm;
@@ -2498,7 +2507,7 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
         bool on = act;
         int idx = 0;
         if (act)
-          idx = S.ord[g][pass == 0 ? nnf-1-mypos : mypos];
+          idx = S_ORD(pass == 0 ? nnf-1-mypos : mypos);
         int snew = -1;
         bool do_sf = false, do_bin = false;
         int tb = 0, te = 0, tcb = 0, tce = 0, tcov = 0, est = 0, c = 0;
