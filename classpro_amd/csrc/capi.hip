@@ -1129,6 +1129,13 @@ extern "C" int cp_debug_seed_prof(unsigned long long *out8)
 }
 #endif
 #ifdef CP_PROF_WALK
+// diagnostic builds only: per read (candidates, tasks, SELF tasks, overflow) as k_wall_tasks left them (scripts/count_dist.py)
+extern "C" int cp_debug_task_counts(cp_workspace *ws, int32_t *out, int64_t nreads)
+{ if (!ws || nreads > ws->nreads) return set_err(CP_EINVAL,"cp_debug_task_counts: bad arguments");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out,ws->fwc.p,(size_t)nreads*4*sizeof(int32_t),hipMemcpyDeviceToHost));
+  return CP_OK;
+}
 // diagnostic builds only: per-phase wave times of k_find_wall (max / sum / arg-max over reads), then reset
 extern "C" int cp_debug_live_prof(unsigned long long *out8)
 { HIPCHK(hipDeviceSynchronize());
