@@ -1695,7 +1695,12 @@ k_find_rel(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, co
 //  independent until the reconciliation), DP cells in registers/private memory, 5 B of HBM scratch
 //  per (interval, direction).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WAVE)
+// (128 registers, the rest in scratch: this is the slow path whatever it holds, and a wave of 203 registers -- what the
+//  compiler takes when left alone -- only starts where TWO of the main class's 128-register waves have left a SIMD: beside
+//  the main class its 1024 waves, nearly all of which leave after two loads, took 1.8-2.7 ms to get on and off the machine;
+//  now 0.15.  The stage is no shorter for it -- the next kernel on the auxiliary stream waits for its holes instead,
+//  profiles/r05_rare_classes.txt -- but 1024 fat waves no longer queue for the register file.)
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4)))
 k_classify_rel(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ prof_off, int nreads,
                cp_intvl *__restrict__ intvl_all, cp_intvl *__restrict__ rintvl_all, const int32_t *__restrict__ relmap_all,
                const int64_t *__restrict__ ioff, const int32_t *__restrict__ nrel,
