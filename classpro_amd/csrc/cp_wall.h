@@ -735,14 +735,17 @@ CP_HD int cp_sum_steps(const PROF &prof, int lo, int hi, int plen, int sgn)
 { int acc = 0, i = lo;
   if (lo >= hi) return 0;
   int prev = prof[lo];
-  while (i+8 <= hi && i+8 < plen)
+  // (a last group of fewer than eight steps takes one wide load as well, of which it uses what it needs, while the eight
+  //  counts lie inside the read: K-1 = 39 steps were four wide loads and SEVEN single ones, each a round trip of its own)
+  while (i < hi && i+8 < plen)
     { const cp_u16x8 x = cp_load_u16x8(prof,i+1);
+      const int n = hi-i;                                 // steps still wanted (>= 8: all of the group)
 #ifdef __HIPCC__
 #pragma unroll
 #endif
       for (int q = 0; q < 8; q++)
         { const int cur = x.v[q], d = sgn*(cur-prev);
-          if (d > 0) acc += d;
+          if (q < n && d > 0) acc += d;
           prev = cur;
         }
       i += 8;
