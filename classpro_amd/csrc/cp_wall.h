@@ -763,6 +763,10 @@ CP_HD int cp_sum_steps(const PROF &prof, int lo, int hi, int plen, int sgn)
 // its index equals its start position (SURVEY.md hazard 2); that case is applied explicitly.
 // seq_b / seq_e: the read's bases as seen by the context scan after the interval's begin / before its end (the same
 // pointer on the host; on the device two short LDS windows backed by the pointer, kernels.hip).
+// The view of the read's bases that the scans around position `pos` use (dir = +1: they go right of it, -1: left): the
+// view itself for plain pointers and LDS windows; kernels.hip's cp_seq_rsrc answers with sixteen bases in registers.
+template <class S> CP_HD const S &cp_seq_window(const S &s, int, int, int) { return s; }
+
 template <class PROF, class SEQB, class SEQE>
 CP_HD bool cp_rel_interval(const cp_dev_params *P, const PROF &prof, const SEQB &seq_b, const SEQE &seq_e, int rlen,
                            cp_intvl *I, int idx)
@@ -773,6 +777,8 @@ CP_HD bool cp_rel_interval(const cp_dev_params *P, const PROF &prof, const SEQB 
     return false;
   if (I->pe >= P->log_pe_final)                          // cp_log(PE_THRES[FINAL][SELF]), wall.c:1018
     return false;
+  const auto wseq_b = cp_seq_window(seq_b,I->b+K-1,rlen,+1);   // rctx scans start here and go right (and a little to the left)
+  const auto wseq_e = cp_seq_window(seq_e,I->e-1,rlen,-1);     // lctx scans start here and go left
 
   int first, last, n_gain = 0, n_drop = 0, lmax;
   const int plen = rlen-(K-1);
@@ -781,7 +787,7 @@ CP_HD bool cp_rel_interval(const cp_dev_params *P, const PROF &prof, const SEQB 
   if (I->b+K-1 < I->e)
     { lmax = 0;
       for (int t = 0; t < 3; t++)
-        { int l = cp_rctx(seq_b,rlen,I->b+K-1,t)*(t+1);
+        { int l = cp_rctx(wseq_b,rlen,I->b+K-1,t)*(t+1);
           if (lmax < l) lmax = l;
         }
       last = I->b+lmax;
@@ -792,7 +798,7 @@ CP_HD bool cp_rel_interval(const cp_dev_params *P, const PROF &prof, const SEQB 
   if (I->b < I->e-K+1)
     { lmax = 0;
       for (int t = 0; t < 3; t++)
-        { int l = cp_lctx(seq_e,rlen,(I->e-K+1)+K-2,t)*(t+1); // ctx[DROP][e-K+1]
+        { int l = cp_lctx(wseq_e,rlen,(I->e-K+1)+K-2,t)*(t+1); // ctx[DROP][e-K+1]
           if (lmax < l) lmax = l;
         }
       first = I->e-lmax;

@@ -846,6 +846,40 @@ __device__ __forceinline__ void fw_seq_win_load(cp_seq_lwin &sq, char *row, int 
   sq.lo = lo; sq.len = len;
 }
 
+// Sixteen bases around a position IN REGISTERS (round 5): the context scans of correct_wall_cnt inside k_find_wall's
+// emission loop (cp_rel_interval) read a handful of bases right of b+K-1 and left of e-1; from the global pointer every
+// one of them was a load of its own in a loop that waits for it (k_find_wall has no LDS left for windows like k_find_rel's).
+// One 16-byte load per side instead; a base outside the sixteen is read from the read as before.  dir = +1: the
+// window starts four bases before the position, -1: it ends four bases after it.
+struct cp_seq_rwin
+  { CP_SEQ_T g;
+    uint64_t wl, wh;                                       // bases lo .. lo+7, lo+8 .. lo+15
+    int lo, len;
+    __device__ __forceinline__ char operator[](int p) const
+    { const unsigned d = (unsigned)(p-lo);
+      if (d < (unsigned)len)                               // (one select and a 64-bit shift: a chain of four 32-bit selects the
+        { const uint64_t x = (d < 8) ? wl : wh;            //  compiler turns into an indexed load from a copy in scratch)
+          return (char)(x >> ((d & 7)*8));
+        }
+      return g[p];
+    }
+  };
+struct cp_seq_rsrc { CP_SEQ_T g; };                        // "make me a register window": what k_find_wall hands to cp_rel_interval
+__device__ __forceinline__ cp_seq_rwin cp_seq_window(const cp_seq_rsrc &src, int pos, int rlen, int dir)
+{ cp_seq_rwin sq;
+  int lo = dir > 0 ? pos-4 : pos-11;
+  if (lo > rlen-16) lo = rlen-16;
+  if (lo < 0) lo = 0;
+  sq.g = src.g; sq.lo = lo; sq.len = 0; sq.wl = sq.wh = 0;
+  if (rlen-lo >= 16)
+    { const cp_u8x16 x = *reinterpret_cast<const cp_u8x16 *>(CP_SPAN(src.g,lo,16));
+      sq.wl = (uint64_t)x.v[0] | ((uint64_t)x.v[1] << 32);
+      sq.wh = (uint64_t)x.v[2] | ((uint64_t)x.v[3] << 32);
+      sq.len = 16;
+    }
+  return sq;
+}
+
 #define FR_STRIDE 68                 // k_find_rel: two 32-base windows per lane, 17 dwords apart
 __device__ __forceinline__ void fr_seq_win_load(cp_seq_lwin &sq, char *row, int lo, int rlen)
 { if (lo > rlen-32) lo = rlen-32;
@@ -1579,7 +1613,8 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
           { const int b0 = k ? (smallc ? (int)s_bnd[k-1] : bnd[k-1]) : 0, e0 = smallc ? (int)s_bnd[k] : bnd[k];
             cp_make_interval(&R,NS,b0,e0,&I);
             if (do_rel)
-              { ok = cp_rel_interval(P,R.prof,R.seq,R.seq,rlen,&I,k);
+              { cp_seq_rsrc rs; rs.g = R.seq;
+                ok = cp_rel_interval(P,R.prof,rs,rs,rlen,&I,k);
                 I.is_rel = ok ? 1 : 0;
               }
             if (aos) intvl[k] = I;
