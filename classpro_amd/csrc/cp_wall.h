@@ -670,9 +670,9 @@ CP_HD void cp_wall_mult(RD *R, int i, int NS, int *midx)
 // The reference bounds both loops by NS while NS grows with every appended union, so the scan runs on
 // into the entries it has just appended (which are not in sorted position); reproduced literally.
 template <class RD>
-CP_HD int cp_merge_eintvl(RD *R, int NS)
+CP_HD int cp_merge_eintvl(RD *R, int NS, int i0 = 0)     // i0: where the scan starts (kernels.hip does the chains before that in parallel)
 { auto &ev = R->eintvl;
-  int i = 0, j;
+  int i = i0, j;
   while (i < NS-1)
     { int    max_e  = ev.e(i);
       double max_pe = ev.pe(i);

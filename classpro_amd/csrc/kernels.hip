@@ -1428,8 +1428,47 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
     { NS = midx;
       wave_sort_ev(R.eintvl,NS,R.ointvl.g,false);
     }
-  if (lane == 0)                                       // wall.c:878-909
-    NS = cp_merge_eintvl(&R,NS);
+  // wall.c:878-909: runs of intervals each of which begins inside its predecessor are united, the unions appended.  The
+  // reference's scan is bounded by the GROWING length, so the run that holds the last interval goes on into the unions
+  // appended before it (cp_merge_eintvl's header); every run before that one is what it looks like in the sorted list.
+  // Those runs are found by all lanes at once (a lane per interval: "my successor begins inside me", one ballot) and
+  // united by the lane of their first interval, the unions appended in order; one lane then scans on from the first
+  // interval of the last run, as the reference does from there.  (One lane used to walk the whole list, four dependent
+  // LDS reads per interval, while 63 waited.)  Lists beyond 64 intervals or close to a capacity take the one-lane scan.
+  int merge_from = 0;
+  if (!R.eintvl.big && NS >= 2 && NS <= WAVE)
+    { cp_eintvl x = { 0, 0, 0. };
+      if (lane < NS) x = R.eintvl.l[lane];
+      const int b_next = __shfl_down(x.b,1);
+      const bool link = lane < NS-1 && b_next <= x.e;      // interval lane+1 continues the run of interval lane
+      const uint64_t Lm = __ballot(link);
+      const bool head = lane < NS && (lane == 0 || !((Lm >> (lane-1)) & 1));
+      const uint64_t Hm = __ballot(head);
+      const int hl = 63-__clzll((long long)Hm);            // first interval of the run that holds the last interval
+      const uint64_t Mm = __ballot(head && link && lane != hl);
+      const int m1 = __popcll(Mm);
+      int lim = R.ecap < plen ? R.ecap : plen;
+      if (lim > FW_EVL) lim = FW_EVL;
+      if (NS+2*(m1+1) < lim)                               // (every append of the scan stays below the capacities: no overflow path, the list stays on chip)
+        { if ((Mm >> lane) & 1)
+            { const int last = lane+__ffsll((long long)~(Lm >> lane))-1;     // the run is lane .. last
+              int max_e = x.e;
+              double max_pe = x.pe;
+              for (int k = lane+1; k <= last; k++)
+                { const cp_eintvl y = R.eintvl.l[k];
+                  if (max_e < y.e) max_e = y.e;
+                  if (!(max_pe > y.pe)) max_pe = y.pe;
+                }
+              cp_eintvl u; u.b = x.b; u.e = max_e; u.pe = max_pe;
+              R.eintvl.l[NS+__popcll(Mm & ((1ull << lane)-1))] = u;
+            }
+          NS += m1;
+          merge_from = hl;
+          wave_sync();
+        }
+    }
+  if (lane == 0)
+    NS = cp_merge_eintvl(&R,NS,merge_from);
   NS = __shfl(NS,0);
   overflow |= __shfl(R.overflow,0);
   R.eintvl.big = __shfl(R.eintvl.big,0);               // lane 0's appends may have moved the list to HBM
