@@ -505,6 +505,48 @@ __device__ int wave_sort_ev_lds(CP_LDS_PTR(cp_eintvl) v, int n, bool dedupe)
   return __popcll(m0)+__popcll(m1);
 }
 
+// The same order when the first ns elements are in order already and only a few were appended behind them (the sorts
+// after the multi-error search and after the merge, wall.c:875,910): an element of the sorted part moves up by the
+// number of appended elements that sort before it; an appended element goes behind the elements of the sorted part
+// that are not after it (a binary search; ties keep insertion order, and the sorted part was inserted first) and behind
+// the appended elements before it.  n - ns steps per lane instead of n.
+__device__ int wave_sort_ev_lds_tail(CP_LDS_PTR(cp_eintvl) v, int n, int ns)
+{ const int lane = lane_id();
+  cp_eintvl x0 = { 0, 0, 0. }, x1 = { 0, 0, 0. };
+  if (lane < n) x0 = v[lane];
+  if (lane+WAVE < n) x1 = v[lane+WAVE];
+  auto rank_of = [&](const cp_eintvl &x, int idx) -> int
+    { int r;
+      if (idx < ns)
+        { r = idx;
+          for (int a = ns; a < n; a++)
+            { const cp_eintvl y = v[a];
+              r += (y.b != x.b ? y.b < x.b : y.e < x.e) ? 1 : 0;       // strictly before: on a tie the sorted part's element stays in front
+            }
+        }
+      else
+        { int lo = 0, hi = ns;                             // elements of the sorted part that are not after x
+          while (lo < hi)
+            { const int m = (lo+hi) >> 1;
+              const cp_eintvl y = v[m];
+              if (y.b != x.b ? y.b < x.b : y.e <= x.e) lo = m+1; else hi = m;
+            }
+          r = lo;
+          for (int a = ns; a < n; a++)
+            { const cp_eintvl y = v[a];
+              r += cp_eintvl_before(y,a,x,idx) ? 1 : 0;
+            }
+        }
+      return r;
+    };
+  const int r0 = (lane < n) ? rank_of(x0,lane) : 0, r1 = (lane+WAVE < n) ? rank_of(x1,lane+WAVE) : 0;
+  wave_sync();
+  if (lane < n) v[r0] = x0;
+  if (lane+WAVE < n) v[r1] = x1;
+  wave_sync();
+  return n;
+}
+
 // the same on an HBM list: rank sort into tmp, then a copy / an ordered compaction back into v
 __device__ int wave_sort_ev_hbm(cp_eintvl *v, int n, cp_eintvl *tmp, bool dedupe)
 { if (n < 2) return n;
@@ -534,8 +576,13 @@ __device__ int wave_sort_ev_hbm(cp_eintvl *v, int n, cp_eintvl *tmp, bool dedupe
   return out;
 }
 
-__device__ __forceinline__ int wave_sort_ev(fw_evl &ev, int n, cp_eintvl *tmp, bool dedupe)
-{ return ev.big ? wave_sort_ev_hbm(ev.g,n,tmp,dedupe) : wave_sort_ev_lds(ev.l,n,dedupe); }
+// ns: the first ns elements are known to be in order (0: nothing is known)
+__device__ __forceinline__ int wave_sort_ev(fw_evl &ev, int n, cp_eintvl *tmp, bool dedupe, int ns = 0)
+{ if (ev.big) return wave_sort_ev_hbm(ev.g,n,tmp,dedupe);
+  if (!dedupe && ns > 0 && n >= 2 && n-ns <= 16)
+    return n == ns ? n : wave_sort_ev_lds_tail(ev.l,n,ns);
+  return wave_sort_ev_lds(ev.l,n,dedupe);
+}
 
 // wall.c:722-731 / 868-872: clear WALL_O at every position strictly inside one of the E-intervals ev[lo..hi).
 // OTHERS walls only exist at candidate positions, so the lanes test the candidates instead of sweeping
@@ -1425,9 +1472,11 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   if (cf) cf_unwall_inside(F,R.eintvl,NS,midx);        // wall.c:868-872
   else    wave_unwall_inside(wall,clist,n_c,R.eintvl,NS,midx,sbuf,SBUF/2);
   if (NS < midx)                                       // wall.c:873-876
-    { NS = midx;
-      wave_sort_ev(R.eintvl,NS,R.ointvl.g,false);
+    { const int ns_sorted = NS;
+      NS = midx;
+      wave_sort_ev(R.eintvl,NS,R.ointvl.g,false,ns_sorted);
     }
+  const int ns_before_merge = NS;
   // wall.c:878-909: runs of intervals each of which begins inside its predecessor are united, the unions appended.  The
   // reference's scan is bounded by the GROWING length, so the run that holds the last interval goes on into the unions
   // appended before it (cp_merge_eintvl's header); every run before that one is what it looks like in the sorted list.
@@ -1473,7 +1522,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   overflow |= __shfl(R.overflow,0);
   R.eintvl.big = __shfl(R.eintvl.big,0);               // lane 0's appends may have moved the list to HBM
   wave_sync();
-  wave_sort_ev(R.eintvl,NS,R.ointvl.g,false);          // wall.c:910
+  wave_sort_ev(R.eintvl,NS,R.ointvl.g,false,ns_before_merge);   // wall.c:910 (the merge only appended)
   PH_STAMP(4);
 
   // ---- interval boundaries (wall.c:917-948) without per-position passes -----------------------
