@@ -1400,11 +1400,38 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
         miss = miss || cf_find(F,R.eintvl.b(k)) < 0 || cf_find(F,R.eintvl.e(k)) < 0;
       cf = __ballot(miss) == 0;
     }
-  if (cf) cf_unwall_inside(F,R.eintvl,0,NS);
+  // With the flags on chip and a list of at most 64 intervals the sort (wall.c:734) comes first -- neither step reads what
+  // the other writes, and the duplicates the sort drops cover nothing their twins do not -- and "strictly inside one of
+  // the intervals" is then a binary search: with the intervals in order of their begins, position i lies inside one iff
+  // the largest end among the intervals that begin before i exceeds i (a prefix maximum over the lanes, one interval
+  // each).  Every candidate used to test every interval (45 of them, two LDS reads each, and most candidates lie in none).
+  bool unwalled = false;
+  if (cf && !R.eintvl.big && NS <= WAVE)
+    { NS = wave_sort_ev(R.eintvl,NS,R.ointvl.g,true);
+      int b_k = 0x7fffffff, pm = -1;
+      if (lane < NS) { b_k = R.eintvl.l[lane].b; pm = R.eintvl.l[lane].e; }
+      for (int o = 1; o < WAVE; o <<= 1) { const int y = __shfl_up(pm,o); if (lane >= o && y > pm) pm = y; }
+      for (int base = 0; base < n_c; base += WAVE)         // (every lane takes part in the shuffles)
+        { const int q = base+lane;
+          int below = 0, i = 0;
+          const bool test = q < n_c && (F.fo[q] & CP_W_WALL_O);
+          if (test)
+            { i = F.pos[q];
+              int lo = 0, hi = NS;                         // intervals that begin before i
+              while (lo < hi) { const int m = (lo+hi) >> 1; if (R.eintvl.l[m].b < i) lo = m+1; else hi = m; }
+              below = lo;
+            }
+          const int pmax = __shfl(pm,below > 0 ? below-1 : 0);
+          if (test && below > 0 && pmax > i) F.fo[q] &= (uint8_t)~CP_W_WALL_O;
+        }
+      wave_sync();
+      unwalled = true;
+    }
+  else if (cf) cf_unwall_inside(F,R.eintvl,0,NS);
   else    wave_unwall_inside(wall,clist,n_c,R.eintvl,0,NS,sbuf,SBUF/2);
 
   // ---- sort + dedupe E-intervals (wall.c:734); the O list is not used again ------------------
-  NS = wave_sort_ev(R.eintvl,NS,R.ointvl.g,true);
+  if (!unwalled) NS = wave_sort_ev(R.eintvl,NS,R.ointvl.g,true);
 
   // ---- multi-error / boundary E-intervals (wall.c:760-861) -----------------------------------
   // The reference scans every position for O-only walls; OTHERS walls are only ever set at wall
