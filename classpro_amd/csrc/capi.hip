@@ -1144,6 +1144,13 @@ extern "C" int cp_debug_live_prof(unsigned long long *out8)
   HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_live_prof),z,sizeof(z)));
   return CP_OK;
 }
+extern "C" int cp_debug_emit_prof(unsigned long long *out8)
+{ HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out8,HIP_SYMBOL(g_emit_prof),8*sizeof(unsigned long long)));
+  unsigned long long z[8] = {0};
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_emit_prof),z,sizeof(z)));
+  return CP_OK;
+}
 extern "C" int cp_debug_phase_prof(unsigned long long *out24)
 { HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpyFromSymbol(out24,HIP_SYMBOL(g_phase_max),8*sizeof(unsigned long long)));

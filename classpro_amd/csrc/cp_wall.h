@@ -164,9 +164,14 @@ struct cp_read_t
 extern __device__ unsigned long long g_live_prof[8];
 #define CP_LT(k) do { unsigned long long t_ = wall_clock64(); if (__ffsll((long long)__ballot(1))-1 == (int)(threadIdx.x & 63)) atomicAdd(&g_live_prof[k],t_-lt_); lt_ = wall_clock64(); } while (0)
 #define CP_LT0() unsigned long long lt_ = wall_clock64()
+extern __device__ unsigned long long g_emit_prof[8];
+#define CP_ET(k) do { unsigned long long t_ = wall_clock64(); if (__ffsll((long long)__ballot(1))-1 == (int)(threadIdx.x & 63)) atomicAdd(&g_emit_prof[k],t_-et_); et_ = wall_clock64(); } while (0)
+#define CP_ET0() unsigned long long et_ = wall_clock64()
 #else
 #define CP_LT(k) ((void)0)
 #define CP_LT0() ((void)0)
+#define CP_ET(k) ((void)0)
+#define CP_ET0() ((void)0)
 #endif
 
 #define CP_PERR(R,i,e,w) ((R)->perror.get(i,e,w))
@@ -777,6 +782,7 @@ CP_HD bool cp_rel_interval(const cp_dev_params *P, const PROF &prof, const SEQB 
     return false;
   if (I->pe >= P->log_pe_final)                          // cp_log(PE_THRES[FINAL][SELF]), wall.c:1018
     return false;
+  CP_ET0();
   const auto wseq_b = cp_seq_window(seq_b,I->b+K-1,rlen,+1);   // rctx scans start here and go right (and a little to the left)
   const auto wseq_e = cp_seq_window(seq_e,I->e-1,rlen,-1);     // lctx scans start here and go left
 
@@ -784,6 +790,7 @@ CP_HD bool cp_rel_interval(const cp_dev_params *P, const PROF &prof, const SEQB 
   const int plen = rlen-(K-1);
   last = (I->b+K-1 < I->e-1) ? I->b+K-1 : I->e-1;
   n_gain += cp_sum_steps(prof,I->b,last,plen,+1);
+  CP_ET(5);
   if (I->b+K-1 < I->e)
     { lmax = 0;
       for (int t = 0; t < 3; t++)
@@ -804,6 +811,7 @@ CP_HD bool cp_rel_interval(const cp_dev_params *P, const PROF &prof, const SEQB 
       first = I->e-lmax;
       n_drop -= cp_sum_steps(prof,first,I->e-1,plen,+1);
     }
+  CP_ET(6);
   int ccb = I->cb+(n_gain > 0 ? n_gain : 0);
   int cce = I->ce+(n_drop > 0 ? n_drop : 0);
   if (ccb > CP_MAX_KMER_CNT) ccb = CP_MAX_KMER_CNT;
@@ -813,9 +821,8 @@ CP_HD bool cp_rel_interval(const cp_dev_params *P, const PROF &prof, const SEQB 
   I->ccb = (uint16_t)ccb;
   I->cce = (uint16_t)cce;
 
-  if (cp_logp_trans(P,I->b,I->e,ccb,cce,(ccb+cce)/2) < CP_THRES_DIFF_REL)
-    return false;
-  if ((ccb > cce ? ccb : cce) == CP_MAX_KMER_CNT)
-    return false;
-  return true;
+  const double lpt_ = cp_logp_trans(P,I->b,I->e,ccb,cce,(ccb+cce)/2);
+  const bool rel_ = !(lpt_ < CP_THRES_DIFF_REL) && !((ccb > cce ? ccb : cce) == CP_MAX_KMER_CNT);
+  CP_ET(7);
+  return rel_;
 }

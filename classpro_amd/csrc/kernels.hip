@@ -830,6 +830,9 @@ __device__ __forceinline__ cp_intvl cp_soa_get(const cp_soa &S, int64_t at)
 #ifdef CP_PROF_WALK
 __device__ unsigned long long g_phase_max[8], g_phase_sum[8], g_phase_arg[8];
 __device__ unsigned long long g_live_prof[8];
+__device__ unsigned long long g_emit_prof[8];           // wave time inside the emission loop: [0] boundaries, [1] make_interval, [2] find_rel, [3] record stores, [4] compaction
+#define EM_LT0() unsigned long long em_t = wall_clock64()
+#define EM_LT(k) do { unsigned long long t_ = wall_clock64(); if (lane == 0) atomicAdd(&g_emit_prof[k],t_-em_t); em_t = wall_clock64(); } while (0)
 #define PH_STAMP(k) do { if (lane == 0) { unsigned long long t_ = wall_clock64(); unsigned long long d_ = t_-ph_t; ph_t = t_; \
       atomicAdd(&g_phase_sum[k],d_); unsigned long long o_ = atomicMax(&g_phase_max[k],d_); if (d_ > o_) g_phase_arg[k] = ((unsigned long long)r << 32) | (unsigned)n_c; } } while (0)
 #elif defined(CP_STOP_AT)
@@ -838,6 +841,10 @@ __device__ unsigned long long g_live_prof[8];
 #define PH_STAMP(k) do { if ((k) == CP_STOP_AT) { PH_STOP_EXTRA; return; } } while (0)
 #else
 #define PH_STAMP(k) ((void)0)
+#endif
+#ifndef CP_PROF_WALK
+#define EM_LT0() ((void)0)
+#define EM_LT(k) ((void)0)
 #endif
 #define PH_STOP_EXTRA
 
@@ -1561,6 +1568,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   // Short lists (the usual case) stay in LDS, so that the one-lane loops below step through on-chip memory instead of
   // paying a global-memory round trip per element: the walls in s16[0..n_w), the boundaries in s16[n_c..), the
   // component starts / ends in s_cb / s_ce.
+  EM_LT0();
   int C = 0;
   if (NS <= WAVE && ccap >= WAVE)                       // a lane per E-interval: a component starts where b exceeds every end before it
     { int b_k = 0, e_k = -1;
@@ -1720,6 +1728,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
     const bool use_soa = do_rel == 2 && soa.a != nullptr;
     const bool aos = !use_soa || Ncl > UNREL_SMALL_MAXN || plen > GRP_MAX_PLEN;
     int M = 0;
+    EM_LT(0);
     for (int base = 0; base < Ncl; base += WAVE)
       { const int k = base+lane;
         bool ok = false;
@@ -1727,14 +1736,21 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
         if (k < Ncl)
           { const int b0 = k ? (smallc ? (int)s_bnd[k-1] : bnd[k-1]) : 0, e0 = smallc ? (int)s_bnd[k] : bnd[k];
             cp_make_interval(&R,NS,b0,e0,&I);
-            if (do_rel)
+          }
+        EM_LT(1);
+        if (k < Ncl)
+          { if (do_rel)
               { cp_seq_rsrc rs; rs.g = R.seq;
                 ok = cp_rel_interval(P,R.prof,rs,rs,rlen,&I,k);
                 I.is_rel = ok ? 1 : 0;
               }
-            if (aos) intvl[k] = I;
+          }
+        EM_LT(2);
+        if (k < Ncl)
+          { if (aos) intvl[k] = I;
             if (use_soa) cp_soa_put(soa,ioff[r]+k,I);
           }
+        EM_LT(3);
         if (do_rel)
           { const uint64_t mask = __ballot(ok);
             if (ok)
@@ -1750,6 +1766,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
               }
             M += __popcll(mask);
           }
+        EM_LT(4);
       }
     if (do_rel && lane == 0) nrel[r] = M;
     // the rare size classes (M beyond the main class, or a read beyond GRP_MAX_PLEN k-mers: the one-read-per-wave and the

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: where the candidate walk of k_find_wall spends its cycles (needs build_diag/lib_walk.so, built
+"""Diagnostic: where k_wall_tasks and k_find_wall spend their cycles on the WHOLE-PATH call (compact records, find_rel inside the emission loop) (needs build_diag/lib_walk.so, built
 with -DCP_PROF_WALK; run with CLASSPRO_AMD_LIB=build_diag/lib_walk.so on the GPU box)."""
 import ctypes as C
 import os
@@ -9,7 +9,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from classpro_amd import synth
-from classpro_amd.api import Classifier, Batch, hist_covs, STAGE_WALL
+from classpro_amd.api import Classifier, Batch, hist_covs, STAGE_REL
 from classpro_amd._lib import lib
 
 if len(sys.argv) > 1 and sys.argv[1] == "python-synth":
@@ -26,12 +26,15 @@ else:                                                     # the bench's generato
 clf = Classifier(40, 20000, hc, dc)
 ph = (C.c_ulonglong * 24)()
 lv = (C.c_ulonglong * 8)()
-clf.run(b, STAGE_WALL)
+em = (C.c_ulonglong * 8)()
+clf.classify(b)
 lib().cp_debug_phase_prof(ph)
 lib().cp_debug_live_prof(lv)
-clf.run(b, STAGE_WALL)
+lib().cp_debug_emit_prof(em)
+clf.classify(b)
 lib().cp_debug_phase_prof(ph)
 lib().cp_debug_live_prof(lv)
+lib().cp_debug_emit_prof(em)
 pn = ["0 candidate list", "1 replay (2 lanes)", "2 unwall/sort/olist", "3 wall_mult (lane 0)", "4 merge + sorts",
       "5 boundaries + records", "6 prelude/filter + live tasks"]
 print("phase                          max over reads (ticks)   mean      argmax read / its ncand   (100 MHz ticks)")
@@ -41,3 +44,7 @@ print("inside the live-task evaluation (wave time, ticks per read): own P(error)
       " its filters + P(error) %.0f, six high-complexity partners %.0f" % tuple(lv[k] / b.nreads for k in range(4)))
 print("reads %d: memo on chip %d, flags on chip to the end %d, started over with the flags in HBM %d, flags on chip after the walk %d" %
       (b.nreads, lv[4], lv[5], lv[6], lv[7]))
+print("inside phase 5 (wave time, ticks per read): boundaries %.0f, make_interval %.0f, find_rel / correct_wall_cnt %.0f, record stores %.0f, compaction of the reliable ones %.0f"
+      % tuple(em[k] / b.nreads for k in range(5)))
+print("inside find_rel (wave time of the lanes that get there): windows + first sum %.0f, scans + the other three sums %.0f, logp_trans look-up + tests %.0f"
+      % tuple(em[k] / b.nreads for k in (5, 6, 7)))
