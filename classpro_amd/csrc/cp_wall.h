@@ -772,57 +772,76 @@ CP_HD int cp_sum_steps(const PROF &prof, int lo, int hi, int plen, int sgn)
 // view itself for plain pointers and LDS windows; kernels.hip's cp_seq_rsrc answers with sixteen bases in registers.
 template <class S> CP_HD const S &cp_seq_window(const S &s, int, int, int) { return s; }
 
-template <class PROF, class SEQB, class SEQE>
-CP_HD bool cp_rel_interval(const cp_dev_params *P, const PROF &prof, const SEQB &seq_b, const SEQE &seq_e, int rlen,
-                           cp_intvl *I, int idx)
-{ const int K = P->K;
-  if (I->e-I->b < K)
+// The three tests of wall.c:1016-1019 that need nothing but the record as cp_make_interval left it.
+CP_HD bool cp_rel_prefilter(const cp_dev_params *P, const cp_intvl *I)
+{ if (I->e-I->b < P->K)
     return false;
   if ((I->cb > I->ce ? I->cb : I->ce) >= P->cov[CP_REPEAT])
     return false;
   if (I->pe >= P->log_pe_final)                          // cp_log(PE_THRES[FINAL][SELF]), wall.c:1018
     return false;
+  return true;
+}
+
+// ... and the rest for an interval that passed them: a function of (b, e, cb, ce, idx) and the read, so that any lane
+// can do it for any interval (k_find_wall packs the intervals that got here into as few 64-lane steps as they need).
+template <class PROF, class SEQB, class SEQE>
+CP_HD bool cp_rel_counts(const cp_dev_params *P, const PROF &prof, const SEQB &seq_b, const SEQE &seq_e, int rlen,
+                         int Ib, int Ie, int Icb, int Ice, int idx, int *ccb_out, int *cce_out)
+{ const int K = P->K;
   CP_ET0();
-  const auto wseq_b = cp_seq_window(seq_b,I->b+K-1,rlen,+1);   // rctx scans start here and go right (and a little to the left)
-  const auto wseq_e = cp_seq_window(seq_e,I->e-1,rlen,-1);     // lctx scans start here and go left
+  const auto wseq_b = cp_seq_window(seq_b,Ib+K-1,rlen,+1);     // rctx scans start here and go right (and a little to the left)
+  const auto wseq_e = cp_seq_window(seq_e,Ie-1,rlen,-1);       // lctx scans start here and go left
 
   int first, last, n_gain = 0, n_drop = 0, lmax;
   const int plen = rlen-(K-1);
-  last = (I->b+K-1 < I->e-1) ? I->b+K-1 : I->e-1;
-  n_gain += cp_sum_steps(prof,I->b,last,plen,+1);
+  last = (Ib+K-1 < Ie-1) ? Ib+K-1 : Ie-1;
+  n_gain += cp_sum_steps(prof,Ib,last,plen,+1);
   CP_ET(5);
-  if (I->b+K-1 < I->e)
+  if (Ib+K-1 < Ie)
     { lmax = 0;
       for (int t = 0; t < 3; t++)
-        { int l = cp_rctx(wseq_b,rlen,I->b+K-1,t)*(t+1);
+        { int l = cp_rctx(wseq_b,rlen,Ib+K-1,t)*(t+1);
           if (lmax < l) lmax = l;
         }
-      last = I->b+lmax;
-      n_gain -= cp_sum_steps(prof,I->b,last,plen,-1);
+      last = Ib+lmax;
+      n_gain -= cp_sum_steps(prof,Ib,last,plen,-1);
     }
-  first = (I->e-K+1 > I->b) ? I->e-K+1 : I->b;
-  n_drop += cp_sum_steps(prof,first,I->e-1,plen,-1);
-  if (I->b < I->e-K+1)
+  first = (Ie-K+1 > Ib) ? Ie-K+1 : Ib;
+  n_drop += cp_sum_steps(prof,first,Ie-1,plen,-1);
+  if (Ib < Ie-K+1)
     { lmax = 0;
       for (int t = 0; t < 3; t++)
-        { int l = cp_lctx(wseq_e,rlen,(I->e-K+1)+K-2,t)*(t+1); // ctx[DROP][e-K+1]
+        { int l = cp_lctx(wseq_e,rlen,(Ie-K+1)+K-2,t)*(t+1);   // ctx[DROP][e-K+1]
           if (lmax < l) lmax = l;
         }
-      first = I->e-lmax;
-      n_drop -= cp_sum_steps(prof,first,I->e-1,plen,+1);
+      first = Ie-lmax;
+      n_drop -= cp_sum_steps(prof,first,Ie-1,plen,+1);
     }
   CP_ET(6);
-  int ccb = I->cb+(n_gain > 0 ? n_gain : 0);
-  int cce = I->ce+(n_drop > 0 ? n_drop : 0);
+  int ccb = Icb+(n_gain > 0 ? n_gain : 0);
+  int cce = Ice+(n_drop > 0 ? n_drop : 0);
   if (ccb > CP_MAX_KMER_CNT) ccb = CP_MAX_KMER_CNT;
   if (cce > CP_MAX_KMER_CNT) cce = CP_MAX_KMER_CNT;
-  if (idx == I->b && I->e-2*K <= I->b && cce < prof[I->b])  // wall.c:1003-1006 with intvl index == position
-    cce = prof[I->b];
-  I->ccb = (uint16_t)ccb;
-  I->cce = (uint16_t)cce;
+  if (idx == Ib && Ie-2*K <= Ib && cce < prof[Ib])       // wall.c:1003-1006 with intvl index == position
+    cce = prof[Ib];
+  *ccb_out = ccb;
+  *cce_out = cce;
 
-  const double lpt_ = cp_logp_trans(P,I->b,I->e,ccb,cce,(ccb+cce)/2);
+  const double lpt_ = cp_logp_trans(P,Ib,Ie,ccb,cce,(ccb+cce)/2);
   const bool rel_ = !(lpt_ < CP_THRES_DIFF_REL) && !((ccb > cce ? ccb : cce) == CP_MAX_KMER_CNT);
   CP_ET(7);
   return rel_;
+}
+
+template <class PROF, class SEQB, class SEQE>
+CP_HD bool cp_rel_interval(const cp_dev_params *P, const PROF &prof, const SEQB &seq_b, const SEQE &seq_e, int rlen,
+                           cp_intvl *I, int idx)
+{ if (!cp_rel_prefilter(P,I))
+    return false;
+  int ccb, cce;
+  const bool rel = cp_rel_counts(P,prof,seq_b,seq_e,rlen,I->b,I->e,I->cb,I->ce,idx,&ccb,&cce);
+  I->ccb = (uint16_t)ccb;
+  I->cce = (uint16_t)cce;
+  return rel;
 }

@@ -1729,43 +1729,103 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
     const bool aos = !use_soa || Ncl > UNREL_SMALL_MAXN || plen > GRP_MAX_PLEN;
     int M = 0;
     EM_LT(0);
-    for (int base = 0; base < Ncl; base += WAVE)
-      { const int k = base+lane;
-        bool ok = false;
-        cp_intvl I;
-        if (k < Ncl)
-          { const int b0 = k ? (smallc ? (int)s_bnd[k-1] : bnd[k-1]) : 0, e0 = smallc ? (int)s_bnd[k] : bnd[k];
-            cp_make_interval(&R,NS,b0,e0,&I);
-          }
+    // Two steps of 64 intervals at a time.  About half of a read's intervals fail the three record-only tests of
+    // wall.c:1016-1019 (the E-intervals, mostly), and correct_wall_cnt -- four step sums over up to K-1 counts and six
+    // context scans: most of this loop's time -- would run with half of each step's lanes idle.  The intervals that pass
+    // are packed into one step instead: their (b, e, cb | ce, index) travel to the lanes 0 .. n-1 by ds_permute (a lane
+    // pushes to the rank of its interval among the passing ones; the lanes that hold none push to the slots left over, so
+    // that every push is a permutation of the wave), any lane does the counts for what it got (cp_rel_counts is a
+    // function of those five numbers and the read), and the owner pulls ccb | cce | reliable back by ds_bpermute.  Two
+    // steps with more than 64 passing intervals between them take two rounds.
+    // (What find_rel does not touch of a record -- the three log-probabilities -- is stored straight after cp_make_interval,
+    //  so that two steps' worth of it does not sit in registers across the counts: b, e, cb, ce and pe stay.)
+    for (int base = 0; base < Ncl; base += 2*WAVE)
+      { const int k0 = base+lane, k1 = base+WAVE+lane;
+        int b0 = 0, e0 = 0, c0 = 0, b1 = 0, e1 = 0, c1 = 0;          // c: cb | ce << 16, later ccb | cce << 16 | reliable << 15
+        double pe0 = 0., pe1 = 0.;
+        bool p0 = false, p1 = false;
+        auto make = [&](int k, int &b, int &e, int &c, double &pe, bool &p) __attribute__((always_inline))
+          { cp_intvl I;
+            b = k ? (smallc ? (int)s_bnd[k-1] : bnd[k-1]) : 0; e = smallc ? (int)s_bnd[k] : bnd[k];
+            cp_make_interval(&R,NS,b,e,&I);
+            p = do_rel && cp_rel_prefilter(P,&I);
+            c = (int)I.cb | ((int)I.ce << 16); pe = I.pe;
+            if (aos) intvl[k] = I;
+            if (use_soa) { cp_ivB q; q.pe = I.pe; q.peo_b = I.peo_b; q.peo_e = I.peo_e; soa.b[ioff[r]+k] = q; }
+          };
+        if (k0 < Ncl) make(k0,b0,e0,c0,pe0,p0);
+        if (k1 < Ncl) make(k1,b1,e1,c1,pe1,p1);
         EM_LT(1);
-        if (k < Ncl)
-          { if (do_rel)
-              { cp_seq_rsrc rs; rs.g = R.seq;
-                ok = cp_rel_interval(P,R.prof,rs,rs,rlen,&I,k);
-                I.is_rel = ok ? 1 : 0;
+        int res0 = 0, res1 = 0;                                       // ccb | cce << 16 | reliable << 15
+        if (do_rel)
+          { const uint64_t m0 = __ballot(p0), m1 = __ballot(p1);
+            const int n0 = __popcll(m0), n1 = __popcll(m1);
+            const int lt0 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32),__builtin_amdgcn_mbcnt_lo((uint32_t)m0,0u));
+            const int lt1 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32),__builtin_amdgcn_mbcnt_lo((uint32_t)m1,0u));
+            const bool both = n0+n1 <= WAVE;
+            const int nrounds = (both || n1 == 0) ? 1 : 2;
+            const int tA = p0 ? lt0 : n0+(lane-lt0);                  // a permutation of 0 .. 63: the passing ones first, in order
+            for (int round = 0; round < nrounds; round++)
+              { const bool useA = both || round == 0, useB = n1 > 0 && (both || round == 1);
+                const int offB = both ? n0 : 0;
+                const int tB = (p1 ? offB+lt1 : offB+n1+(lane-lt1)) & (WAVE-1);
+                int xb = 0, xe = 0, xc = 0, xk = 0;
+                bool act = false;
+                if (useA)
+                  { xb = __builtin_amdgcn_ds_permute(tA*4,b0);
+                    xe = __builtin_amdgcn_ds_permute(tA*4,e0);
+                    xc = __builtin_amdgcn_ds_permute(tA*4,c0);
+                    xk = base+__builtin_amdgcn_ds_permute(tA*4,lane);
+                    act = lane < n0;
+                  }
+                if (useB)
+                  { const int yb = __builtin_amdgcn_ds_permute(tB*4,b1);
+                    const int ye = __builtin_amdgcn_ds_permute(tB*4,e1);
+                    const int yc = __builtin_amdgcn_ds_permute(tB*4,c1);
+                    const int yk = base+WAVE+__builtin_amdgcn_ds_permute(tB*4,lane);
+                    if (lane >= offB && lane < offB+n1) { xb = yb; xe = ye; xc = yc; xk = yk; act = true; }
+                  }
+                int res = 0;
+                if (act)
+                  { cp_seq_rsrc rs; rs.g = R.seq;
+                    int ccb, cce;
+                    const bool rel = cp_rel_counts(P,R.prof,rs,rs,rlen,xb,xe,xc & 0xffff,(xc >> 16) & 0xffff,xk,&ccb,&cce);
+                    res = ccb | (cce << 16) | (rel ? 0x8000 : 0);      // counts are at most CP_MAX_KMER_CNT = 0x7fff
+                  }
+                if (useA) { const int g = __builtin_amdgcn_ds_bpermute(tA*4,res); if (p0) res0 = g; }
+                if (useB) { const int g = __builtin_amdgcn_ds_bpermute(tB*4,res); if (p1) res1 = g; }
               }
           }
         EM_LT(2);
-        if (k < Ncl)
-          { if (aos) intvl[k] = I;
-            if (use_soa) cp_soa_put(soa,ioff[r]+k,I);
-          }
-        EM_LT(3);
-        if (do_rel)
-          { const uint64_t mask = __ballot(ok);
-            if (ok)
-              { const int rank = __popcll(mask & ((1ull << lane)-1));
-                if (do_rel == 2)                             // whole-path call: the compact record only
-                  { cp_rrec q; q.b = I.b; q.e = I.e; q.ccb = I.ccb; q.cce = I.cce; q.idx = k; q.pe = I.pe;
-                    rrec_all[ioff[r]+M+rank] = q;
-                  }
-                else
-                  { rintvl[M+rank] = I;
-                    relmap[M+rank] = k;
+        auto put = [&](int k, int b, int e, int c, double pe, int res) __attribute__((always_inline))
+          { const bool ok = (res & 0x8000) != 0;
+            const uint16_t ccb = (uint16_t)(res & 0x7fff), cce = (uint16_t)((res >> 16) & 0x7fff);
+            if (k < Ncl)
+              { if (aos && res) { intvl[k].ccb = ccb; intvl[k].cce = cce; intvl[k].is_rel = ok ? 1 : 0; }
+                if (use_soa)
+                  { cp_ivA qa; qa.b = b; qa.e = e; qa.cb = (uint16_t)(c & 0xffff); qa.ce = (uint16_t)((c >> 16) & 0xffff); qa.ccb = ccb; qa.cce = cce;
+                    cp_ivC qc; qc.is_rel = ok ? 1 : 0; qc.asgn = CP_N_STATE;
+                    soa.a[ioff[r]+k] = qa; soa.c[ioff[r]+k] = qc;
                   }
               }
-            M += __popcll(mask);
-          }
+            if (do_rel)
+              { const uint64_t mask = __ballot(ok);
+                if (ok)
+                  { const int rank = __popcll(mask & ((1ull << lane)-1));
+                    if (do_rel == 2)                           // whole-path call: the compact record only
+                      { cp_rrec q; q.b = b; q.e = e; q.ccb = ccb; q.cce = cce; q.idx = k; q.pe = pe;
+                        rrec_all[ioff[r]+M+rank] = q;
+                      }
+                    else                                       // (the stage API: a copy of the record this lane has just completed)
+                      { rintvl[M+rank] = intvl[k];
+                        relmap[M+rank] = k;
+                      }
+                  }
+                M += __popcll(mask);
+              }
+          };
+        put(k0,b0,e0,c0,pe0,res0);
+        if (base+WAVE < Ncl) put(k1,b1,e1,c1,pe1,res1);
         EM_LT(4);
       }
     if (do_rel && lane == 0) nrel[r] = M;
