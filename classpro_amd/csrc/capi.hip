@@ -1151,12 +1151,12 @@ extern "C" int cp_debug_emit_prof(unsigned long long *out8)
   HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_emit_prof),z,sizeof(z)));
   return CP_OK;
 }
-extern "C" int cp_debug_phase_prof(unsigned long long *out24)
+extern "C" int cp_debug_phase_prof(unsigned long long *out36)
 { HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpyFromSymbol(out24,HIP_SYMBOL(g_phase_max),8*sizeof(unsigned long long)));
-  HIPCHK(hipMemcpyFromSymbol(out24+8,HIP_SYMBOL(g_phase_sum),8*sizeof(unsigned long long)));
-  HIPCHK(hipMemcpyFromSymbol(out24+16,HIP_SYMBOL(g_phase_arg),8*sizeof(unsigned long long)));
-  unsigned long long z[8] = {0};
+  HIPCHK(hipMemcpyFromSymbol(out36,HIP_SYMBOL(g_phase_max),12*sizeof(unsigned long long)));
+  HIPCHK(hipMemcpyFromSymbol(out36+12,HIP_SYMBOL(g_phase_sum),12*sizeof(unsigned long long)));
+  HIPCHK(hipMemcpyFromSymbol(out36+24,HIP_SYMBOL(g_phase_arg),12*sizeof(unsigned long long)));
+  unsigned long long z[12] = {0};
   HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_max),z,sizeof(z)));
   HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_sum),z,sizeof(z)));
   return CP_OK;

@@ -162,9 +162,13 @@ struct cp_read_t
 
 #if defined(CP_PROF_WALK) && defined(__HIP_DEVICE_COMPILE__)
 extern __device__ unsigned long long g_live_prof[8];
+extern __device__ unsigned long long g_emit_prof[8];
+#endif
+// (the stamps inside per-lane code cost more than what they measure: they are a build of their own, -DCP_PROF_WALK -DCP_PROF_INNER;
+//  the per-phase stamps of -DCP_PROF_WALK alone are one clock read per phase and read on lane 0)
+#if defined(CP_PROF_WALK) && defined(CP_PROF_INNER) && defined(__HIP_DEVICE_COMPILE__)
 #define CP_LT(k) do { unsigned long long t_ = wall_clock64(); if (__ffsll((long long)__ballot(1))-1 == (int)(threadIdx.x & 63)) atomicAdd(&g_live_prof[k],t_-lt_); lt_ = wall_clock64(); } while (0)
 #define CP_LT0() unsigned long long lt_ = wall_clock64()
-extern __device__ unsigned long long g_emit_prof[8];
 #define CP_ET(k) do { unsigned long long t_ = wall_clock64(); if (__ffsll((long long)__ballot(1))-1 == (int)(threadIdx.x & 63)) atomicAdd(&g_emit_prof[k],t_-et_); et_ = wall_clock64(); } while (0)
 #define CP_ET0() unsigned long long et_ = wall_clock64()
 #else

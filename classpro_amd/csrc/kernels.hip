@@ -828,11 +828,13 @@ __device__ __forceinline__ cp_intvl cp_soa_get(const cp_soa &S, int64_t at)
 //  k_find_wall: wall.c:570-958, one wave per read.
 // ---------------------------------------------------------------------------------------------
 #ifdef CP_PROF_WALK
-__device__ unsigned long long g_phase_max[8], g_phase_sum[8], g_phase_arg[8];
+__device__ unsigned long long g_phase_max[12], g_phase_sum[12], g_phase_arg[12];
 __device__ unsigned long long g_live_prof[8];
 __device__ unsigned long long g_emit_prof[8];           // wave time inside the emission loop: [0] boundaries, [1] make_interval, [2] find_rel, [3] record stores, [4] compaction
+#ifdef CP_PROF_INNER
 #define EM_LT0() unsigned long long em_t = wall_clock64()
 #define EM_LT(k) do { unsigned long long t_ = wall_clock64(); if (lane == 0) atomicAdd(&g_emit_prof[k],t_-em_t); em_t = wall_clock64(); } while (0)
+#endif
 #define PH_STAMP(k) do { if (lane == 0) { unsigned long long t_ = wall_clock64(); unsigned long long d_ = t_-ph_t; ph_t = t_; \
       atomicAdd(&g_phase_sum[k],d_); unsigned long long o_ = atomicMax(&g_phase_max[k],d_); if (d_ > o_) g_phase_arg[k] = ((unsigned long long)r << 32) | (unsigned)n_c; } } while (0)
 #elif defined(CP_STOP_AT)
@@ -842,7 +844,7 @@ __device__ unsigned long long g_emit_prof[8];           // wave time inside the 
 #else
 #define PH_STAMP(k) ((void)0)
 #endif
-#ifndef CP_PROF_WALK
+#ifndef EM_LT0
 #define EM_LT0() ((void)0)
 #define EM_LT(k) ((void)0)
 #endif
@@ -1712,6 +1714,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   if (!(cf && smallc)) N = __shfl(N,0);
   if (N > icap) overflow |= 2;
   wave_sync();
+  PH_STAMP(8);
   // wall.c:928-946, one lane per interval -- and, on the whole-path call (do_rel), find_rel_intvl / correct_wall_cnt
   // (wall.c:960-1051) on the record while it is still in the lane's registers: every interval is independent, the
   // reliable ones are compacted in order (ballot + popcount) into rintvl / relmap.  As a kernel of its own (k_find_rel,

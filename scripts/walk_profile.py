@@ -24,7 +24,7 @@ else:                                                     # the bench's generato
     hc, dc = hist_covs(h, low, high, il, ih, 0)
     b = Batch.from_device(sy.reads(0, sy.n_reads))
 clf = Classifier(40, 20000, hc, dc)
-ph = (C.c_ulonglong * 24)()
+ph = (C.c_ulonglong * 36)()
 lv = (C.c_ulonglong * 8)()
 em = (C.c_ulonglong * 8)()
 clf.classify(b)
@@ -35,11 +35,12 @@ clf.classify(b)
 lib().cp_debug_phase_prof(ph)
 lib().cp_debug_live_prof(lv)
 lib().cp_debug_emit_prof(em)
-pn = ["0 candidate list", "1 replay (2 lanes)", "2 unwall/sort/olist", "3 wall_mult (lane 0)", "4 merge + sorts",
-      "5 boundaries + records", "6 prelude/filter + live tasks"]
+pn = {0: "k_wall_tasks: candidate list", 7: "k_wall_tasks: prelude + filters", 6: "k_wall_tasks: live tasks",
+      1: "k_find_wall: replay", 2: "unwall/sort/olist", 3: "multi-error search", 4: "merge + sorts",
+      8: "components + boundaries", 5: "records + find_rel"}
 print("phase                          max over reads (ticks)   mean      argmax read / its ncand   (100 MHz ticks)")
-for k in (0, 6, 1, 2, 3, 4, 5):
-    print("  %-30s %12d %12.1f      %d / %d" % (pn[k], ph[k], ph[8 + k] / b.nreads, ph[16 + k] >> 32, ph[16 + k] & 0xffffffff))
+for k in (0, 7, 6, 1, 2, 3, 4, 8, 5):
+    print("  %-34s %12d %12.1f      %d / %d" % (pn[k], ph[k], ph[12 + k] / b.nreads, ph[24 + k] >> 32, ph[24 + k] & 0xffffffff))
 print("inside the live-task evaluation (wave time, ticks per read): own P(error) %.0f, low-complexity partner search %.0f,"
       " its filters + P(error) %.0f, six high-complexity partners %.0f" % tuple(lv[k] / b.nreads for k in range(4)))
 print("reads %d: memo on chip %d, flags on chip to the end %d, started over with the flags in HBM %d, flags on chip after the walk %d" %
