@@ -744,6 +744,32 @@ CP_HD int cp_sum_steps(const PROF &prof, int lo, int hi, int plen, int sgn)
 { int acc = 0, i = lo;
   if (lo >= hi) return 0;
   int prev = prof[lo];
+  // The two long sums of an interval that passed the tests are K-1 and K-2 steps: with K <= 41 and forty counts after `lo`
+  // inside the read, their five wide loads are issued together -- as a loop each load waited for the sum of the one before
+  // (the trip count is the lane's own), five round trips in a row, twice per interval.
+  if (hi-lo > 8 && hi-lo <= 40 && lo+40 < plen)
+    { cp_u16x8 x[5];
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+      for (int g = 0; g < 5; g++) x[g] = cp_load_u16x8(prof,lo+1+8*g);
+      const int n = hi-lo;
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+      for (int g = 0; g < 5; g++)
+        {
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+          for (int q = 0; q < 8; q++)
+            { const int cur = x[g].v[q], d = sgn*(cur-prev);
+              if (8*g+q < n && d > 0) acc += d;
+              prev = cur;
+            }
+        }
+      return acc;
+    }
   // (a last group of fewer than eight steps takes one wide load as well, of which it uses what it needs, while the eight
   //  counts lie inside the read: K-1 = 39 steps were four wide loads and SEVEN single ones, each a round trip of its own)
   while (i < hi && i+8 < plen)

@@ -9,7 +9,7 @@ rm -rf $OUT && mkdir -p $OUT
 for v in "$@"; do
   if [ "$v" = full ]; then unset CLASSPRO_AMD_LIB; else export CLASSPRO_AMD_LIB=$GRAFT_REPO_ROOT/build_diag/libstop_$v.so; fi
   rm -rf $OUT/tmp
-  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES --output-format csv -d $OUT/tmp -- python scripts/stage_once.py ${STAGE:-wall} > $OUT/run_$v.log 2>&1 || true
+  rocprofv3 --kernel-trace --pmc ${PMC:-SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES} --output-format csv -d $OUT/tmp -- python scripts/stage_once.py ${STAGE:-wall} > $OUT/run_$v.log 2>&1 || true
   python - "$OUT" "$v" <<'PY'
 import csv, glob, collections, sys
 out, v = sys.argv[1], sys.argv[2]
