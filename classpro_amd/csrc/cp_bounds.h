@@ -42,6 +42,15 @@ typedef cp_chk_view<char,2>     CP_SEQ_T;
 template <class T, int KIND> CP_HDM const T *cp_span(const cp_chk_view<T,KIND> &v, int lo, int len) { return v.span(lo,len); }
 template <class T> CP_HDM const T *cp_span(const T *v, int lo, int len) { (void)len; return v+lo; }      // unchecked callers (whole-batch kernels)
 #define CP_SPAN(v,lo,len)     cp_span((v),(lo),(len))
+// eight bases from `pos` in direction `dir` as one word (cp_ctx.h): checked like every other wide load
+CP_HDM int cp_seq_dirword(const cp_chk_view<char,2> &seq, int rlen, int pos, int dir, uint64_t *D)
+{ const int lo = dir > 0 ? pos : pos-7;
+  if (lo < 0 || lo+8 > rlen) return 0;
+  uint64_t x;
+  __builtin_memcpy(&x,seq.span(lo,8),8);
+  *D = dir > 0 ? x : __builtin_bswap64(x);
+  return 8;
+}
 #else
 #define CP_BCHK(kind,i,n) ((void)0)
 typedef const uint16_t *CP_PROF_T;

@@ -262,8 +262,10 @@ CP_HD void cp_wall_candidate_pre(const RD *R, int i, cp_wall_pre *pre)
   else           { pre->wtype = CP_GAIN; pre->cin = cim1; pre->cout = ci;   }
   int maxt = -1, maxl = -1;                              // wall.c:624-634
   double maxpe = CP_NEG_INF;
+  int l3[3];
+  cp_ctx3(R->seq,R->rlen,P->K,pre->wtype,i,l3);
   for (int t = 0; t < 3; t++)
-    { int l = cp_ctx(R->seq,R->rlen,P->K,pre->wtype,i,t);
+    { int l = l3[t];
       if (l > P->lmax[t]) l = P->lmax[t];
       double pe = P->pe[t][l];
       if (maxpe < pe)
@@ -830,8 +832,10 @@ CP_HD bool cp_rel_counts(const cp_dev_params *P, const PROF &prof, const SEQB &s
   CP_ET(5);
   if (Ib+K-1 < Ie)
     { lmax = 0;
+      int l3[3];
+      cp_rctx3(wseq_b,rlen,Ib+K-1,l3);
       for (int t = 0; t < 3; t++)
-        { int l = cp_rctx(wseq_b,rlen,Ib+K-1,t)*(t+1);
+        { int l = l3[t]*(t+1);
           if (lmax < l) lmax = l;
         }
       last = Ib+lmax;
@@ -841,8 +845,10 @@ CP_HD bool cp_rel_counts(const cp_dev_params *P, const PROF &prof, const SEQB &s
   n_drop += cp_sum_steps(prof,first,Ie-1,plen,-1);
   if (Ib < Ie-K+1)
     { lmax = 0;
+      int l3[3];
+      cp_lctx3(wseq_e,rlen,(Ie-K+1)+K-2,l3);                 // ctx[DROP][e-K+1]
       for (int t = 0; t < 3; t++)
-        { int l = cp_lctx(wseq_e,rlen,(Ie-K+1)+K-2,t)*(t+1);   // ctx[DROP][e-K+1]
+        { int l = l3[t]*(t+1);
           if (lmax < l) lmax = l;
         }
       first = Ie-lmax;

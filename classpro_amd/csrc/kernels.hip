@@ -881,6 +881,21 @@ struct cp_seq_lwin
     __device__ __forceinline__ char operator[](int p) const
     { const unsigned d = (unsigned)(p-lo); return d < (unsigned)len ? w[d] : g[p]; }
   };
+// eight bases of an LDS window as one word (cp_ctx.h: the contexts without loops): three aligned dwords and two funnel
+// shifts (the rows are four-byte aligned, the position is not); a position whose eight bases are not all in the window
+// is left to the loops, which read past the window from the read itself
+__device__ __forceinline__ int cp_seq_dirword(const cp_seq_lwin &sq, int rlen, int pos, int dir, uint64_t *D)
+{ (void)rlen;
+  const int d = (dir > 0 ? pos : pos-7)-sq.lo;
+  if (d < 0 || d+8 > sq.len) return 0;
+  CP_LDS_PTR(const uint32_t) rw = (CP_LDS_PTR(const uint32_t))(sq.w+(d & ~3));
+  const uint32_t x0 = rw[0], x1 = rw[1], x2 = rw[2];
+  const uint32_t sh = (uint32_t)(d & 3)*8;
+  const uint32_t lo = __builtin_amdgcn_alignbit(x1,x0,sh), hi = __builtin_amdgcn_alignbit(x2,x1,sh);
+  const uint64_t x = (uint64_t)lo | ((uint64_t)hi << 32);
+  *D = dir > 0 ? x : __builtin_bswap64(x);
+  return 8;
+}
 struct __attribute__((packed, aligned(1))) cp_u8x16 { uint32_t v[4]; };
 struct __attribute__((packed, aligned(1))) cp_u8x4 { uint32_t v; };
 __device__ __forceinline__ void fw_seq_win_load(cp_seq_lwin &sq, char *row, int i, int rlen)
@@ -906,7 +921,7 @@ __device__ __forceinline__ void fw_seq_win_load(cp_seq_lwin &sq, char *row, int 
 // emission loop (cp_rel_interval) read a handful of bases right of b+K-1 and left of e-1; from the global pointer every
 // one of them was a load of its own in a loop that waits for it (k_find_wall has no LDS left for windows like k_find_rel's).
 // One 16-byte load per side instead; a base outside the sixteen is read from the read as before.  dir = +1: the
-// window starts four bases before the position, -1: it ends four bases after it.
+// window starts seven bases before the position, -1: it ends four bases after it.
 struct cp_seq_rwin
   { CP_SEQ_T g;
     uint64_t wl, wh;                                       // bases lo .. lo+7, lo+8 .. lo+15
@@ -920,10 +935,18 @@ struct cp_seq_rwin
       return g[p];
     }
   };
+__device__ __forceinline__ int cp_seq_dirword(const cp_seq_rwin &sq, int rlen, int pos, int dir, uint64_t *D)
+{ (void)rlen;
+  const int d = (dir > 0 ? pos : pos-7)-sq.lo;
+  if (sq.len != 16 || d < 0 || d > 8) return 0;
+  const uint64_t x = d == 0 ? sq.wl : d == 8 ? sq.wh : (sq.wl >> (8*d)) | (sq.wh << (64-8*d));
+  *D = dir > 0 ? x : __builtin_bswap64(x);
+  return 8;
+}
 struct cp_seq_rsrc { CP_SEQ_T g; };                        // "make me a register window": what k_find_wall hands to cp_rel_interval
 __device__ __forceinline__ cp_seq_rwin cp_seq_window(const cp_seq_rsrc &src, int pos, int rlen, int dir)
 { cp_seq_rwin sq;
-  int lo = dir > 0 ? pos-4 : pos-11;
+  int lo = dir > 0 ? pos-7 : pos-11;                       // (the eight bases on either side of a position scanned to the right, cp_rctx3)
   if (lo > rlen-16) lo = rlen-16;
   if (lo < 0) lo = 0;
   sq.g = src.g; sq.lo = lo; sq.len = 0; sq.wl = sq.wh = 0;
