@@ -871,11 +871,15 @@ __device__ unsigned long long g_emit_prof[8];           // wave time inside the 
 // [2] the count pair, and [3] the task list; `tres` the task results; `fwc` per read n_c, n_t, SELF tasks, overflow.
 struct task_res { double own_pe, lc_v, hc_pe; int lc_j, hc;  };   // hc: lc_kind | (hc_j >= 0) << 2 | (hc_j - i) << 16
 
-// The sequence-context scans of the walk (cp_ctx.h: runs of equal bases / of period 2 and 3 around a position) are
-// chains of dependent byte loads.  A lane copies the 96 bases around its candidate into its row of an LDS block once
-// (six independent 16-byte loads) and the scans read the row; a position outside the row is read from HBM as before.
-#define FW_SEQ_WIN    96
-#define FW_SEQ_STRIDE 100            // bytes per lane: 25 dwords, an odd number of banks apart
+// The sequence contexts of the walk (cp_ctx.h) look at the bases next to a position.  Phase 1a needs the three contexts
+// of the candidate itself: eight bases before i+K-2 (a DROP) or on either side of i (a GAIN) -- ONE 16-byte load into
+// registers (cp_seq_rwin below).  Phase 1b asks for the context of the low-complexity partners, a few unit lengths to the
+// right (DROP) or left (GAIN) of the candidate, in a loop: a lane copies the 32 bases that cover the first five or more
+// partners into its row of an LDS block (two independent 16-byte loads) and the loop reads the row; a position outside
+// the row is read from HBM.  (Until the contexts came from words, round 5, both phases filled a 96-base row: six loads
+// and 24 LDS stores per lane and phase.)
+#define FW_SEQ_WIN    32
+#define FW_SEQ_STRIDE 36             // bytes per lane: 9 dwords, an odd number of banks apart
 struct cp_seq_lwin
   { CP_SEQ_T g; CP_LDS_PTR(const char) w; int lo, len;
     __device__ __forceinline__ char operator[](int p) const
@@ -898,25 +902,6 @@ __device__ __forceinline__ int cp_seq_dirword(const cp_seq_lwin &sq, int rlen, i
 }
 struct __attribute__((packed, aligned(1))) cp_u8x16 { uint32_t v[4]; };
 struct __attribute__((packed, aligned(1))) cp_u8x4 { uint32_t v; };
-__device__ __forceinline__ void fw_seq_win_load(cp_seq_lwin &sq, char *row, int i, int rlen)
-{ int lo = i-32;
-  if (lo > rlen-FW_SEQ_WIN) lo = rlen-FW_SEQ_WIN;
-  if (lo < 0) lo = 0;
-  const int len = rlen-lo < FW_SEQ_WIN ? rlen-lo : FW_SEQ_WIN;
-  uint32_t *rw = reinterpret_cast<uint32_t *>(row);
-  if (len == FW_SEQ_WIN)
-    {
-#pragma unroll
-      for (int k = 0; k < FW_SEQ_WIN/16; k++)
-        { const cp_u8x16 x = *reinterpret_cast<const cp_u8x16 *>(CP_SPAN(sq.g,lo+16*k,16));
-          rw[4*k] = x.v[0]; rw[4*k+1] = x.v[1]; rw[4*k+2] = x.v[2]; rw[4*k+3] = x.v[3];
-        }
-    }
-  else
-    for (int k = 0; k < len; k++) row[k] = sq.g[lo+k];
-  sq.lo = lo; sq.len = len;
-}
-
 // Sixteen bases around a position IN REGISTERS (round 5): the context scans of correct_wall_cnt inside k_find_wall's
 // emission loop (cp_rel_interval) read a handful of bases right of b+K-1 and left of e-1; from the global pointer every
 // one of them was a load of its own in a loop that waits for it (k_find_wall has no LDS left for windows like k_find_rel's).
@@ -1001,6 +986,9 @@ k_wall_tasks(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, 
   R.seq.g = CP_SEQ_VIEW(seq+seq_off[r],rlen); R.seq.w = (CP_LDS_PTR(const char))(s_win+lane*FW_SEQ_STRIDE); R.seq.lo = 0; R.seq.len = 0;
   R.wall = wall_all+po+r; R.wall_s = R.wall;
   R.eintvl = R.ointvl = nullptr; R.ecap = 0; R.eidx = R.oidx = 0; R.overflow = 0;
+  cp_read_t<cp_perr_hybrid,cp_seq_rwin> R1;             // phase 1a's view of the read: the bases as a register window
+  R1.P = P; R1.prof = R.prof; R1.lf = P->logfact; R1.plen = plen; R1.rlen = rlen;
+  R1.wall = R.wall; R1.wall_s = R.wall; R1.eintvl = R1.ointvl = nullptr; R1.ecap = 0; R1.eidx = R1.oidx = 0; R1.overflow = 0;
   const int icap = (int)(ioff[r+1]-ioff[r]);
   int32_t *wl = wlist+ioff[r]*4;                        // four int32 lists of capacity icap
   task_res *tres = tres_all+ioff[r];
@@ -1037,9 +1025,11 @@ k_wall_tasks(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, 
     { int f0 = 0, f1 = 0;
       if (base+lane < n_c)
         { const int i = clist[base+lane];
-          fw_seq_win_load(R.seq,s_win+lane*FW_SEQ_STRIDE,i,rlen);
+          const bool drop = R.prof[i-1] > R.prof[i];       // (cp_wall_candidate_pre's rule: the contexts of a DROP end at i+K-2, those of a GAIN begin at i)
+          cp_seq_rsrc rs; rs.g = R.seq.g;
+          R1.seq = cp_seq_window(rs,drop ? i+P->K-2 : i,rlen,drop ? -1 : +1);
           cp_wall_pre pre;
-          cp_wall_candidate_pre(&R,i,&pre);
+          cp_wall_candidate_pre(&R1,i,&pre);
           f0 = cp_wall_candidate_filter(P,CP_SELF,pre);
           f1 = cp_wall_candidate_filter(P,CP_OTHERS,pre);
           cinfo[base+lane] = pre.maxt*32+pre.maxl+(f0 << 8)+(f1 << 12);
@@ -1067,9 +1057,10 @@ k_wall_tasks(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, 
       if (lane < nb)
         { const int code = tlist[tb+lane], k = code >> 1, e = code & 1;
           const int i = clist[k], tl = cinfo[k] & 255, cc = ccnt[k];
-          fw_seq_win_load(R.seq,s_win+lane*FW_SEQ_STRIDE,i,rlen);
           cp_wall_pre pre;
           const int cim1 = cc & 0xffff, ci = (cc >> 16) & 0xffff;
+          // the partners of a DROP lie to the right and their contexts end K-2 bases further on, those of a GAIN to the left
+          fr_seq_win_load(R.seq,s_win+lane*FW_SEQ_STRIDE,cim1 > ci ? i+P->K-16 : i-24,rlen);
           pre.cng = cim1 > ci ? cim1-ci : ci-cim1;
           if (cim1 > ci) { pre.wtype = CP_DROP; pre.cin = ci;   pre.cout = cim1; }
           else           { pre.wtype = CP_GAIN; pre.cin = cim1; pre.cout = ci;   }
