@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/kt
 for l in "$@"; do
   if [ "$l" = default ]; then unset CLASSPRO_AMD_LIB; else export CLASSPRO_AMD_LIB=$GRAFT_REPO_ROOT/$l; fi
-  for ns in 1 2; do
+  for ns in ${KT_STREAMS:-1 2}; do
     rm -rf gpurun_out/kt/tmp
     rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt/tmp -- python bench.py --steps 3 --warmup 1 --no-cpu --no-extras --streams $ns > gpurun_out/kt/log.txt 2>&1
     python - "$l" "$ns" <<'PY'
