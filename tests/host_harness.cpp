@@ -22,6 +22,29 @@ void hh_seq_context(const char *seq, int rlen, unsigned char *lctx, unsigned cha
       }
 }
 
+// the same from the three-at-once forms (cp_lctx3 / cp_rctx3: one 8-base word for the three contexts of a position) and
+// from the per-base scans alone; returns how many (position, direction) pairs the words decided without a scan
+long long hh_seq_context3(const char *seq, int rlen, unsigned char *lctx, unsigned char *rctx, unsigned char *lscan, unsigned char *rscan)
+{ long long hits = 0;
+  for (int i = 0; i < rlen; i++)
+    { int l3[3], r3[3];
+      cp_lctx3(seq,rlen,i,l3);
+      cp_rctx3(seq,rlen,i,r3);
+      for (int t = 0; t < 3; t++)
+        { lctx[i*3+t] = (unsigned char)l3[t];
+          rctx[i*3+t] = (unsigned char)r3[t];
+          lscan[i*3+t] = (unsigned char)cp_lctx_scan(seq,rlen,i,t);
+          rscan[i*3+t] = (unsigned char)cp_rctx_scan(seq,rlen,i,t);
+        }
+      uint64_t D = 0;
+      int nv = cp_seq_dirword(seq,rlen,i,-1,&D);
+      if (nv && cp_word_hp(D,nv) >= 0 && cp_word_ds(D,nv) >= 0 && cp_word_ts(D,nv) >= 0) hits++;
+      nv = cp_seq_dirword(seq,rlen,i,+1,&D);
+      if (nv && cp_word_hp(D,nv) >= 0 && cp_word_ds(D,nv) >= 0 && cp_word_ts(D,nv) >= 0) hits++;
+    }
+  return hits;
+}
+
 double hh_bessi(int n, double x) { return cp_bessi(n,x); }
 
 void *hh_params_new(int K, int read_len, int hcov, int dcov)

@@ -43,6 +43,33 @@ def test_closed_form_context_random(harness):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), s
 
 
+def test_context_words_equal_the_scans(harness):
+    """cp_ctx.h, round 5: the contexts from eight bases at a time (cp_lctx3 / cp_rctx3, what the kernels call) against the
+    per-base scans and the oracle's sequential pass: random reads, runs of every unit length that end inside, at and beyond
+    the eight-base word, runs at both ends of a read, runs beyond the 127 cap, reads shorter than a word."""
+    O = Oracle()
+    rng = np.random.default_rng(5)
+    harness.hh_seq_context3.restype = C.c_longlong
+    hits = total = 0
+    cases = []
+    for ul in (1, 2, 3):
+        for rep in list(range(1, 14)) + [40, 130, 300]:
+            u = bytes(AL[rng.permutation(4)[:ul]])
+            for pre, post in ((0, 0), (0, 9), (9, 0), (3, 3), (20, 20)):
+                cases.append(bytes(AL[rng.integers(0, 4, size=pre)]) + u * rep + bytes(AL[rng.integers(0, 4, size=post)]))
+    for _ in range(600):
+        cases.append(bytes(AL[rng.integers(0, int(rng.integers(2, 5)), size=int(rng.integers(1, 200)))]))
+    for s in cases:
+        rlen = len(s)
+        a = [np.zeros((rlen, 3), np.uint8) for _ in range(4)]
+        hits += harness.hh_seq_context3(C.c_char_p(s), rlen, *[x.ctypes.data_as(C.c_void_p) for x in a])
+        total += 2 * rlen
+        ol, orr = O.seq_context(s)
+        assert np.array_equal(a[0], a[2]) and np.array_equal(a[1], a[3]), s
+        assert np.array_equal(a[0], ol) and np.array_equal(a[1], orr), s
+    assert hits > 0.3 * total          # the words decide most positions of ordinary sequence (and none inside long runs)
+
+
 def test_closed_form_context_golden(harness):
     g = load_golden("context.npz")
     off = g["off"]
