@@ -61,6 +61,7 @@ with open(os.path.join(dst, name + "_pmc.txt"), "w") as f:
     f.write("# doubled: the x2 is calibrated for 16-B-per-lane streaming reads, the other kernels' access widths are not):\n")
     scan_f = scan_per_sub * sum(agg[("k_scan_candidates", "FETCH_SIZE")]) / len(agg[("k_scan_candidates", "FETCH_SIZE")])
     f.write("#   FETCH_SIZE %.0f KiB raw, %.0f KiB with the scan doubled; WRITE_SIZE %.0f KiB\n" % (tot["FETCH_SIZE"], tot["FETCH_SIZE"] + scan_f, tot["WRITE_SIZE"]))
+    f.write("#   in bytes (x 1024): %.2f GB fetched + %.2f GB written = %.2f GB per sub-batch\n" % ((tot["FETCH_SIZE"] + scan_f) * 1024 / 1e9, tot["WRITE_SIZE"] * 1024 / 1e9, (tot["FETCH_SIZE"] + scan_f + tot["WRITE_SIZE"]) * 1024 / 1e9))
 fs = agg[("k_scan_candidates", "FETCH_SIZE")]
 wsz = agg[("k_scan_candidates", "WRITE_SIZE")]
 fetch = 2.0 * 1024 * sum(fs) / len(fs)
