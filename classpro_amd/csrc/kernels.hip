@@ -1255,8 +1255,42 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
                   if (p2 >= 0) dep |= s_dep[s2];
                   dep &= ltm;
                 }
+              // The table is hashed (the keys of a chunk outnumber its 128 slots): a lane's mask holds every earlier task
+              // whose keys fall into its slots, and 5.2 dependency rounds per chunk came of it where the tasks that really
+              // share a position make 2.0 (diagnostic build, scripts/walk_profile.py).  Every bit is checked against the
+              // keys of the lane it names (three ds_bpermute per step, as many steps as the fullest mask has bits).
+              { const int k0 = open ? pos*2+e : -2, k1 = (open && p1 >= 0) ? p1*2+e : -1, k2 = (open && p2 >= 0) ? p2*2+e : -1;
+                uint64_t rem = dep, keep = 0;
+                while (__ballot(rem != 0))
+                  { const int u = rem ? __ffsll((long long)rem)-1 : lane;
+                    const int a0 = __shfl(k0,u), a1 = __shfl(k1,u), a2 = __shfl(k2,u);
+                    const bool hit = a0 == k0 || a0 == k1 || a0 == k2
+                                     || (a1 >= 0 && (a1 == k0 || a1 == k1 || a1 == k2))
+                                     || (a2 >= 0 && (a2 == k0 || a2 == k1 || a2 == k2));
+                    if (rem) { if (hit) keep |= 1ull << u; rem &= rem-1; }
+                  }
+                dep = keep;
+              }
               bool hasE = false, hasO = false, off_list = false;
               cp_eintvl I; I.b = I.e = 0; I.pe = 0.;
+#ifdef CP_PROF_WALK
+              { // rounds this chunk takes with the hashed dependency table, and with exact key comparisons
+                uint64_t depx = 0;
+                const int k0 = pos*2+e, k1 = p1 >= 0 ? p1*2+e : -1, k2 = p2 >= 0 ? p2*2+e : -1;
+                for (int u = 0; u < WAVE; u++)
+                  { const int a0 = __shfl(k0,u), a1 = __shfl(k1,u), a2 = __shfl(k2,u);
+                    const bool uo = __shfl((int)open,u) != 0;
+                    if (uo && u < lane && (a0 == k0 || (k1 >= 0 && a0 == k1) || (k2 >= 0 && a0 == k2)
+                                          || (a1 >= 0 && (a1 == k0 || a1 == k1 || a1 == k2)) || (a2 >= 0 && (a2 == k0 || a2 == k1 || a2 == k2))))
+                      depx |= 1ull << u;
+                  }
+                int rh = 0, rx = 0;
+                bool oh = open, ox = open;
+                for (uint64_t um = __ballot(oh); um; um = __ballot(oh)) { if (oh && (dep & um) == 0) oh = false; rh++; }
+                for (uint64_t um = __ballot(ox); um; um = __ballot(ox)) { if (ox && (depx & um) == 0) ox = false; rx++; }
+                if (lane == 0) { atomicAdd(&g_live_prof[0],(unsigned long long)rh); atomicAdd(&g_live_prof[1],(unsigned long long)rx); atomicAdd(&g_live_prof[2],1ull); atomicAdd(&g_live_prof[3],(unsigned long long)nb); }
+              }
+#endif
               for (uint64_t um = __ballot(open); um; um = __ballot(open))
                 { if (open && (dep & um) == 0)
                     { open = false;

@@ -41,6 +41,8 @@ pn = {0: "k_wall_tasks: candidate list", 7: "k_wall_tasks: prelude + filters", 6
 print("phase                          max over reads (ticks)   mean      argmax read / its ncand   (100 MHz ticks)")
 for k in (0, 7, 6, 1, 2, 3, 4, 8, 5):
     print("  %-34s %12d %12.1f      %d / %d" % (pn[k], ph[k], ph[12 + k] / b.nreads, ph[24 + k] >> 32, ph[24 + k] & 0xffffffff))
+print("replay chunks %d (%.1f tasks each): dependency rounds per chunk %.2f with the hashed table, %.2f with exact key comparisons"
+      % (lv[2], lv[3] / max(1, lv[2]), lv[0] / max(1, lv[2]), lv[1] / max(1, lv[2])))
 print("inside the live-task evaluation (wave time, ticks per read): own P(error) %.0f, low-complexity partner search %.0f,"
       " its filters + P(error) %.0f, six high-complexity partners %.0f" % tuple(lv[k] / b.nreads for k in range(4)))
 print("reads %d: memo on chip %d, flags on chip to the end %d, started over with the flags in HBM %d, flags on chip after the walk %d" %
