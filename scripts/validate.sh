@@ -25,5 +25,5 @@ PY
 set +e
 python bench.py --gpus 2 --backend gloo --no-cpu --no-extras --steps 1 --warmup 1 > $O/n2_default.json 2> $O/n2_default.err; rc=$?
 set -e
-echo "2 ranks, default windows, one card: exit code $rc (2 expected)"; grep "bench.py: rank" $O/n2_default.err | head -2
+echo "2 ranks, default windows, one card: launcher exit code $rc (every rank exits 2: below)"; grep -o "exitcode  : [0-9]*" $O/n2_default.err | sort | uniq -c; grep "bench.py: rank" $O/n2_default.err | head -2
 python bench.py --gpus 1 --backend nccl --force-dist --no-cpu --no-extras --steps 3 --warmup 1 > $O/nccl1.json 2> $O/nccl1.err && echo "nccl world 1 ok: $(cut -c1-120 $O/nccl1.json)"
