@@ -1148,8 +1148,11 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
 #ifdef CP_PROF_WALK
   unsigned long long ph_t = wall_clock64();
 #endif
-  // a pass memoises at most two entries per live candidate (its own and its low-complexity partner's)
-  R.perror.use_lds = ((8*n_live0 <= 3*LCAP0) ? 1 : 0) | ((8*(n_t-n_live0) <= 3*LCAP1) ? 2 : 0);
+  // a pass memoises at most two entries per live candidate (its own and its low-complexity partner's): the table never
+  // fills while twice the tasks leave eight slots free.  (Until the end of round 5 the rule was a load of 3/4 -- 96 SELF
+  // tasks -- and 9 % of the bench's reads, the ones with 97-120, took the one-lane replay on the tables in HBM, several
+  // times the time of the lane-parallel one: a long probe sequence in LDS costs less than that.)
+  R.perror.use_lds = ((2*n_live0 <= LCAP0-8) ? 1 : 0) | ((2*(n_t-n_live0) <= LCAP1-8) ? 2 : 0);
   // the SELF pass appends at most one E-interval per live task: with that many slots on chip the replay never moves the list
   R.eintvl.big = (n_live0 > FW_EVL || R.ecap < FW_EVL) ? 1 : 0;
   // a pass whose memo does not fit on chip uses its table in HBM: empty it here (the few reads that need one), instead
