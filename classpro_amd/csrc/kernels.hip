@@ -433,7 +433,7 @@ k_order_scatter(const int32_t *__restrict__ key, int n, int shift, int32_t *__re
 // ---------------------------------------------------------------------------------------------
 #ifndef FW_EVL
 #ifndef FW_EVL
-#define FW_EVL 96
+#define FW_EVL 128
 #endif
 #endif
 struct fw_evl
