@@ -1226,7 +1226,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
             }
           else flags_to_hbm();
           bool bail = false;
-          for (int tb = 0; tb < n_t && !bail; tb += WAVE)
+          for (int tb = 0; tb < n_t; tb += WAVE)
             { const int nb = (n_t-tb < WAVE) ? n_t-tb : WAVE;
               bool open = lane < nb;
               int pos = 1, kc = 0, e = 0, w = 0, lc_j = -1, lc_kind = CP_LC_NONE, hc_j = -1;
@@ -1323,7 +1323,14 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
                                   // A partner that is no candidate: its SELF flag would be a wall the later phases must see --
                                   // the read starts over; its OTHERS flag nobody ever reads (a task reads the flag of its own
                                   // position, a candidate, and the ends of O-pairs are un-walled after the walk): not kept.
-                                  if (kj < 0 && e == CP_SELF) off_list = true;
+                                  if (kj < 0 && e == CP_SELF)
+                                    { // No task ever reads this flag (a task reads the flag of its own position, a candidate):
+                                      // it goes to the array for the phases after the walk, the candidate's own stays here, and
+                                      // the read's other flags follow it to the arrays once the replay is through.
+                                      F.fs[kc] = (CP_W_WALL_S|CP_W_PAIRED_S);
+                                      R.wall_s[max_j] = (CP_W_WALL_S|CP_W_PAIRED_S);
+                                      off_list = true; hasE = true;
+                                    }
                                   else if (e == CP_SELF)                                     // wall.c:655-668 (the SELF array only ever holds these two bits)
                                     { if (onchip) { F.fs[kc] = (CP_W_WALL_S|CP_W_PAIRED_S); F.fs[kj] = (CP_W_WALL_S|CP_W_PAIRED_S); }
                                       else { R.wall_s[I.b] = (CP_W_WALL_S|CP_W_PAIRED_S); R.wall_s[I.e] = (CP_W_WALL_S|CP_W_PAIRED_S); }
@@ -1351,7 +1358,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
                     }
                   wave_sync();                                     // the round's flags and memo entries are visible to the next
                 }
-              if (__ballot(off_list)) { bail = true; break; }
+              if (__ballot(off_list)) bail = true;            // (not a restart any more: see below)
               const uint64_t mE = __ballot(hasE), mO = __ballot(hasO);
               if (hasE)
                 { const int sl = eidx+__popcll(mE & ltm);
@@ -1366,14 +1373,20 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
               if (oidx > ecap) { oidx = ecap; ovf = 1; }
             }
           wave_sync();
-          if (!bail) break;
+          if (bail)                                        // a SELF pair ends off the candidates: the phases after the walk need the
+            {                                              // flag ARRAYS (the multi-error search meets walls position by position)
 #ifdef CP_PROF_WALK
-          if (lane == 0) atomicAdd(&g_live_prof[6],1ull);
+              if (lane == 0) atomicAdd(&g_live_prof[6],1ull);
 #endif
-          onchip = false;                                  // once more from the start, the flags in the arrays (nothing but LDS was written)
-          eidx = oidx = ovf = 0;
-          for (int k = lane; k < LCAP0+LCAP1; k += WAVE) s_mkey[k] = -1;
-          wave_sync();
+              for (int q = lane; q < n_c; q += WAVE)
+                { const int i = F.pos[q];
+                  if (F.fo[q]) wall[i] = F.fo[q];
+                  if (F.fs[q]) R.wall_s[i] = F.fs[q];
+                }
+              onchip = false;                              // (until the end of round 5 such a read started the replay over on the arrays:
+              wave_sync();                                 //  11 % of the bench's reads, twice through the most expensive phase)
+            }
+          break;
         }
       if (lane < 2) { R.eidx = lane == 0 ? eidx : 0; R.oidx = lane == 1 ? oidx : 0; R.overflow |= ovf; }
     }
