@@ -724,8 +724,10 @@ __device__ __forceinline__ void cf_unwall_inside(const fw_cflags &F, const fw_ev
 // cp_wall_mult (wall.c:763-860) for the O-only wall at candidate q, all lanes together: the walls the reference meets
 // within 200 positions are the flagged candidates after (DROP) / before (GAIN) q, 64 of them per step, in order; the read's
 // boundary (plen / 0), when it lies within reach, comes last.  Same values on every lane, stores by lane 0.
+// xs[0..nx): the SELF walls that are no candidates (partners below the scan's threshold, in increasing order; usually
+// none): the reference meets them on its way like any other wall; they are never OTHERS walls, so they end no search.
 template <class RD>
-__device__ __forceinline__ void cf_wall_mult(RD *R, const fw_cflags &F, int q, int NS, int *midx)
+__device__ __forceinline__ void cf_wall_mult(RD *R, const fw_cflags &F, int q, int NS, int *midx, const uint16_t *xs, int nx)
 { const int lane = lane_id();
   const int plen = R->plen, i = F.pos[q];
   fw_evl &ev = R->eintvl;
@@ -737,6 +739,35 @@ __device__ __forceinline__ void cf_wall_mult(RD *R, const fw_cflags &F, int q, i
       const int jend = right ? ((i+CP_MULT_WINDOW < plen+1) ? i+CP_MULT_WINDOW : plen+1)
                              : ((i-CP_MULT_WINDOW > 0) ? i-CP_MULT_WINDOW : 0);
       bool done = false;
+      int xi = right ? 0 : nx-1;                           // the next off-list wall in the direction of the search
+      if (right) { while (xi < nx && (int)xs[xi] <= i) xi++; } else { while (xi >= 0 && (int)xs[xi] >= i) xi--; }
+      // an off-list wall at jj (wall.c:793-806 / 837-850 for a wall that is not an OTHERS wall); false: a capacity ran out
+      auto visit_x = [&](int jj) -> bool
+        { if (cp_bs_eintvl(ev,0,NS-1,right ? i : jj,right ? jj : i) == -1)
+            { const double pe_j = CP_PERR(R,jj,CP_SELF,right ? CP_GAIN : CP_DROP);
+              const double pe = pe_i * pe_j;
+              if (pe >= CP_PE_THRES_FINAL)
+                { if (*midx >= R->ecap) { R->overflow = 1; return false; }
+                  ev.wave_grow(*midx);
+                  if (lane == 0)
+                    { cp_eintvl x; x.b = right ? i : jj; x.e = right ? jj : i; x.pe = pe;
+                      ev.put(*midx,x);
+                      F.fo[q] |= CP_W_PAIRED_M;            // (the flag of jj itself is read by nobody: jj is the origin of no search)
+                    }
+                  (*midx)++;
+                  if (*midx >= plen) { R->overflow = 8; return false; }
+                }
+            }
+          return true;
+        };
+      // the off-list walls before position `lim` in the direction of the search (and inside the window)
+      auto flush_x = [&](int lim) -> bool
+        { while (right ? (xi < nx && (int)xs[xi] < lim && (int)xs[xi] < jend) : (xi >= 0 && (int)xs[xi] > lim && (int)xs[xi] >= jend))
+            { if (!visit_x((int)xs[xi])) return false;
+              xi += right ? 1 : -1;
+            }
+          return true;
+        };
       for (int c0 = 0; !done; c0 += WAVE)
         { const int qq = right ? q+1+c0+lane : q-1-c0-lane;
           int pj = 0, fo = 0, fs = 0;
@@ -749,6 +780,7 @@ __device__ __forceinline__ void cf_wall_mult(RD *R, const fw_cflags &F, int q, i
           for (uint64_t t = mw; t; t &= t-1)
             { const int b = __ffsll((long long)t)-1;
               const int jj = __shfl(pj,b), qj = right ? q+1+c0+b : q-1-c0-b;
+              if (nx > 0 && !flush_x(jj)) return;
               if (cp_bs_eintvl(ev,0,NS-1,right ? i : jj,right ? jj : i) == -1)
                 { const double pe_j = CP_PERR(R,jj,CP_SELF,right ? CP_GAIN : CP_DROP);
                   const double pe = pe_i * pe_j;
@@ -769,6 +801,7 @@ __device__ __forceinline__ void cf_wall_mult(RD *R, const fw_cflags &F, int q, i
             }
           if (mv != ~0ull) break;                          // the candidates within reach end inside these 64
         }
+      if (nx > 0 && !done && !flush_x(right ? 0x7fffffff : -1)) return;      // off-list walls beyond the last candidate wall
       if (!done && (right ? plen < jend : jend == 0))     // the boundary is within reach: wall.c:772-789 / 816-833
         { const double pe = pe_i * pe_i;
           if (pe >= CP_PE_THRES_FINAL)
@@ -1104,6 +1137,9 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   const int plen = (int)(prof_off[r+1]-po);
   const int rlen = (int)(seq_off[r+1]-seq_off[r]);
 
+#ifndef FW_XCAP
+#define FW_XCAP 8                     // off-list SELF walls kept on chip per read (a diagnostic build with 1 drives the full-list path: scripts/r5_xcap.sh)
+#endif
 #ifndef FW_LCAP1
 #define FW_LCAP1 64
 #endif
@@ -1114,6 +1150,8 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   constexpr int LCAP0 = 256, LCAP1 = FW_LCAP1;           // on-chip memo slots of the SELF / OTHERS pass
   __shared__ int32_t s_mkey[LCAP0+LCAP1];
   __shared__ double  s_mval[LCAP0+LCAP1];
+  __shared__ uint16_t s_x[FW_XCAP];                      // SELF walls off the candidates (see the replay), sorted after it
+  __shared__ int s_nx;
   __shared__ cp_eintvl s_ev[FW_EVL];                     // the E-interval list while it is short (fw_evl)
   cp_read_t<cp_perr_hybrid,CP_SEQ_T,CP_PROF_T,const double *,fw_evl> R;
   R.P = P; R.prof = CP_PROF_VIEW(prof+po,plen); R.seq = CP_SEQ_VIEW(seq+seq_off[r],rlen); R.lf = P->logfact; R.plen = plen; R.rlen = rlen;
@@ -1128,6 +1166,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
     R.perror.lcap0 = LCAP0; R.perror.lcap1 = LCAP1;
     R.perror.use_lds = 0;
   }
+  if (lane == 0) s_nx = 0;
   for (int k = lane; k < LCAP0+LCAP1; k += WAVE)
     s_mkey[k] = -1;
   R.eintvl.g = eintvl_all+eoff[r];
@@ -1324,12 +1363,20 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
                                   // the read starts over; its OTHERS flag nobody ever reads (a task reads the flag of its own
                                   // position, a candidate, and the ends of O-pairs are un-walled after the walk): not kept.
                                   if (kj < 0 && e == CP_SELF)
-                                    { // No task ever reads this flag (a task reads the flag of its own position, a candidate):
-                                      // it goes to the array for the phases after the walk, the candidate's own stays here, and
-                                      // the read's other flags follow it to the arrays once the replay is through.
+                                    { // No task ever reads this flag (a task reads the flag of its own position, a candidate);
+                                      // the multi-error search after the walk does, position by position: the partner goes to a
+                                      // short list of off-list SELF walls (cf_wall_mult), the candidate's own flag stays here.  A
+                                      // list that is full sends the flag -- and after the replay all the others -- to the arrays.
                                       F.fs[kc] = (CP_W_WALL_S|CP_W_PAIRED_S);
-                                      R.wall_s[max_j] = (CP_W_WALL_S|CP_W_PAIRED_S);
-                                      off_list = true; hasE = true;
+                                      bool known = false;
+                                      const int nx0 = s_nx;
+                                      for (int k = 0; k < nx0 && k < FW_XCAP; k++) known = known || (int)s_x[k] == max_j;
+                                      if (!known)
+                                        { const int sl = atomicAdd(&s_nx,1);
+                                          if (sl < FW_XCAP) s_x[sl] = (uint16_t)max_j;
+                                          else { R.wall_s[max_j] = (CP_W_WALL_S|CP_W_PAIRED_S); off_list = true; }
+                                        }
+                                      hasE = true;
                                     }
                                   else if (e == CP_SELF)                                     // wall.c:655-668 (the SELF array only ever holds these two bits)
                                     { if (onchip) { F.fs[kc] = (CP_W_WALL_S|CP_W_PAIRED_S); F.fs[kj] = (CP_W_WALL_S|CP_W_PAIRED_S); }
@@ -1373,8 +1420,8 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
               if (oidx > ecap) { oidx = ecap; ovf = 1; }
             }
           wave_sync();
-          if (bail)                                        // a SELF pair ends off the candidates: the phases after the walk need the
-            {                                              // flag ARRAYS (the multi-error search meets walls position by position)
+          if (bail)                                        // more SELF pairs end off the candidates than the list holds: the phases
+            {                                              // after the walk work on the flag ARRAYS
 #ifdef CP_PROF_WALK
               if (lane == 0) atomicAdd(&g_live_prof[6],1ull);
 #endif
@@ -1383,6 +1430,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
                   if (F.fo[q]) wall[i] = F.fo[q];
                   if (F.fs[q]) R.wall_s[i] = F.fs[q];
                 }
+              if (lane < FW_XCAP) R.wall_s[s_x[lane]] = (CP_W_WALL_S|CP_W_PAIRED_S);     // (the list is full)
               onchip = false;                              // (until the end of round 5 such a read started the replay over on the arrays:
               wave_sync();                                 //  11 % of the bench's reads, twice through the most expensive phase)
             }
@@ -1427,6 +1475,19 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
     }
   }
   R.use_win = 0; R.spec_wallnow = 0;
+  int n_x = 0;                                          // off-list SELF walls of a read whose flags stayed on chip, in increasing order
+  if (onchip)
+    { n_x = __builtin_amdgcn_readfirstlane(s_nx);
+      if (n_x > FW_XCAP) n_x = FW_XCAP;
+      if (lane == 0)
+        for (int a = 1; a < n_x; a++)
+          { const uint16_t v = s_x[a];
+            int b = a-1;
+            while (b >= 0 && s_x[b] > v) { s_x[b+1] = s_x[b]; b--; }
+            s_x[b+1] = v;
+          }
+      wave_sync();
+    }
   PH_STAMP(1);
   int NS = __shfl(R.eidx,0), NO = __shfl(R.oidx,1);
   int overflow = __shfl(R.overflow,0) | __shfl(R.overflow,1);
@@ -1536,7 +1597,7 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
               wave_sync();                             // lane 0's flag updates of the previous wall
               if (F.fo[qq] & CP_W_PAIRED_M)            // may have been set by an earlier wall
                 continue;
-              cf_wall_mult(&R,F,qq,NS,&midx);
+              cf_wall_mult(&R,F,qq,NS,&midx,s_x,n_x);
             }
         }
     }
