@@ -1540,6 +1540,9 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   // the largest end among the intervals that begin before i exceeds i (a prefix maximum over the lanes, one interval
   // each).  Every candidate used to test every interval (45 of them, two LDS reads each, and most candidates lie in none).
   bool unwalled = false;
+#ifdef CP_PROF_WALK
+  if (lane == 0) { atomicAdd(&g_emit_prof[0],NS <= WAVE ? 1ull : 0ull); atomicAdd(&g_emit_prof[1],(unsigned long long)NS); }
+#endif
   if (cf && !R.eintvl.big && NS <= WAVE)
     { NS = wave_sort_ev(R.eintvl,NS,R.ointvl.g,true);
       int b_k = 0x7fffffff, pm = -1;
@@ -1646,6 +1649,9 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   // interval of the last run, as the reference does from there.  (One lane used to walk the whole list, four dependent
   // LDS reads per interval, while 63 waited.)  Lists beyond 64 intervals or close to a capacity take the one-lane scan.
   int merge_from = 0;
+#ifdef CP_PROF_WALK
+  if (lane == 0) { atomicAdd(&g_emit_prof[2],NS <= WAVE ? 1ull : 0ull); atomicAdd(&g_emit_prof[3],(unsigned long long)NS); }
+#endif
   if (!R.eintvl.big && NS >= 2 && NS <= WAVE)
     { cp_eintvl x = { 0, 0, 0. };
       if (lane < NS) x = R.eintvl.l[lane];
@@ -1697,6 +1703,9 @@ k_find_wall(const cp_dev_params *__restrict__ P, const char *__restrict__ seq, c
   // component starts / ends in s_cb / s_ce.
   EM_LT0();
   int C = 0;
+#ifdef CP_PROF_WALK
+  if (lane == 0) { atomicAdd(&g_emit_prof[4],NS <= WAVE ? 1ull : 0ull); atomicAdd(&g_emit_prof[5],(unsigned long long)NS); }
+#endif
   if (NS <= WAVE && ccap >= WAVE)                       // a lane per E-interval: a component starts where b exceeds every end before it
     { int b_k = 0, e_k = -1;
       if (lane < NS) { b_k = R.eintvl.b(lane); e_k = R.eintvl.e(lane); }

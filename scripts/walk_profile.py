@@ -43,11 +43,7 @@ for k in (0, 7, 6, 1, 2, 3, 4, 8, 5):
     print("  %-34s %12d %12.1f      %d / %d" % (pn[k], ph[k], ph[12 + k] / b.nreads, ph[24 + k] >> 32, ph[24 + k] & 0xffffffff))
 print("replay chunks %d (%.1f tasks each): dependency rounds per chunk %.2f with the hashed table, %.2f with exact key comparisons"
       % (lv[2], lv[3] / max(1, lv[2]), lv[0] / max(1, lv[2]), lv[1] / max(1, lv[2])))
-print("inside the live-task evaluation (wave time, ticks per read): own P(error) %.0f, low-complexity partner search %.0f,"
-      " its filters + P(error) %.0f, six high-complexity partners %.0f" % tuple(lv[k] / b.nreads for k in range(4)))
-print("reads %d: memo on chip %d, flags on chip to the end %d, started over with the flags in HBM %d, flags on chip after the walk %d" %
+print("E-interval lists of at most 64 (the wave-parallel forms): before the un-wall %d reads (mean length %.1f), before the merge %d (%.1f), before the components %d (%.1f)"
+      % (em[0], em[1] / b.nreads / 2, em[2], em[3] / b.nreads / 2, em[4], em[5] / b.nreads / 2))
+print("reads %d: memo on chip %d, flags on chip to the end %d, sent their flags to the arrays after the replay (more off-list SELF walls than slots) %d, flags on chip after the walk %d" %
       (b.nreads, lv[4], lv[5], lv[6], lv[7]))
-print("inside phase 5 (wave time, ticks per read): boundaries %.0f, make_interval %.0f, find_rel / correct_wall_cnt %.0f, record stores %.0f, compaction of the reliable ones %.0f"
-      % tuple(em[k] / b.nreads for k in range(5)))
-print("inside find_rel (wave time of the lanes that get there): windows + first sum %.0f, scans + the other three sums %.0f, logp_trans look-up + tests %.0f"
-      % tuple(em[k] / b.nreads for k in (5, 6, 7)))
