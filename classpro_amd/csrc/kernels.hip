@@ -2613,6 +2613,11 @@ k_classify_rel_grp(const cp_dev_params *__restrict__ P, const int64_t *__restric
   COV[CP_HAPLO] = __shfl(COV[CP_HAPLO],leadlane);
   COV[CP_DIPLO] = __shfl(COV[CP_DIPLO],leadlane);
   if (M == 0 || ql >= 2*LD) rerun = 0;
+#ifdef CP_PROF_WALK
+  { const uint64_t rm = __ballot(lead && rerun != 0), lm_ = __ballot(lead);      // (read, direction) pairs that repeat the pass / all; waves that do
+    if (lane == 0) { atomicAdd(&g_emit_prof[6],(unsigned long long)__popcll(rm) | ((unsigned long long)__popcll(lm_) << 32)); atomicAdd(&g_emit_prof[7],(rm ? 1ull : 0ull) | (1ull << 32)); }
+  }
+#endif
   if (__ballot(rerun != 0))
     rel_grp_pass<MAXM,G,WPB>(P,S,T,pe0,pe_stride,M,plen,rerun != 0,COV);
   double hdrr = 1.;
@@ -2853,6 +2858,9 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
   const uint64_t glm = (L == 64) ? ~0ull : ((1ull << L)-1);
   int pass = 0, it = 0;                                    // class_unrel.c:260-274, position of this read
   bool done = (N == 0) || (nnf == 0);
+#ifdef CP_PROF_WALK
+  int prof_rounds[2] = { 0, 0 };
+#endif
   while (__ballot(!done) != 0)
       { int mypos = it+sub;                                // order position of this slot's update
         int cover = (it+K < nnf) ? it+K : nnf;             // the round settles the positions [it, cover) if every slot commits
@@ -3023,12 +3031,20 @@ k_classify_unrel_grp(const cp_dev_params *__restrict__ P, int nreads, cp_intvl *
               }
           }
         newit = __shfl(newit,gbase);
+#ifdef CP_PROF_WALK
+        if (!done) prof_rounds[pass]++;
+#endif
         if (!done)
           { it = newit;
             if (it >= nnf) { it = 0; pass++; if (pass == 2) done = true; }
           }
         wave_sync();
       }
+#ifdef CP_PROF_WALK
+  if (ql == 0 && N > 0 && MINN == 0)                       // rounds of the first / second sweep, non-fixed intervals, reads (main class)
+    { atomicAdd(&g_phase_sum[9],(unsigned long long)prof_rounds[0]); atomicAdd(&g_phase_max[9],(unsigned long long)prof_rounds[1]);
+      atomicAdd(&g_phase_sum[10],(unsigned long long)nnf); atomicAdd(&g_phase_sum[11],1ull); }
+#endif
   if (pcls_all)                                            // whole-path calls: 4 bytes per interval for k_paint_labels instead of a
     for (int k = ql; k < N; k += L)                        // one-byte store into every 48-byte record (CP_PCLS)
       pcls_all[io+k] = CP_PCLS((int)S.e[g][k],S.asgn[g][k]);

@@ -44,6 +44,10 @@ for k in (0, 7, 6, 1, 2, 3, 4, 8, 5):
 print("replay chunks %d (%.1f tasks each): dependency rounds per chunk %.2f with the hashed table, %.2f with exact key comparisons"
       % (lv[2], lv[3] / max(1, lv[2]), lv[0] / max(1, lv[2]), lv[1] / max(1, lv[2])))
 print("E-interval lists of at most 64 (the wave-parallel forms): before the un-wall %d reads (mean length %.1f), before the merge %d (%.1f), before the components %d (%.1f)"
-      % (em[0], em[1] / b.nreads / 2, em[2], em[3] / b.nreads / 2, em[4], em[5] / b.nreads / 2))
+      % (em[0], em[1] / b.nreads, em[2], em[3] / b.nreads, em[4], em[5] / b.nreads))
+print("classify_unrel (main class): %.1f non-fixed intervals per read, %.1f speculation rounds in the first sweep (four slots per round), %.1f in the second"
+      % (ph[12 + 10] / max(1, ph[12 + 11]), ph[12 + 9] / max(1, ph[12 + 11]), ph[9] / max(1, ph[12 + 11])))
+print("classify_rel: %d of %d (read, direction) passes are repeated with adjusted coverages (class_rel.c:629-650); %d of %d waves run the DP a second time"
+      % (em[6] & 0xffffffff, em[6] >> 32, em[7] & 0xffffffff, em[7] >> 32))
 print("reads %d: memo on chip %d, flags on chip to the end %d, sent their flags to the arrays after the replay (more off-list SELF walls than slots) %d, flags on chip after the walk %d" %
       (b.nreads, lv[4], lv[5], lv[6], lv[7]))
