@@ -3121,7 +3121,13 @@ k_paint_labels(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ 
                 }
               e = s_end[k];
             }
+#ifdef PAINT_NT
+          { const cp_u4v v = { w[0], w[1], w[2], w[3] };     // the labels are written once and never read on the device
+            __builtin_nontemporal_store(v,reinterpret_cast<cp_u4v *>(dst+pc));
+          }
+#else
           dst[pc] = make_uint4(w[0],w[1],w[2],w[3]);
+#endif
         }
       const int t0 = h+16*npiece;                        // the bytes behind the last aligned piece
       if (t0+lane < rlen) lab[t0+lane] = (char)s_chr[find(t0+lane)];
