@@ -3121,8 +3121,9 @@ k_paint_labels(const cp_dev_params *__restrict__ P, const int64_t *__restrict__ 
                 }
               e = s_end[k];
             }
-#ifdef PAINT_NT
-          { const cp_u4v v = { w[0], w[1], w[2], w[3] };     // the labels are written once and never read on the device
+#ifdef PAINT_NT                                          // (A/B knob: non-temporal label stores, measured and dropped -- this kernel 1.18 -> 1.51 ms
+                                                         //  per 4 Gbases in the pipeline, the step 0.4-0.9 % slower: profiles/r05_paint_nt_fw5_ab.txt)
+          { const cp_u4v v = { w[0], w[1], w[2], w[3] };
             __builtin_nontemporal_store(v,reinterpret_cast<cp_u4v *>(dst+pc));
           }
 #else
