@@ -4,7 +4,7 @@ oracle on adversarial and tail-run reads made for many K, -r and coverage settin
 oracle/_ref holds the GSL-free part of the reference's wall.c), BOTH against the reference's own per-read functions
 (Ref.classify_read: context.c -> wall.c:245-1051 -> class_rel.c -> class_unrel.c -> paint); the reads the oracle rejects
 must be the reads on which the reference exit(1)s.  With CP_SANITIZE=1 and libasan preloaded (see scripts/sanitize.sh) the
-oracle and the harness also run under ASan + UBSan.      python scripts/fuzz_host.py [seeds=3]"""
+oracle and the harness also run under ASan + UBSan.      python scripts/fuzz_host.py [seeds=3] [first_seed=0]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -21,6 +21,7 @@ conftest.build_if_changed(out, ["g++", "-O2", "-fPIC", "-shared", "-ffp-contract
 H = C.CDLL(out)
 H.hh_params_new.restype = C.c_void_p
 nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 tot = bad = rej = refbad = 0
 REF = ref_wall_available() and os.environ.get("CP_SANITIZE") != "1"     # (the reference library is not a sanitizer build)
 for Kx in (15, 21, 32, 40, 50, 63):
@@ -29,7 +30,7 @@ for Kx in (15, 21, 32, 40, 50, 63):
             O = Oracle(Kx, rl, hc, dc)
             P = H.hh_params_new(Kx, rl, hc, dc)
             R = Ref(rl, hc, dc).wall_setup_from(O) if REF else None
-            for seed in range(nseeds):
+            for seed in range(first, first + nseeds):
                 a_s, a_p = adversarial_reads(7000 + seed + Kx, n=40, K=Kx)
                 t_s, t_p = tail_run_reads(8000 + seed + Kx, n=24, K=Kx)
                 for s, p in zip(a_s + t_s, a_p + t_p):

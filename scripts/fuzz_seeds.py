@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off soak of the -s seed kernel: random label strings / profiles / odd letters (the generator of
 tests/test_gpu_seeds.py::test_seeds_random_labels_odd_letters) over many more cases, vs the oracle.
-python scripts/fuzz_seeds.py [cases=400]"""
+python scripts/fuzz_seeds.py [cases=400] [rng_seed=2024] [K,K,...=40,21,63]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,13 +9,14 @@ import numpy as np, torch
 from classpro_amd.api import Classifier, Batch
 from oracle.oracle import Oracle
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 400
-rng = np.random.default_rng(2024)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+KS = tuple(int(x) for x in sys.argv[3].split(',')) if len(sys.argv) > 3 else (40, 21, 63)
 letters = np.frombuffer(b"ACGTacgtNnUuRYKM", np.uint8)
 bad = tot = 0
-for Kx in (40, 21, 63):
+for Kx in KS:
     O = Oracle(Kx, 20000, 20, 40)
     clf = Classifier(K=Kx, read_len=20000, hcov=20, dcov=40)
-    for chunk in range(ncases // 3 // 25):
+    for chunk in range(ncases // len(KS) // 25):
         cases = []
         for rep_i in range(25):
             plen = int(rng.integers(1, 12000))
@@ -36,6 +37,7 @@ for Kx in (40, 21, 63):
             if not ok:
                 bad += 1
                 print("K", Kx, "chunk", chunk, "case", j, "plen", len(prof), "DIFFERS", flush=True)
+        if chunk % 4 == 3: print("K", Kx, "ok so far:", tot, "cases,", bad, "bad", flush=True)
     clf.close()
     print("K", Kx, "done:", tot, "cases,", bad, "bad", flush=True)
 print("TOTAL", tot, "cases", bad, "bad")
