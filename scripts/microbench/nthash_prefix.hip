@@ -7,7 +7,7 @@
 //        fh(i) = srol^(i+K-1)(P(i+K) ^ P(i)),  rh(i) = srol^-i(Q(i+K) ^ Q(i))   (scripts/proto/nthash_prefix.py has the derivation).
 // All three must agree on every k-mer (compared on the host; the first positions also against the literal fold on the CPU).
 //   hipcc --offload-arch=gfx950 -O3 -I classpro_amd/csrc scripts/microbench/nthash_prefix.hip -o build_diag/nthash_prefix
-//   build_diag/nthash_prefix [K=40] [Mbases=64] [S=0]
+//   build_diag/nthash_prefix [K=40] [Mbases=64] [S=0] [const]      (const: S and K as compile-time constants in Bs, for 16/40 and 64/40)
 // S > 0 (8, 16, 32 or 64): what the marks really hash -- SHORT taken segments of S k-mers each (about 16 in the seed bench), spread over
 // the sequence.  (A2s) a lane per k-mer, all segments' k-mers side by side, as sw_mark_all does; (Bs) a wave takes 64/S segments: their
 // base ranges [b, b+S+K-1) side by side, a lane per BASE, scanned straight across the segment borders -- P(p+K) ^ P(p) cancels whatever
@@ -127,8 +127,10 @@ __global__ void __launch_bounds__(256) k_table_seg(const char *seq, int64_t nseg
 }
 
 #define MAXB (WAVE+8*(KMAXT-1))                                    // bases of 64/S segments, S >= 8, K <= 64
-__global__ void __launch_bounds__(256) k_prefix_seg(const char *seq, int64_t nseg, int64_t stride, int S, int K, int *out)
+template <int CS, int CK>                                          // CS, CK > 0: S and K known to the compiler (divisions by constants); 0: run-time values
+__global__ void __launch_bounds__(256) k_prefix_seg(const char *seq, int64_t nseg, int64_t stride, int S_, int K_, int *out)
 { __shared__ uint64_t sP[4][MAXB+1], sQ[4][MAXB+1];
+  const int S = CS ? CS : S_, K = CK ? CK : K_;
   const int lane = threadIdx.x & (WAVE-1), w = threadIdx.x >> 6;
   const int per = WAVE/S, span = S+K-1, nbase = per*span;          // segments per wave, bases per segment, bases per wave
   const int64_t g0 = ((int64_t)blockIdx.x*4+w)*per;                // the wave's first segment
@@ -176,7 +178,7 @@ int main(int argc, char **argv)
   CK(hipMemcpy(d_seq,h.data(),(size_t)n,hipMemcpyHostToDevice));
   for (int v = 0; v < 3; v++) { CK(hipMalloc(&d_o[v],(size_t)nk*4)); CK(hipMemset(d_o[v],0xff,(size_t)nk*4)); }
   const unsigned nb = (unsigned)((nk+255)/256);
-  const char *name[3] = { "A1 fold on the ALU (cp_kmer_hash)", "A2 table of rotated seeds in LDS  ", S ? "Bs prefix-XOR over the base ranges" : "B  two prefix-XOR scans per tile  " };
+  const char *name[3] = { "A1 fold on the ALU (cp_kmer_hash)", "A2 table of rotated seeds in LDS  ", S ? (argc > 4 ? "Bs prefix-XOR, S and K constants  " : "Bs prefix-XOR over the base ranges") : "B  two prefix-XOR scans per tile  " };
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float ms[3];
   for (int v = 0; v < 3; v++)
@@ -185,7 +187,11 @@ int main(int argc, char **argv)
           if (S)
             { if (v == 0) hipLaunchKernelGGL(k_fold_seg,dim3(nb),dim3(256),0,0,d_seq,nseg,stride,S,K,d_o[0]);
               if (v == 1) hipLaunchKernelGGL(k_table_seg,dim3(nb),dim3(256),0,0,d_seq,nseg,stride,S,K,d_o[1]);
-              if (v == 2) hipLaunchKernelGGL(k_prefix_seg,dim3(nb),dim3(256),0,0,d_seq,nseg,stride,S,K,d_o[2]);
+              if (v == 2)
+                { if (S == 16 && K == 40 && argc > 4) hipLaunchKernelGGL((k_prefix_seg<16,40>),dim3(nb),dim3(256),0,0,d_seq,nseg,stride,S,K,d_o[2]);
+                  else if (S == 64 && K == 40 && argc > 4) hipLaunchKernelGGL((k_prefix_seg<64,40>),dim3(nb),dim3(256),0,0,d_seq,nseg,stride,S,K,d_o[2]);
+                  else hipLaunchKernelGGL((k_prefix_seg<0,0>),dim3(nb),dim3(256),0,0,d_seq,nseg,stride,S,K,d_o[2]);
+                }
               continue;
             }
           if (v == 0) hipLaunchKernelGGL(k_fold,dim3(nb),dim3(256),0,0,d_seq,n,K,d_o[0]);
